@@ -1,0 +1,420 @@
+// Batched FFT linear convolution for gfx950 (MI355X): three HBM passes per transform pair.
+//
+// Replaces scipy.signal.convolve(x, h, 'same'|'full') as called by the reference at
+//   core/impulse_response_estimator.py:151  (estimate: recording (*) inverse_filter, 'same')
+//   core/impulse_response.py:119,135        (equalize / convolve: 'full')
+//
+// One real channel x[L] is packed even/odd into z[n] = x[2n] + i x[2n+1] (Nc = nfft/2 complex
+// points, Nc = N1*N2, N2 = 4096, N1 = 16*R2) and transformed with a four-step FFT:
+//   pass A  cols_kernel<fwd>   : length-N1 column FFTs (stride N2), x w_Nc^(n2 k1)     -> ws[k1][n2]
+//   pass B  rows_kernel        : length-4096 row FFT -> real-FFT unpack * H * repack
+//                                (W = alpha Z[k] + beta conj Z[Nc-k]) -> row IFFT, in place
+//   pass C  cols_kernel<inv>   : x conj w_Nc^(n2 k1), column IFFTs, unpack + crop     -> out
+// The spectrum never leaves the transposed [k1][k2] order, so there is no transpose pass.
+// No MFMA: the work is butterflies (VALU) + LDS exchanges; the bound is HBM/MALL traffic.
+#pragma once
+#include "fft_regs.hip.h"
+
+namespace imp {
+
+constexpr int kN2 = 4096;        // row length (complex points)
+constexpr int kLogN2 = 12;
+constexpr int kRowPad = 272;     // LDS row pitch (float2) of the 16x256 exchange planes
+
+// ---------------------------------------------------------------------------------------------
+// Twiddle tables (device, fp32 rounded from fp64 on the host):
+//   tw_lo[m]  = exp(-2 pi i m / Nc),        m < 1024
+//   tw_hi[m]  = exp(-2 pi i 1024 m / Nc),   m < Nc/1024     (also gives w_N1^j = tw_hi[4 j])
+//   tw_row[m] = exp(-2 pi i m / 4096),      m < 4096
+// ---------------------------------------------------------------------------------------------
+struct Twiddles {
+  const cf* __restrict__ lo;
+  const cf* __restrict__ hi;
+  const cf* __restrict__ row;
+};
+
+__device__ __forceinline__ cf tw_nc(const Twiddles& tw, unsigned idx) {
+  cf a = tw.lo[idx & 1023u];
+  cf b = tw.hi[idx >> 10];
+  return cmul(a, b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loaders / storers for the column passes.  n1 = row (0..N1), n2 = column (0..4096).
+// ---------------------------------------------------------------------------------------------
+
+// Real channel, planar [B][ld] or interleaved frames [L][C] (elem_stride = C, chan offset folded
+// into the base): z = (x[2n], x[2n+1]) with zero fill beyond `len`.
+struct LoadRealPacked {
+  const float* __restrict__ base;   // channel 0, sample 0
+  long long chan_stride;            // elements between channels
+  long long elem_stride;            // elements between consecutive samples of a channel
+  long long len;                    // valid samples per channel
+  __device__ __forceinline__ cf operator()(int b, int n1, int n2) const {
+    long long n = ((long long)n1 << kLogN2) + n2;
+    long long i0 = 2 * n;
+    const float* p = base + (long long)b * chan_stride;
+    cf z = make_float2(0.f, 0.f);
+    if (i0 + 1 < len) {
+      if (elem_stride == 1 && ((reinterpret_cast<uintptr_t>(p + i0) & 7u) == 0)) {
+        z = *reinterpret_cast<const float2*>(p + i0);
+      } else {
+        z.x = p[i0 * elem_stride];
+        z.y = p[(i0 + 1) * elem_stride];
+      }
+    } else if (i0 < len) {
+      z.x = p[i0 * elem_stride];
+    }
+    return z;
+  }
+  // rows n1 >= this are entirely zero: skip their loads
+  __device__ __forceinline__ int live_rows() const {
+    long long nz = (len + 1) / 2;                       // complex points with data
+    return (int)((nz + kN2 - 1) >> kLogN2);
+  }
+};
+
+struct LoadWorkspace {
+  const cf* __restrict__ ws;   // [B][N1][4096]
+  int n1_total;
+  __device__ __forceinline__ cf operator()(int b, int n1, int n2) const {
+    return ws[((long long)b * n1_total + n1) * kN2 + n2];
+  }
+  __device__ __forceinline__ int live_rows() const { return n1_total; }
+};
+
+struct StoreWorkspace {
+  cf* __restrict__ ws;
+  int n1_total;
+  __device__ __forceinline__ void operator()(int b, int k1, int n2, cf v) const {
+    ws[((long long)b * n1_total + k1) * kN2 + n2] = v;
+  }
+};
+
+// Unpack y[2n] = re, y[2n+1] = im and keep the window [start, start+len) of the linear
+// convolution ('same': start = (M-1)/2, len = L; 'full': start = 0, len = L+M-1).
+struct StoreRealCrop {
+  float* __restrict__ base;
+  long long chan_stride;
+  long long elem_stride;
+  long long start;
+  long long len;
+  __device__ __forceinline__ void operator()(int b, int n1, int n2, cf v) const {
+    long long n = ((long long)n1 << kLogN2) + n2;
+    long long i0 = 2 * n - start;
+    float* p = base + (long long)b * chan_stride;
+    if (i0 >= 0 && i0 + 1 < len && elem_stride == 1 && ((reinterpret_cast<uintptr_t>(p + i0) & 7u) == 0)) {
+      *reinterpret_cast<float2*>(p + i0) = v;
+    } else {
+      if (i0 >= 0 && i0 < len) p[i0 * elem_stride] = v.x;
+      if (i0 + 1 >= 0 && i0 + 1 < len) p[(i0 + 1) * elem_stride] = v.y;
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Column pass.  Tile = TC columns x N1 rows, one thread = 16 rows of one column.
+//   thread (g, c): g = tid / TC in [0, R2), c = tid % TC; rows i = g + R2*j, j = 0..15
+//   FFT16 over j -> a ; x w_N1^(g a) ; LDS exchange ; FFT_R2 over g -> b ; output row = a + 16 b
+// DIR < 0: forward, four-step twiddle applied to the outputs (pass A).
+// DIR > 0: inverse, conj four-step twiddle applied to the inputs (pass C).
+// LDS plane index = a*T + tid with the column as the lane index: conflict-free both ways.
+// ---------------------------------------------------------------------------------------------
+template <int R2>
+struct ColsCfg {
+  static constexpr int TC = (R2 >= 16) ? 32 : 64;
+  static constexpr int T = TC * R2;
+  static constexpr int G = 16 / R2;            // groups of R2 per thread in the 2nd stage
+  static constexpr size_t lds_bytes = (R2 > 1) ? sizeof(cf) * 16 * T : 0;
+};
+
+template <int R2, int DIR, class Load, class Store>
+__global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st, Twiddles tw,
+                                                                int tiles_per_chan) {
+  using Cfg = ColsCfg<R2>;
+  constexpr int TC = Cfg::TC, T = Cfg::T, G = Cfg::G;
+  constexpr int N1 = 16 * R2;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cf* buf = reinterpret_cast<cf*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int c = tid % TC;
+  const int g = tid / TC;
+  const int b = blockIdx.x / tiles_per_chan;
+  const int tile = blockIdx.x - b * tiles_per_chan;
+  const int n2 = tile * TC + c;
+
+  cf v[16];
+  const int live = ld.live_rows();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int row = g + R2 * j;
+    cf z = make_float2(0.f, 0.f);
+    if (row < live) {
+      z = ld(b, row, n2);
+      if constexpr (DIR > 0) z = cmulc(z, tw_nc(tw, (unsigned)n2 * (unsigned)row));
+    }
+    v[j] = z;
+  }
+
+  fft16<DIR>(v);   // index a
+
+  if constexpr (R2 > 1) {
+    // w_N1^(g a) = tw_hi[4 g a]  (Nc/1024 = 4 N1 entries)
+#pragma unroll
+    for (int a = 1; a < 16; ++a) v[a] = ctw<DIR>(v[a], tw.hi[4 * g * a]);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) buf[a * T + tid] = v[a];
+    __syncthreads();
+    // thread (q = g, c) now owns a in {q*G .. q*G+G-1}, all g'
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int gp = 0; gp < R2; ++gp) v[i * R2 + gp] = buf[(g * G + i) * T + gp * TC + c];
+    fft_groups<DIR, R2>(v);
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int kb = 0; kb < R2; ++kb) {
+        const int row = (g * G + i) + 16 * kb;
+        cf z = v[i * R2 + kb];
+        if constexpr (DIR < 0) z = cmul(z, tw_nc(tw, (unsigned)n2 * (unsigned)row));
+        st(b, row, n2, z);
+      }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+      cf z = v[a];
+      if constexpr (DIR < 0) z = cmul(z, tw_nc(tw, (unsigned)n2 * (unsigned)a));
+      st(b, a, n2, z);
+    }
+  }
+  (void)N1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row pass (pass B).  One workgroup = 512 threads = two rows (k1, N1-k1), or the two
+// self-paired rows (0, N1/2) when pair == 0.  Everything between the load and the store of a
+// row happens in registers + 68 KiB of LDS:
+//   fwd FFT4096 = [FFT16, x w4096^(t a), X1, FFT16, x w256^(t2 b), X2, FFT16]
+//   middle      = W[k] = alpha[k] Z[k] + beta[k] conj(Z[Nc-k])   (partner read through LDS)
+//   inv FFT4096 = mirror image with conjugate twiddles
+// Register layout after the forward FFT: thread u = 16*ka + kb1 holds k2 = ka + 16 kb1 + 256 kb2
+// in v[kb2]; the plan stores alpha/beta in exactly that order: ab[k1][kb2*256 + u].
+// ---------------------------------------------------------------------------------------------
+struct RowsArgs {
+  cf* __restrict__ ws;             // [B][N1][4096], in place
+  const float4* __restrict__ ab;   // [HB][N1][4096] (alpha.x, alpha.y, beta.x, beta.y)
+  long long ab_chan_stride;        // 0: one spectrum shared by all channels; N1*4096: per channel
+  int n1_total;
+  int log_n1;
+  int npairs;                      // N1/2: pair 0 = rows (0, N1/2), pair p = rows (p, N1-p)
+};
+
+__global__ __launch_bounds__(512) void rows_kernel(RowsArgs args, Twiddles tw) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cf* lds = reinterpret_cast<cf*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int half = tid >> 8;
+  const int t = tid & 255;
+  const int N1 = args.n1_total;
+  const int b = blockIdx.x / args.npairs;
+  const int pair = blockIdx.x - b * args.npairs;
+  const int rowA = pair;
+  const int rowB = (pair == 0) ? (N1 >> 1) : (N1 - pair);
+  const int k1 = half ? rowB : rowA;
+  cf* buf = lds + half * (16 * kRowPad);
+
+  cf* wsrow = args.ws + ((long long)b * N1 + k1) * kN2;
+
+  const int hi4 = t >> 4;   // "ka" of the (ka, x) thread naming
+  const int lo4 = t & 15;
+
+  cf v[16], u[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = wsrow[t + 256 * j];
+
+  // ---- forward FFT4096 ----
+  fft16<-1>(v);                                            // over j -> a
+#pragma unroll
+  for (int a = 1; a < 16; ++a) v[a] = cmul(v[a], tw.row[t * a]);
+#pragma unroll
+  for (int a = 0; a < 16; ++a) buf[a * kRowPad + t] = v[a];
+  __syncthreads();
+  // thread (ka = hi4, t2 = lo4) gathers j2 = 0..15 (t = 16 j2 + t2)
+#pragma unroll
+  for (int j2 = 0; j2 < 16; ++j2) u[j2] = buf[hi4 * kRowPad + 16 * j2 + lo4];
+  fft16<-1>(u);                                            // over j2 -> kb1
+#pragma unroll
+  for (int q = 1; q < 16; ++q) u[q] = cmul(u[q], tw.row[16 * lo4 * q]);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) buf[hi4 * kRowPad + lo4 * 17 + q] = u[q];
+  __syncthreads();
+  // thread (ka = hi4, kb1 = lo4) gathers t2 = 0..15
+#pragma unroll
+  for (int t2 = 0; t2 < 16; ++t2) v[t2] = buf[hi4 * kRowPad + t2 * 17 + lo4];
+  fft16<-1>(v);                                            // over t2 -> kb2
+  __syncthreads();
+
+  // ---- partner exchange: plane [kb2][u] ----
+#pragma unroll
+  for (int q = 0; q < 16; ++q) buf[q * kRowPad + t] = v[q];
+  __syncthreads();
+
+  const float4* abrow = args.ab + (long long)b * args.ab_chan_stride + (long long)k1 * kN2;
+  const unsigned ncmask = ((unsigned)N1 << kLogN2) - 1u;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const unsigned k2 = (unsigned)hi4 + 16u * (unsigned)lo4 + 256u * (unsigned)q;
+    const unsigned k = (unsigned)k1 + ((unsigned)k2 << args.log_n1);
+    const unsigned kp = (0u - k) & ncmask;                 // (Nc - k) mod Nc
+    const unsigned prow = kp & (unsigned)(N1 - 1);
+    const unsigned pk2 = kp >> args.log_n1;
+    const int phalf = (prow == (unsigned)rowA) ? 0 : 1;
+    const cf zp = lds[phalf * (16 * kRowPad) + (pk2 >> 8) * kRowPad + 16 * (pk2 & 15u) + ((pk2 >> 4) & 15u)];
+    const float4 ab = abrow[q * 256 + t];
+    const cf z = v[q];
+    cf w;
+    // alpha*z + beta*conj(zp)
+    w.x = ab.x * z.x - ab.y * z.y + ab.z * zp.x + ab.w * zp.y;
+    w.y = ab.x * z.y + ab.y * z.x + ab.w * zp.x - ab.z * zp.y;
+    if (k == 0u) {
+      // DC / Nyquist share bin 0 of the packed transform: ab.x = H[0]/Nc, ab.z = H[Nc]/Nc
+      const float x0 = z.x + z.y, xn = z.x - z.y;
+      w.x = 0.5f * (x0 * ab.x + xn * ab.z);
+      w.y = 0.5f * (x0 * ab.x - xn * ab.z);
+    }
+    u[q] = w;
+  }
+  __syncthreads();
+
+  // ---- inverse FFT4096 (mirror) ----
+  fft16<+1>(u);                                            // over kb2 -> t2
+#pragma unroll
+  for (int q = 1; q < 16; ++q) u[q] = cmulc(u[q], tw.row[16 * q * lo4]);
+#pragma unroll
+  for (int t2 = 0; t2 < 16; ++t2) buf[hi4 * kRowPad + t2 * 17 + lo4] = u[t2];
+  __syncthreads();
+  // thread (ka = hi4, t2 = lo4) gathers kb1 = 0..15
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = buf[hi4 * kRowPad + lo4 * 17 + q];
+  fft16<+1>(v);                                            // over kb1 -> j2
+#pragma unroll
+  for (int j2 = 0; j2 < 16; ++j2) {
+    const int tt = 16 * j2 + lo4;
+    v[j2] = cmulc(v[j2], tw.row[tt * hi4]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j2 = 0; j2 < 16; ++j2) buf[hi4 * kRowPad + 16 * j2 + lo4] = v[j2];
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 16; ++a) u[a] = buf[a * kRowPad + t];
+  fft16<+1>(u);                                            // over ka -> j
+#pragma unroll
+  for (int j = 0; j < 16; ++j) wsrow[t + 256 * j] = u[j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Spectrum pass: same forward row FFT, but instead of filtering it turns the packed transform
+// of a real filter h into the alpha/beta planes (device-side plan build for per-channel FIRs,
+// reference core/impulse_response.py:110-119 equalize).  scale = 1/Nc.
+//   H[k]    = E + w^k O,  conj(H[Nc-k]) = E - w^k O,  E = (Z[k]+conj Z[Nc-k])/2, O = -i (Z[k]-conj Z[Nc-k])/2
+//   alpha   = (H[k](1+s) + conj(H[Nc-k])(1-s)) / 2 * scale,  s = Im w^k = -sin(2 pi k / nfft)
+//   beta    = i c (H[k] - conj(H[Nc-k])) / 2 * scale,          c = Re w^k
+// ---------------------------------------------------------------------------------------------
+struct SpectrumArgs {
+  const cf* __restrict__ ws;       // [HB][N1][4096] pass-A output of the filters
+  float4* __restrict__ ab;         // [HB][N1][4096]
+  const cf* __restrict__ tw_nfft_lo;   // exp(-2 pi i m / nfft), m < 2048
+  const cf* __restrict__ tw_nfft_hi;   // exp(-2 pi i 2048 m / nfft), m < Nc/1024
+  int n1_total;
+  int log_n1;
+  int npairs;
+  float scale;
+};
+
+__global__ __launch_bounds__(512) void spectrum_kernel(SpectrumArgs args, Twiddles tw) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cf* lds = reinterpret_cast<cf*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int half = tid >> 8;
+  const int t = tid & 255;
+  const int N1 = args.n1_total;
+  const int b = blockIdx.x / args.npairs;
+  const int pair = blockIdx.x - b * args.npairs;
+  const int rowA = pair;
+  const int rowB = (pair == 0) ? (N1 >> 1) : (N1 - pair);
+  const int k1 = half ? rowB : rowA;
+  cf* buf = lds + half * (16 * kRowPad);
+  const cf* wsrow = args.ws + ((long long)b * N1 + k1) * kN2;
+  const int hi4 = t >> 4;
+  const int lo4 = t & 15;
+
+  cf v[16], u[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = wsrow[t + 256 * j];
+  fft16<-1>(v);
+#pragma unroll
+  for (int a = 1; a < 16; ++a) v[a] = cmul(v[a], tw.row[t * a]);
+#pragma unroll
+  for (int a = 0; a < 16; ++a) buf[a * kRowPad + t] = v[a];
+  __syncthreads();
+#pragma unroll
+  for (int j2 = 0; j2 < 16; ++j2) u[j2] = buf[hi4 * kRowPad + 16 * j2 + lo4];
+  fft16<-1>(u);
+#pragma unroll
+  for (int q = 1; q < 16; ++q) u[q] = cmul(u[q], tw.row[16 * lo4 * q]);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) buf[hi4 * kRowPad + lo4 * 17 + q] = u[q];
+  __syncthreads();
+#pragma unroll
+  for (int t2 = 0; t2 < 16; ++t2) v[t2] = buf[hi4 * kRowPad + t2 * 17 + lo4];
+  fft16<-1>(v);
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) buf[q * kRowPad + t] = v[q];
+  __syncthreads();
+
+  float4* abrow = args.ab + ((long long)b * N1 + k1) * kN2;
+  const unsigned ncmask = ((unsigned)N1 << kLogN2) - 1u;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const unsigned k2 = (unsigned)hi4 + 16u * (unsigned)lo4 + 256u * (unsigned)q;
+    const unsigned k = (unsigned)k1 + ((unsigned)k2 << args.log_n1);
+    const unsigned kp = (0u - k) & ncmask;
+    const unsigned prow = kp & (unsigned)(N1 - 1);
+    const unsigned pk2 = kp >> args.log_n1;
+    const int phalf = (prow == (unsigned)rowA) ? 0 : 1;
+    const cf zp = lds[phalf * (16 * kRowPad) + (pk2 >> 8) * kRowPad + 16 * (pk2 & 15u) + ((pk2 >> 4) & 15u)];
+    const cf z = v[q];
+    const cf zc = make_float2(zp.x, -zp.y);                 // conj Z[Nc-k]
+    const cf E = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y + zc.y));
+    const cf D = make_float2(0.5f * (z.x - zc.x), 0.5f * (z.y - zc.y));
+    const cf O = make_float2(D.y, -D.x);                    // -i D
+    const cf wk = cmul(args.tw_nfft_lo[k & 2047u], args.tw_nfft_hi[k >> 11]);
+    const cf wO = cmul(wk, O);
+    const cf Hk = cadd(E, wO);
+    const cf Gk = csub(E, wO);                              // conj(H[Nc-k])
+    const float s = wk.y, c = wk.x;
+    float4 out;
+    out.x = 0.5f * args.scale * (Hk.x * (1.f + s) + Gk.x * (1.f - s));
+    out.y = 0.5f * args.scale * (Hk.y * (1.f + s) + Gk.y * (1.f - s));
+    const cf dH = csub(Hk, Gk);
+    out.z = 0.5f * args.scale * (-c * dH.y);                // i c dH
+    out.w = 0.5f * args.scale * (c * dH.x);
+    if (k == 0u) {
+      out.x = args.scale * (z.x + z.y);                     // H[0]
+      out.y = 0.f;
+      out.z = args.scale * (z.x - z.y);                     // H[Nc]
+      out.w = 0.f;
+    }
+    abrow[q * 256 + t] = out;
+  }
+}
+
+}  // namespace imp

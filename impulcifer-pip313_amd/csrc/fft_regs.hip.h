@@ -1,0 +1,133 @@
+// In-register radix-2/4/8/16 butterflies for gfx950 (wave64, fp32).
+// Every array index below is a compile-time constant after unrolling, so the
+// 16 complex values of a thread stay in VGPRs (32 regs) - no scratch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace imp {
+
+typedef float2 cf;  // complex fp32: .x = re, .y = im
+
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+  return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+// a * conj(b)
+__device__ __forceinline__ cf cmulc(cf a, cf b) {
+  return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+}
+__device__ __forceinline__ cf cconj(cf a) { return make_float2(a.x, -a.y); }
+// multiply by twiddle w (forward table value); DIR<0 -> a*w, DIR>0 -> a*conj(w)
+template <int DIR>
+__device__ __forceinline__ cf ctw(cf a, cf w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
+
+// DIR = -1: forward kernel exp(-2 pi i nk/N); DIR = +1: inverse (unnormalised).
+template <int DIR>
+__device__ __forceinline__ void bfly2(cf& a, cf& b) {
+  cf t = a;
+  a = cadd(t, b);
+  b = csub(t, b);
+}
+
+template <int DIR>
+__device__ __forceinline__ void bfly4(cf& a, cf& b, cf& c, cf& d) {
+  cf t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
+  // forward: (-i)*t3 ; inverse: (+i)*t3
+  cf r3 = DIR < 0 ? make_float2(t3.y, -t3.x) : make_float2(-t3.y, t3.x);
+  a = cadd(t0, t2);
+  b = cadd(t1, r3);
+  c = csub(t0, t2);
+  d = csub(t1, r3);
+}
+
+// multiply by exp(DIR * 2 pi i * m / 16) with compile-time m
+template <int DIR, int M>
+__device__ __forceinline__ cf mul_w16(cf a) {
+  constexpr float C1 = 0.92387953251128675613f;  // cos(pi/8)
+  constexpr float S1 = 0.38268343236508977173f;  // sin(pi/8)
+  constexpr float R = 0.70710678118654752440f;   // sqrt(1/2)
+  constexpr int m = M & 15;
+  // forward value w = (cr, -si); inverse = conj
+  constexpr float cr = (m == 0) ? 1.f : (m == 1) ? C1 : (m == 2) ? R : (m == 3) ? S1 : (m == 4) ? 0.f
+                     : (m == 5) ? -S1 : (m == 6) ? -R : (m == 7) ? -C1 : (m == 8) ? -1.f
+                     : (m == 9) ? -C1 : (m == 10) ? -R : (m == 11) ? -S1 : (m == 12) ? 0.f
+                     : (m == 13) ? S1 : (m == 14) ? R : C1;
+  constexpr float sf = (m == 0) ? 0.f : (m == 1) ? S1 : (m == 2) ? R : (m == 3) ? C1 : (m == 4) ? 1.f
+                     : (m == 5) ? C1 : (m == 6) ? R : (m == 7) ? S1 : (m == 8) ? 0.f
+                     : (m == 9) ? -S1 : (m == 10) ? -R : (m == 11) ? -C1 : (m == 12) ? -1.f
+                     : (m == 13) ? -C1 : (m == 14) ? -R : -S1;
+  // forward twiddle = cr - i*sf ; inverse = cr + i*sf
+  constexpr float wi = DIR < 0 ? -sf : sf;
+  if constexpr (m == 0) return a;
+  else if constexpr (m == 4) return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+  else if constexpr (m == 8) return make_float2(-a.x, -a.y);
+  else if constexpr (m == 12) return DIR < 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+  else return make_float2(fmaf(a.x, cr, -a.y * wi), fmaf(a.x, wi, a.y * cr));
+}
+
+// 16-point DFT, natural order in / natural order out.
+template <int DIR>
+__device__ __forceinline__ void fft16(cf (&v)[16]) {
+  // n = 4*n1 + n2 ; k = k1 + 4*k2
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) bfly4<DIR>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+  // now v[4*k1 + n2] = A[n2][k1]; twiddle w16^(n2*k1)
+  v[4 * 1 + 1] = mul_w16<DIR, 1>(v[4 * 1 + 1]);
+  v[4 * 1 + 2] = mul_w16<DIR, 2>(v[4 * 1 + 2]);
+  v[4 * 1 + 3] = mul_w16<DIR, 3>(v[4 * 1 + 3]);
+  v[4 * 2 + 1] = mul_w16<DIR, 2>(v[4 * 2 + 1]);
+  v[4 * 2 + 2] = mul_w16<DIR, 4>(v[4 * 2 + 2]);
+  v[4 * 2 + 3] = mul_w16<DIR, 6>(v[4 * 2 + 3]);
+  v[4 * 3 + 1] = mul_w16<DIR, 3>(v[4 * 3 + 1]);
+  v[4 * 3 + 2] = mul_w16<DIR, 6>(v[4 * 3 + 2]);
+  v[4 * 3 + 3] = mul_w16<DIR, 9>(v[4 * 3 + 3]);
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) bfly4<DIR>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+  // v[4*k1 + k2] = X[k1 + 4*k2] -> transpose the 4x4 index grid
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = a + 1; b < 4; ++b) {
+      cf t = v[4 * a + b];
+      v[4 * a + b] = v[4 * b + a];
+      v[4 * b + a] = t;
+    }
+}
+
+// 8-point DFT on v[0..7] (natural in / natural out).
+template <int DIR>
+__device__ __forceinline__ void fft8(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4, cf& x5, cf& x6, cf& x7) {
+  // n = 2*n1 + n2 ; k = k1 + 4*k2
+  bfly4<DIR>(x0, x2, x4, x6);   // n2 = 0 -> A[0][k1] in x0,x2,x4,x6
+  bfly4<DIR>(x1, x3, x5, x7);   // n2 = 1 -> A[1][k1] in x1,x3,x5,x7
+  x3 = mul_w16<DIR, 2>(x3);     // w8^1
+  x5 = mul_w16<DIR, 4>(x5);     // w8^2
+  x7 = mul_w16<DIR, 6>(x7);     // w8^3
+  bfly2<DIR>(x0, x1);           // k1=0: X[0], X[4]
+  bfly2<DIR>(x2, x3);           // k1=1: X[1], X[5]
+  bfly2<DIR>(x4, x5);           // k1=2: X[2], X[6]
+  bfly2<DIR>(x6, x7);           // k1=3: X[3], X[7]
+  // currently: x0=X0 x1=X4 x2=X1 x3=X5 x4=X2 x5=X6 x6=X3 x7=X7
+  cf t1 = x1, t2 = x2, t3 = x3, t4 = x4, t5 = x5, t6 = x6;
+  x1 = t2; x2 = t4; x3 = t6; x4 = t1; x5 = t3; x6 = t5;
+}
+
+// R-point DFT applied to the G = 16/R independent groups v[i*R .. i*R+R-1].
+template <int DIR, int R>
+__device__ __forceinline__ void fft_groups(cf (&v)[16]) {
+  if constexpr (R == 16) {
+    fft16<DIR>(v);
+  } else if constexpr (R == 8) {
+    fft8<DIR>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    fft8<DIR>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);
+  } else if constexpr (R == 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bfly4<DIR>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+  } else if constexpr (R == 2) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bfly2<DIR>(v[2 * i], v[2 * i + 1]);
+  }
+}
+
+}  // namespace imp

@@ -1,0 +1,850 @@
+// libimpulse_hip.so - host side of the C ABI declared in include/impulse_hip.h.
+// Built with: hipcc --offload-arch=gfx950 -O3 -shared -fPIC impulse_hip.hip -o libimpulse_hip.so
+// gfx950 only; no torch, no rocFFT/hipFFT, no RCCL linkage (the one broadcast of the filter
+// spectrum is done by the caller on the buffer returned by imp_plan_spectrum).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/impulse_hip.h"
+#include "conv_kernels.hip.h"
+#include "ir_kernels.hip.h"
+
+using imp::cf;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(IMP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                  \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct TwSet {
+  cf* lo = nullptr;       // exp(-2 pi i m / Nc), m < 1024
+  cf* hi = nullptr;       // exp(-2 pi i 1024 m / Nc), m < Nc/1024
+  cf* nfft_lo = nullptr;  // exp(-2 pi i m / nfft), m < 2048
+  cf* nfft_hi = nullptr;  // exp(-2 pi i 2048 m / nfft), m < Nc/1024 (only Nc/2048 used)
+};
+
+struct imp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  cf* tw_row = nullptr;                 // exp(-2 pi i m / 4096)
+  std::map<int, TwSet> tw_by_log_n1;    // keyed by log2(N1)
+  std::mutex mu;
+  // scratch for the small ragged kernels
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+static int ctx_bind(imp_ctx* ctx) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  return IMP_OK;
+}
+
+static int upload_twiddle(cf** dptr, size_t n, double step_num, double denom, hipStream_t s) {
+  std::vector<cf> h(n);
+  for (size_t m = 0; m < n; ++m) {
+    // angle = -2 pi * (step_num * m) / denom, reduced exactly in integers first
+    double frac = std::fmod(step_num * (double)m, denom) / denom;
+    double ang = -2.0 * M_PI * frac;
+    h[m] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+  }
+  HIP_TRY(hipMalloc((void**)dptr, n * sizeof(cf)));
+  HIP_TRY(hipMemcpyAsync(*dptr, h.data(), n * sizeof(cf), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return IMP_OK;
+}
+
+static int ctx_twiddles(imp_ctx* ctx, int log_n1, TwSet* out) {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  auto it = ctx->tw_by_log_n1.find(log_n1);
+  if (it != ctx->tw_by_log_n1.end()) {
+    *out = it->second;
+    return IMP_OK;
+  }
+  const double Nc = (double)((int64_t)1 << (log_n1 + imp::kLogN2));
+  TwSet t;
+  int rc;
+  if ((rc = upload_twiddle(&t.lo, 1024, 1.0, Nc, ctx->stream))) return rc;
+  if ((rc = upload_twiddle(&t.hi, (size_t)(Nc / 1024), 1024.0, Nc, ctx->stream))) return rc;
+  if ((rc = upload_twiddle(&t.nfft_lo, 2048, 1.0, 2.0 * Nc, ctx->stream))) return rc;
+  if ((rc = upload_twiddle(&t.nfft_hi, (size_t)(Nc / 1024), 2048.0, 2.0 * Nc, ctx->stream))) return rc;
+  ctx->tw_by_log_n1[log_n1] = t;
+  *out = t;
+  return IMP_OK;
+}
+
+static int ctx_scratch(imp_ctx* ctx, size_t bytes, void** out) {
+  if (ctx->scratch_bytes < bytes) {
+    if (ctx->scratch) HIP_TRY(hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    size_t want = std::max(bytes, (size_t)1 << 20);
+    HIP_TRY(hipMalloc(&ctx->scratch, want));
+    ctx->scratch_bytes = want;
+  }
+  *out = ctx->scratch;
+  return IMP_OK;
+}
+
+extern "C" const char* imp_version(void) { return "impulse_hip 0.1.0 (gfx950)"; }
+extern "C" const char* imp_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int imp_device_count(int* n) {
+  if (!n) return fail(IMP_ERR_INVALID, "imp_device_count: null output");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *n = 0;
+    return fail(IMP_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *n = c;
+  return IMP_OK;
+}
+
+extern "C" int imp_ctx_create(int device_id, imp_ctx** out) {
+  if (!out) return fail(IMP_ERR_INVALID, "imp_ctx_create: null output");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(IMP_ERR_NO_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+  if (device_id < 0 || device_id >= n)
+    return fail(IMP_ERR_INVALID, "device_id %d out of range [0,%d)", device_id, n);
+  HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(IMP_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device_id,
+                prop.gcnArchName);
+  imp_ctx* ctx = new (std::nothrow) imp_ctx();
+  if (!ctx) return fail(IMP_ERR_ALLOC, "out of host memory");
+  ctx->device = device_id;
+  hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (se != hipSuccess) {
+    delete ctx;
+    return fail(IMP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
+  }
+  int rc = upload_twiddle(&ctx->tw_row, 4096, 1.0, 4096.0, ctx->stream);
+  if (rc) {
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return rc;
+  }
+  *out = ctx;
+  return IMP_OK;
+}
+
+extern "C" int imp_ctx_set_stream(imp_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail(IMP_ERR_INVALID, "null ctx");
+  if (ctx->own_stream && ctx->stream) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipStreamDestroy(ctx->stream));
+  }
+  ctx->stream = (hipStream_t)hip_stream;
+  ctx->own_stream = false;
+  return IMP_OK;
+}
+
+extern "C" int imp_ctx_synchronize(imp_ctx* ctx) {
+  if (!ctx) return fail(IMP_ERR_INVALID, "null ctx");
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return IMP_OK;
+}
+
+extern "C" void imp_ctx_destroy(imp_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->tw_by_log_n1) {
+    (void)hipFree(kv.second.lo);
+    (void)hipFree(kv.second.hi);
+    (void)hipFree(kv.second.nfft_lo);
+    (void)hipFree(kv.second.nfft_hi);
+  }
+  if (ctx->tw_row) (void)hipFree(ctx->tw_row);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int imp_malloc(imp_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) return fail(IMP_ERR_INVALID, "imp_malloc: null argument");
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  *dptr = nullptr;
+  if (bytes == 0) return IMP_OK;
+  hipError_t e = hipMalloc(dptr, bytes);
+  if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  return IMP_OK;
+}
+
+extern "C" int imp_free(imp_ctx* ctx, void* dptr) {
+  if (!ctx) return fail(IMP_ERR_INVALID, "null ctx");
+  if (!dptr) return IMP_OK;
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipFree(dptr));
+  return IMP_OK;
+}
+
+extern "C" int imp_memcpy_h2d(imp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || (!dst && bytes) || (!src && bytes)) return fail(IMP_ERR_INVALID, "imp_memcpy_h2d: null argument");
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (!bytes) return IMP_OK;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return IMP_OK;
+}
+
+extern "C" int imp_memcpy_d2h(imp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || (!dst && bytes) || (!src && bytes)) return fail(IMP_ERR_INVALID, "imp_memcpy_d2h: null argument");
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (!bytes) return IMP_OK;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return IMP_OK;
+}
+
+extern "C" int imp_memset(imp_ctx* ctx, void* dptr, int value, size_t bytes) {
+  if (!ctx || (!dptr && bytes)) return fail(IMP_ERR_INVALID, "imp_memset: null argument");
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (!bytes) return IMP_OK;
+  HIP_TRY(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+  return IMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host fp64 FFT (plan preparation only): iterative radix-2, power-of-two sizes
+// ------------------------------------------------------------------------------------------------
+typedef std::complex<double> cd;
+
+static void host_fft_pow2(std::vector<cd>& a) {
+  const size_t n = a.size();
+  if (n < 2) return;
+  for (size_t i = 1, j = 0; i < n; ++i) {   // bit reversal
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(a[i], a[j]);
+  }
+  std::vector<cd> w(n / 2);
+  for (size_t k = 0; k < n / 2; ++k) {
+    double ang = -2.0 * M_PI * (double)k / (double)n;
+    w[k] = cd(std::cos(ang), std::sin(ang));
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const size_t half = len >> 1, step = n / len;
+    for (size_t i = 0; i < n; i += len)
+      for (size_t k = 0; k < half; ++k) {
+        cd u = a[i + k], v = a[i + k + half] * w[k * step];
+        a[i + k] = u + v;
+        a[i + k + half] = u - v;
+      }
+  }
+}
+
+// H[0..Nc] = rfft(h zero-padded to nfft = 2 Nc) via one Nc-point complex FFT
+static void host_rfft(const double* h, int64_t M, int64_t Nc, std::vector<cd>& H) {
+  std::vector<cd> z((size_t)Nc, cd(0, 0));
+  for (int64_t n = 0; 2 * n < M; ++n) {
+    double re = h[2 * n];
+    double im = (2 * n + 1 < M) ? h[2 * n + 1] : 0.0;
+    z[(size_t)n] = cd(re, im);
+  }
+  host_fft_pow2(z);
+  H.assign((size_t)Nc + 1, cd(0, 0));
+  const double nfft = 2.0 * (double)Nc;
+  for (int64_t k = 0; k <= Nc; ++k) {
+    cd zk = z[(size_t)(k % Nc)];
+    cd zm = std::conj(z[(size_t)((Nc - k) % Nc)]);
+    cd E = 0.5 * (zk + zm);
+    cd O = cd(0, -0.5) * (zk - zm);
+    double ang = -2.0 * M_PI * (double)k / nfft;
+    H[(size_t)k] = E + cd(std::cos(ang), std::sin(ang)) * O;
+  }
+}
+
+// alpha/beta planes in the row kernel's register order, fp32 (see conv_kernels.hip.h)
+static void host_alpha_beta(const std::vector<cd>& H, int64_t Nc, int N1, int log_n1, float4* ab) {
+  const double nfft = 2.0 * (double)Nc;
+  const double inv = 1.0 / (double)Nc;
+  for (int k1 = 0; k1 < N1; ++k1) {
+    for (int k2 = 0; k2 < imp::kN2; ++k2) {
+      const int64_t k = (int64_t)k1 + ((int64_t)k2 << log_n1);
+      const int u = 16 * (k2 & 15) + ((k2 >> 4) & 15);
+      const int q = k2 >> 8;
+      float4 o;
+      if (k == 0) {
+        o = make_float4((float)(H[0].real() * inv), 0.f, (float)(H[(size_t)Nc].real() * inv), 0.f);
+      } else {
+        cd Hk = H[(size_t)k];
+        cd Gk = std::conj(H[(size_t)(Nc - k)]);
+        double ang = -2.0 * M_PI * (double)k / nfft;
+        double s = std::sin(ang), c = std::cos(ang);
+        cd alpha = 0.5 * inv * (Hk * (1.0 + s) + Gk * (1.0 - s));
+        cd beta = cd(0, 0.5 * inv * c) * (Hk - Gk);
+        o = make_float4((float)alpha.real(), (float)alpha.imag(), (float)beta.real(), (float)beta.imag());
+      }
+      ab[(size_t)k1 * imp::kN2 + (size_t)q * 256 + (size_t)u] = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// convolution plan
+// ------------------------------------------------------------------------------------------------
+static constexpr int kMaxTimed = 8192;
+
+struct imp_plan {
+  imp_ctx* ctx = nullptr;
+  int64_t L = 0, M = 0, n_filters = 1;
+  int mode = IMP_MODE_SAME;
+  int64_t out_start = 0, out_len = 0;
+  int64_t nfft = 0, Nc = 0;
+  int N1 = 0, log_n1 = 0, R2 = 0;
+  int64_t ws_channels = 0;
+  TwSet tw;
+  float4* ab = nullptr;    // [n_filters][N1][4096]
+  cf* ws = nullptr;        // [ws_channels][N1][4096]
+  // staging for the host-buffer entry points
+  float* d_in = nullptr;
+  float* d_out = nullptr;
+  size_t d_in_bytes = 0, d_out_bytes = 0;
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> events;   // 4 per launch group
+  int64_t timed = 0;
+  double acc_ms[3] = {0, 0, 0};
+  int64_t acc_launches = 0;
+};
+
+template <int R2, int DIR, class Load, class Store>
+static int launch_cols(imp_plan* p, int64_t nchan, Load ld, Store st) {
+  using Cfg = imp::ColsCfg<R2>;
+  auto kern = imp::cols_kernel<R2, DIR, Load, Store>;
+  static bool attr_set = false;   // per instantiation
+  if (!attr_set && Cfg::lds_bytes > 0) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes));
+    attr_set = true;
+  }
+  const int tiles = imp::kN2 / Cfg::TC;
+  imp::Twiddles tw{p->tw.lo, p->tw.hi, p->ctx->tw_row};
+  dim3 grid((unsigned)(nchan * tiles)), block(Cfg::T);
+  hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->ctx->stream, ld, st, tw, tiles);
+  HIP_TRY(hipGetLastError());
+  return IMP_OK;
+}
+
+template <int DIR, class Load, class Store>
+static int launch_cols_any(imp_plan* p, int64_t nchan, Load ld, Store st) {
+  switch (p->R2) {
+    case 1: return launch_cols<1, DIR>(p, nchan, ld, st);
+    case 2: return launch_cols<2, DIR>(p, nchan, ld, st);
+    case 4: return launch_cols<4, DIR>(p, nchan, ld, st);
+    case 8: return launch_cols<8, DIR>(p, nchan, ld, st);
+    case 16: return launch_cols<16, DIR>(p, nchan, ld, st);
+  }
+  return fail(IMP_ERR_UNSUPPORTED, "unsupported column radix %d", p->R2);
+}
+
+static constexpr size_t kRowsLds = sizeof(cf) * 2 * 16 * imp::kRowPad;
+
+static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(imp::rows_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLds));
+    attr_set = true;
+  }
+  imp::RowsArgs a;
+  a.ws = p->ws;
+  const int64_t plane = (int64_t)p->N1 * imp::kN2;
+  a.ab = p->ab + (p->n_filters > 1 ? first_chan * plane : 0);
+  a.ab_chan_stride = p->n_filters > 1 ? plane : 0;
+  a.n1_total = p->N1;
+  a.log_n1 = p->log_n1;
+  a.npairs = p->N1 / 2;
+  imp::Twiddles tw{p->tw.lo, p->tw.hi, p->ctx->tw_row};
+  dim3 grid((unsigned)(nchan * a.npairs)), block(512);
+  hipLaunchKernelGGL(imp::rows_kernel, grid, block, kRowsLds, p->ctx->stream, a, tw);
+  HIP_TRY(hipGetLastError());
+  return IMP_OK;
+}
+
+static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, int mode, int64_t ws_channels) {
+  if (M < 1 || L < 1) return fail(IMP_ERR_INVALID, "M and L must be >= 1 (M=%lld L=%lld)", (long long)M, (long long)L);
+  if (n_filters < 1) return fail(IMP_ERR_INVALID, "n_filters must be >= 1");
+  if (mode != IMP_MODE_SAME && mode != IMP_MODE_FULL) return fail(IMP_ERR_INVALID, "mode must be IMP_MODE_SAME or IMP_MODE_FULL");
+  const int64_t need = L + M - 1;
+  int log_nfft = 17;
+  while (((int64_t)1 << log_nfft) < need) ++log_nfft;
+  if (log_nfft > 21)
+    return fail(IMP_ERR_UNSUPPORTED, "L+M-1 = %lld needs nfft > 2^21, beyond the two-level plan", (long long)need);
+  p->L = L;
+  p->M = M;
+  p->n_filters = n_filters;
+  p->mode = mode;
+  p->nfft = (int64_t)1 << log_nfft;
+  p->Nc = p->nfft / 2;
+  p->log_n1 = log_nfft - 1 - imp::kLogN2;
+  p->N1 = 1 << p->log_n1;
+  p->R2 = p->N1 / 16;
+  if (mode == IMP_MODE_SAME) {
+    // scipy.signal._signaltools._centered: start = (full - L) // 2 with full = L + M - 1
+    p->out_start = (M - 1) / 2;
+    p->out_len = L;
+  } else {
+    p->out_start = 0;
+    p->out_len = need;
+  }
+  if (ws_channels <= 0) {
+    // keep the workspace within ~128 MiB so A->B->C hand-offs stay in the 256 MiB Infinity Cache
+    ws_channels = std::max<int64_t>(1, ((int64_t)128 << 20) / (p->Nc * (int64_t)sizeof(cf)));
+  }
+  p->ws_channels = ws_channels;
+  return IMP_OK;
+}
+
+static int plan_alloc(imp_plan* p) {
+  int rc = ctx_bind(p->ctx);
+  if (rc) return rc;
+  if ((rc = ctx_twiddles(p->ctx, p->log_n1, &p->tw))) return rc;
+  const size_t plane = (size_t)p->N1 * imp::kN2;
+  hipError_t e = hipMalloc((void**)&p->ab, plane * (size_t)p->n_filters * sizeof(float4));
+  if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(spectrum): %s", hipGetErrorString(e));
+  e = hipMalloc((void**)&p->ws, plane * (size_t)p->ws_channels * sizeof(cf));
+  if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(workspace): %s", hipGetErrorString(e));
+  return IMP_OK;
+}
+
+extern "C" void imp_plan_destroy(imp_plan* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->ctx->device);
+  (void)hipStreamSynchronize(p->ctx->stream);
+  if (p->ab) (void)hipFree(p->ab);
+  if (p->ws) (void)hipFree(p->ws);
+  if (p->d_in) (void)hipFree(p->d_in);
+  if (p->d_out) (void)hipFree(p->d_out);
+  for (auto ev : p->events) (void)hipEventDestroy(ev);
+  delete p;
+}
+
+extern "C" int imp_conv_plan_create_empty(imp_ctx* ctx, int64_t M, int64_t n_filters, int64_t L, int mode,
+                                          int64_t ws_channels, imp_plan** out) {
+  if (!ctx || !out) return fail(IMP_ERR_INVALID, "imp_conv_plan_create_empty: null argument");
+  *out = nullptr;
+  imp_plan* p = new (std::nothrow) imp_plan();
+  if (!p) return fail(IMP_ERR_ALLOC, "out of host memory");
+  p->ctx = ctx;
+  int rc = plan_geometry(p, M, n_filters, L, mode, ws_channels);
+  if (!rc) rc = plan_alloc(p);
+  if (rc) {
+    imp_plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return IMP_OK;
+}
+
+extern "C" int imp_conv_plan_create(imp_ctx* ctx, const double* filter, int64_t M, int64_t n_filters,
+                                    int64_t filter_ld, int64_t L, int mode, int64_t ws_channels,
+                                    imp_plan** out) {
+  if (!filter) return fail(IMP_ERR_INVALID, "imp_conv_plan_create: null filter");
+  if (n_filters > 1 && filter_ld < M) return fail(IMP_ERR_INVALID, "filter_ld < M");
+  imp_plan* p = nullptr;
+  int rc = imp_conv_plan_create_empty(ctx, M, n_filters, L, mode, ws_channels, &p);
+  if (rc) return rc;
+  const size_t plane = (size_t)p->N1 * imp::kN2;
+  std::vector<float4> ab(plane);
+  std::vector<cd> H;
+  for (int64_t f = 0; f < n_filters; ++f) {
+    host_rfft(filter + f * filter_ld, M, p->Nc, H);
+    host_alpha_beta(H, p->Nc, p->N1, p->log_n1, ab.data());
+    hipError_t e = hipMemcpyAsync(p->ab + (size_t)f * plane, ab.data(), plane * sizeof(float4),
+                                  hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+      imp_plan_destroy(p);
+      return fail(IMP_ERR_HIP, "spectrum upload: %s", hipGetErrorString(e));
+    }
+  }
+  *out = p;
+  return IMP_OK;
+}
+
+extern "C" int imp_plan_info(const imp_plan* p, int64_t* nfft, int64_t* out_len, int64_t* ws_channels,
+                             int64_t* n1_rows) {
+  if (!p) return fail(IMP_ERR_INVALID, "null plan");
+  if (nfft) *nfft = p->nfft;
+  if (out_len) *out_len = p->out_len;
+  if (ws_channels) *ws_channels = p->ws_channels;
+  if (n1_rows) *n1_rows = p->N1;
+  return IMP_OK;
+}
+
+extern "C" int imp_plan_spectrum(imp_plan* p, void** dptr, size_t* bytes) {
+  if (!p || !dptr || !bytes) return fail(IMP_ERR_INVALID, "imp_plan_spectrum: null argument");
+  *dptr = p->ab;
+  *bytes = (size_t)p->N1 * imp::kN2 * (size_t)p->n_filters * sizeof(float4);
+  return IMP_OK;
+}
+
+extern "C" int imp_plan_set_timing(imp_plan* p, int enable) {
+  if (!p) return fail(IMP_ERR_INVALID, "null plan");
+  int rc = ctx_bind(p->ctx);
+  if (rc) return rc;
+  p->timing = enable != 0;
+  return IMP_OK;
+}
+
+static int plan_collect_timing(imp_plan* p) {
+  if (p->timed == 0) return IMP_OK;
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  for (int64_t i = 0; i < p->timed; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, p->events[(size_t)(4 * i + k)], p->events[(size_t)(4 * i + k + 1)]));
+      p->acc_ms[k] += ms;
+    }
+  }
+  p->acc_launches += p->timed;
+  p->timed = 0;
+  return IMP_OK;
+}
+
+extern "C" int imp_plan_get_timing(imp_plan* p, double ms[3], int64_t* launches, int reset) {
+  if (!p || !ms || !launches) return fail(IMP_ERR_INVALID, "imp_plan_get_timing: null argument");
+  int rc = ctx_bind(p->ctx);
+  if (rc) return rc;
+  if ((rc = plan_collect_timing(p))) return rc;
+  for (int k = 0; k < 3; ++k) ms[k] = p->acc_ms[k];
+  *launches = p->acc_launches;
+  if (reset) {
+    p->acc_ms[0] = p->acc_ms[1] = p->acc_ms[2] = 0;
+    p->acc_launches = 0;
+  }
+  return IMP_OK;
+}
+
+static int timing_event(imp_plan* p, int slot) {
+  if (!p->timing) return IMP_OK;
+  if (p->timed >= kMaxTimed) {
+    int rc = plan_collect_timing(p);   // drains the stream; only every kMaxTimed launch groups
+    if (rc) return rc;
+  }
+  const size_t need = (size_t)(4 * (p->timed + 1));
+  while (p->events.size() < need) {
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreate(&ev));
+    p->events.push_back(ev);
+  }
+  HIP_TRY(hipEventRecord(p->events[(size_t)(4 * p->timed + slot)], p->ctx->stream));
+  if (slot == 3) ++p->timed;
+  return IMP_OK;
+}
+
+// one launch group: nchan <= ws_channels channels, device pointers
+static int run_group(imp_plan* p, const float* d_x, int64_t nchan, int64_t chan_stride_in,
+                     int64_t elem_stride_in, float* d_y, int64_t chan_stride_out, int64_t first_chan,
+                     int last_stage) {
+  int rc;
+  imp::LoadRealPacked ld{d_x, chan_stride_in, elem_stride_in, p->L};
+  imp::StoreWorkspace stw{p->ws, p->N1};
+  if ((rc = timing_event(p, 0))) return rc;
+  if ((rc = launch_cols_any<-1>(p, nchan, ld, stw))) return rc;
+  if ((rc = timing_event(p, 1))) return rc;
+  if (last_stage < 1) return IMP_OK;
+  if ((rc = launch_rows(p, nchan, first_chan))) return rc;
+  if ((rc = timing_event(p, 2))) return rc;
+  if (last_stage < 2) return IMP_OK;
+  imp::LoadWorkspace ldw{p->ws, p->N1};
+  imp::StoreRealCrop stc{d_y, chan_stride_out, 1, p->out_start, p->out_len};
+  if ((rc = launch_cols_any<+1>(p, nchan, ldw, stc))) return rc;
+  if ((rc = timing_event(p, 3))) return rc;
+  return IMP_OK;
+}
+
+extern "C" int imp_conv_execute_device(imp_plan* p, const float* d_x, int64_t B, int64_t chan_stride_in,
+                                       int64_t elem_stride_in, float* d_y, int64_t chan_stride_out) {
+  if (!p || !d_x || !d_y) return fail(IMP_ERR_INVALID, "imp_conv_execute_device: null argument");
+  if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
+  if (elem_stride_in < 1) return fail(IMP_ERR_INVALID, "elem_stride_in must be >= 1");
+  if (chan_stride_out < p->out_len) return fail(IMP_ERR_INVALID, "chan_stride_out %lld < out_len %lld",
+                                                (long long)chan_stride_out, (long long)p->out_len);
+  if (p->n_filters > 1 && B > p->n_filters)
+    return fail(IMP_ERR_INVALID, "B = %lld exceeds the plan's %lld per-channel filters", (long long)B,
+                (long long)p->n_filters);
+  int rc = ctx_bind(p->ctx);
+  if (rc) return rc;
+  for (int64_t c0 = 0; c0 < B; c0 += p->ws_channels) {
+    const int64_t n = std::min(p->ws_channels, B - c0);
+    rc = run_group(p, d_x + c0 * chan_stride_in, n, chan_stride_in, elem_stride_in,
+                   d_y + c0 * chan_stride_out, chan_stride_out, c0, 2);
+    if (rc) return rc;
+  }
+  return IMP_OK;
+}
+
+static int plan_staging(imp_plan* p, size_t in_bytes, size_t out_bytes) {
+  if (p->d_in_bytes < in_bytes) {
+    if (p->d_in) HIP_TRY(hipFree(p->d_in));
+    p->d_in = nullptr;
+    p->d_in_bytes = 0;
+    hipError_t e = hipMalloc((void**)&p->d_in, in_bytes);
+    if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(input staging %zu): %s", in_bytes, hipGetErrorString(e));
+    p->d_in_bytes = in_bytes;
+  }
+  if (p->d_out_bytes < out_bytes) {
+    if (p->d_out) HIP_TRY(hipFree(p->d_out));
+    p->d_out = nullptr;
+    p->d_out_bytes = 0;
+    hipError_t e = hipMalloc((void**)&p->d_out, out_bytes);
+    if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(output staging %zu): %s", out_bytes, hipGetErrorString(e));
+    p->d_out_bytes = out_bytes;
+  }
+  return IMP_OK;
+}
+
+extern "C" int imp_conv_execute(imp_plan* p, const float* x, int64_t B, int64_t ld_in, float* y, int64_t ld_out) {
+  if (!p || (!x && B) || (!y && B)) return fail(IMP_ERR_INVALID, "imp_conv_execute: null argument");
+  if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
+  if (ld_in < p->L) return fail(IMP_ERR_INVALID, "ld_in %lld < L %lld", (long long)ld_in, (long long)p->L);
+  if (ld_out < p->out_len) return fail(IMP_ERR_INVALID, "ld_out %lld < out_len %lld", (long long)ld_out, (long long)p->out_len);
+  if (B == 0) return IMP_OK;
+  int rc = ctx_bind(p->ctx);
+  if (rc) return rc;
+  // even row pitches keep the float2 fast paths aligned
+  const int64_t pin = (p->L + 1) & ~(int64_t)1, pout = (p->out_len + 1) & ~(int64_t)1;
+  const int64_t grp = std::min(B, p->ws_channels);
+  if ((rc = plan_staging(p, (size_t)(grp * pin) * sizeof(float), (size_t)(grp * pout) * sizeof(float)))) return rc;
+  hipStream_t s = p->ctx->stream;
+  for (int64_t c0 = 0; c0 < B; c0 += grp) {
+    const int64_t n = std::min(grp, B - c0);
+    HIP_TRY(hipMemcpy2DAsync(p->d_in, (size_t)pin * sizeof(float), x + c0 * ld_in, (size_t)ld_in * sizeof(float),
+                             (size_t)p->L * sizeof(float), (size_t)n, hipMemcpyHostToDevice, s));
+    if ((rc = run_group(p, p->d_in, n, pin, 1, p->d_out, pout, c0, 2))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(y + c0 * ld_out, (size_t)ld_out * sizeof(float), p->d_out, (size_t)pout * sizeof(float),
+                             (size_t)p->out_len * sizeof(float), (size_t)n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return IMP_OK;
+}
+
+extern "C" int imp_conv_execute_interleaved(imp_plan* p, const float* frames, int64_t C, float* y, int64_t ld_out) {
+  if (!p || !frames || !y) return fail(IMP_ERR_INVALID, "imp_conv_execute_interleaved: null argument");
+  if (C < 1) return fail(IMP_ERR_INVALID, "C < 1");
+  if (ld_out < p->out_len) return fail(IMP_ERR_INVALID, "ld_out < out_len");
+  int rc = ctx_bind(p->ctx);
+  if (rc) return rc;
+  const int64_t pout = (p->out_len + 1) & ~(int64_t)1;
+  const int64_t grp = std::min(C, p->ws_channels);
+  if ((rc = plan_staging(p, (size_t)(p->L * C) * sizeof(float), (size_t)(grp * pout) * sizeof(float)))) return rc;
+  hipStream_t s = p->ctx->stream;
+  // the whole frame block goes up once, in wire order; channels are picked apart by the loader
+  HIP_TRY(hipMemcpyAsync(p->d_in, frames, (size_t)(p->L * C) * sizeof(float), hipMemcpyHostToDevice, s));
+  for (int64_t c0 = 0; c0 < C; c0 += grp) {
+    const int64_t n = std::min(grp, C - c0);
+    if ((rc = run_group(p, p->d_in + c0, n, 1, C, p->d_out, pout, c0, 2))) return rc;
+    HIP_TRY(hipMemcpy2DAsync(y + c0 * ld_out, (size_t)ld_out * sizeof(float), p->d_out, (size_t)pout * sizeof(float),
+                             (size_t)p->out_len * sizeof(float), (size_t)n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return IMP_OK;
+}
+
+extern "C" int imp_plan_debug_run_stage(imp_plan* p, const float* x, int64_t B, int64_t ld_in, int stage,
+                                        float* ws_out_host) {
+  if (!p || !x || !ws_out_host) return fail(IMP_ERR_INVALID, "imp_plan_debug_run_stage: null argument");
+  if (B < 1 || B > p->ws_channels) return fail(IMP_ERR_INVALID, "debug stage: B must be in [1, ws_channels]");
+  if (stage < 0 || stage > 1) return fail(IMP_ERR_INVALID, "stage must be 0 (after pass A) or 1 (after pass B)");
+  int rc = ctx_bind(p->ctx);
+  if (rc) return rc;
+  const int64_t pin = (p->L + 1) & ~(int64_t)1, pout = (p->out_len + 1) & ~(int64_t)1;
+  if ((rc = plan_staging(p, (size_t)(B * pin) * sizeof(float), (size_t)(B * pout) * sizeof(float)))) return rc;
+  hipStream_t s = p->ctx->stream;
+  HIP_TRY(hipMemcpy2DAsync(p->d_in, (size_t)pin * sizeof(float), x, (size_t)ld_in * sizeof(float),
+                           (size_t)p->L * sizeof(float), (size_t)B, hipMemcpyHostToDevice, s));
+  if ((rc = run_group(p, p->d_in, B, pin, 1, p->d_out, pout, 0, stage))) return rc;
+  HIP_TRY(hipMemcpyAsync(ws_out_host, p->ws, (size_t)B * p->N1 * imp::kN2 * sizeof(cf), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return IMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 peak index, K4/K8 windows (ragged batches)
+// ------------------------------------------------------------------------------------------------
+static int peak_index_impl(imp_ctx* ctx, const float* d_x, const int64_t* off, const int64_t* len, int64_t B,
+                           double peak_height, int64_t* idx_out, float* maxabs_out) {
+  if (B == 0) return IMP_OK;
+  // scratch: off[B], len[B], res[B] (RowPeak)
+  const size_t meta = (size_t)B * sizeof(int64_t);
+  const size_t res_bytes = (size_t)B * sizeof(imp::RowPeak);
+  void* scr = nullptr;
+  int rc = ctx_scratch(ctx, 2 * meta + res_bytes, &scr);
+  if (rc) return rc;
+  int64_t* d_off = (int64_t*)scr;
+  int64_t* d_len = d_off + B;
+  imp::RowPeak* d_res = (imp::RowPeak*)(d_len + B);
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(d_off, off, meta, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_len, len, meta, hipMemcpyHostToDevice, s));
+  std::vector<imp::RowPeak> h((size_t)B);
+  for (auto& r : h) {
+    r.maxabs_bits = 0u;
+    r.pad = 0u;
+    r.first_peak = ~0ull;
+    r.first_max = ~0ull;
+  }
+  HIP_TRY(hipMemcpyAsync(d_res, h.data(), res_bytes, hipMemcpyHostToDevice, s));
+  int64_t maxlen = 0;
+  for (int64_t b = 0; b < B; ++b) maxlen = std::max(maxlen, len[b]);
+  const int bpr = (int)std::max<int64_t>(1, std::min<int64_t>(256, (maxlen + 4095) / 4096));
+  dim3 grid((unsigned)bpr, (unsigned)B), block(256);
+  hipLaunchKernelGGL(imp::row_maxabs_kernel, grid, block, 0, s, d_x, d_off, d_len, d_res);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(imp::row_first_peak_kernel, grid, block, 0, s, d_x, d_off, d_len, d_res, peak_height);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h.data(), d_res, res_bytes, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int64_t b = 0; b < B; ++b) {
+    float m;
+    std::memcpy(&m, &h[(size_t)b].maxabs_bits, sizeof(float));
+    if (maxabs_out) maxabs_out[b] = m;
+    int64_t idx;
+    if (len[b] == 0 || !(m >= 1e-20f)) idx = 0;                         // EPSILON rule, impulse_response.py:56-58
+    else if (h[(size_t)b].first_peak != ~0ull) idx = (int64_t)h[(size_t)b].first_peak;
+    else idx = (int64_t)h[(size_t)b].first_max;                          // argmax fallback, :66-67
+    idx_out[b] = idx;
+  }
+  return IMP_OK;
+}
+
+extern "C" int imp_peak_index_device(imp_ctx* ctx, const float* d_x, const int64_t* off, const int64_t* len,
+                                     int64_t B, double peak_height, int64_t* idx_out, float* maxabs_out) {
+  if (!ctx || (B && (!d_x || !off || !len || !idx_out))) return fail(IMP_ERR_INVALID, "imp_peak_index_device: null argument");
+  if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
+  for (int64_t b = 0; b < B; ++b)
+    if (len[b] < 0 || off[b] < 0) return fail(IMP_ERR_INVALID, "negative offset/length in row %lld", (long long)b);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  return peak_index_impl(ctx, d_x, off, len, B, peak_height, idx_out, maxabs_out);
+}
+
+extern "C" int imp_peak_index(imp_ctx* ctx, const float* x, const int64_t* off, const int64_t* len, int64_t B,
+                              double peak_height, int64_t* idx_out, float* maxabs_out) {
+  if (!ctx || (B && (!x || !off || !len || !idx_out))) return fail(IMP_ERR_INVALID, "imp_peak_index: null argument");
+  if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
+  if (B == 0) return IMP_OK;
+  int64_t total = 0;
+  for (int64_t b = 0; b < B; ++b) {
+    if (len[b] < 0 || off[b] < 0) return fail(IMP_ERR_INVALID, "negative offset/length in row %lld", (long long)b);
+    total = std::max(total, off[b] + len[b]);
+  }
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  float* d_x = nullptr;
+  if (total > 0) {
+    hipError_t e = hipMalloc((void**)&d_x, (size_t)total * sizeof(float));
+    if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(%lld floats): %s", (long long)total, hipGetErrorString(e));
+    e = hipMemcpyAsync(d_x, x, (size_t)total * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) {
+      (void)hipFree(d_x);
+      return fail(IMP_ERR_HIP, "h2d: %s", hipGetErrorString(e));
+    }
+  }
+  rc = peak_index_impl(ctx, d_x, off, len, B, peak_height, idx_out, maxabs_out);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (d_x) (void)hipFree(d_x);
+  return rc;
+}
+
+extern "C" int imp_apply_window(imp_ctx* ctx, float* x, const int64_t* off, const int64_t* len, int64_t B,
+                                const imp_window_params* params) {
+  if (!ctx || (B && (!x || !off || !len || !params))) return fail(IMP_ERR_INVALID, "imp_apply_window: null argument");
+  if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
+  if (B == 0) return IMP_OK;
+  int64_t total = 0, maxlen = 0;
+  for (int64_t b = 0; b < B; ++b) {
+    if (len[b] < 0 || off[b] < 0) return fail(IMP_ERR_INVALID, "negative offset/length in row %lld", (long long)b);
+    if (params[b].fade_in < 0 || params[b].fade_out < 0 || params[b].fade_in > len[b] || params[b].fade_out > len[b])
+      return fail(IMP_ERR_INVALID, "fade longer than row %lld", (long long)b);
+    if (params[b].decay_half >= 0) {
+      // numpy would raise on the concatenate/multiply length mismatch (core/decay.py:391-402)
+      if (params[b].decay_start < 0 || params[b].decay_knee > len[b] ||
+          params[b].decay_start + params[b].decay_half != params[b].decay_knee)
+        return fail(IMP_ERR_INVALID, "decay window of row %lld does not tile the row", (long long)b);
+    }
+    total = std::max(total, off[b] + len[b]);
+    maxlen = std::max(maxlen, len[b]);
+  }
+  if (total == 0) return IMP_OK;
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  float* d_x = nullptr;
+  hipError_t e = hipMalloc((void**)&d_x, (size_t)total * sizeof(float));
+  if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc: %s", hipGetErrorString(e));
+  auto cleanup = [&](int code) {
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(d_x);
+    return code;
+  };
+  const size_t meta = (size_t)B * sizeof(int64_t);
+  void* scr = nullptr;
+  if ((rc = ctx_scratch(ctx, 2 * meta + (size_t)B * sizeof(imp_window_params), &scr))) return cleanup(rc);
+  int64_t* d_off = (int64_t*)scr;
+  int64_t* d_len = d_off + B;
+  imp_window_params* d_par = (imp_window_params*)(d_len + B);
+  if (hipMemcpyAsync(d_x, x, (size_t)total * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(d_off, off, meta, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(d_len, len, meta, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(d_par, params, (size_t)B * sizeof(imp_window_params), hipMemcpyHostToDevice, s) != hipSuccess)
+    return cleanup(fail(IMP_ERR_HIP, "imp_apply_window: h2d copy failed"));
+  const int bpr = (int)std::max<int64_t>(1, std::min<int64_t>(256, (maxlen + 1023) / 1024));
+  dim3 grid((unsigned)bpr, (unsigned)B), block(256);
+  hipLaunchKernelGGL(imp::apply_window_kernel, grid, block, 0, s, d_x, d_off, d_len,
+                     reinterpret_cast<const imp::WindowParams*>(d_par));
+  if (hipGetLastError() != hipSuccess) return cleanup(fail(IMP_ERR_HIP, "apply_window launch failed"));
+  if (hipMemcpyAsync(x, d_x, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess)
+    return cleanup(fail(IMP_ERR_HIP, "imp_apply_window: d2h copy failed"));
+  return cleanup(IMP_OK);
+}

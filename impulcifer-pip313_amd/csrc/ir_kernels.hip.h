@@ -1,0 +1,135 @@
+// Small batched kernels on ragged sets of impulse responses (rows at x + off[b], length len[b]).
+//   K3  first significant peak   core/impulse_response.py:32-70  (twin core/decay.py:12-41)
+//   K4  gain + Hann fades        core/hrir.py:530-544, :591-612, :642-651
+//   K8  decay window             core/decay.py:383-403
+// All of them are HBM-bound streaming passes (1 read, or 1 read + 1 write); no MFMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace imp {
+
+struct RowPeak {
+  unsigned int maxabs_bits;         // bits of max|x| (non-negative floats order like unsigned ints)
+  unsigned int pad;
+  unsigned long long first_peak;    // smallest index passing the find_peaks rule, ~0 if none
+  unsigned long long first_max;     // smallest index with |x| == max|x|
+};
+
+// grid = (blocks_per_row, B)
+__global__ __launch_bounds__(256) void row_maxabs_kernel(const float* __restrict__ x,
+                                                         const int64_t* __restrict__ off,
+                                                         const int64_t* __restrict__ len,
+                                                         RowPeak* __restrict__ res) {
+  const int b = blockIdx.y;
+  const int64_t n = len[b];
+  const float* row = x + off[b];
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(row[i]));
+  // wave64 reduction
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+  __shared__ float wm[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wm[wv] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+    // NaN-free inputs assumed (as the reference: np.max would propagate NaN and find_peaks none)
+    atomicMax(&res[b].maxabs_bits, __float_as_uint(m));
+  }
+}
+
+// SciPy _local_maxima_1d on +x and -x, height filter x[peak]/max >= h (inclusive), min index.
+//  - sample i starts a candidate iff v[i-1] < v[i]
+//  - plateau: run of equal samples i..j; it is a peak iff j+1 < n and v[j+1] < v[j];
+//    reported index = (i + j) / 2; first and last samples are never peaks
+__global__ __launch_bounds__(256) void row_first_peak_kernel(const float* __restrict__ x,
+                                                             const int64_t* __restrict__ off,
+                                                             const int64_t* __restrict__ len,
+                                                             RowPeak* __restrict__ res, double height) {
+  const int b = blockIdx.y;
+  const int64_t n = len[b];
+  const float* row = x + off[b];
+  const float maxabs = __uint_as_float(res[b].maxabs_bits);
+  if (!(maxabs >= 1e-20f)) return;
+  const double dmax = (double)maxabs;
+  unsigned long long best = ~0ull, bestmax = ~0ull;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float xi = row[i];
+    if (fabsf(xi) == maxabs && (unsigned long long)i < bestmax) bestmax = (unsigned long long)i;
+    if (i == 0 || i >= n - 1) continue;
+    if ((unsigned long long)i >= best) continue;
+    const float xm = row[i - 1];
+    // polarity: +x peak needs xm < xi ; -x peak needs xm > xi
+    const bool up = xm < xi, dn = xm > xi;
+    if (!up && !dn) continue;
+    // data / max >= height, evaluated in fp64 exactly like the reference does on float64 data
+    const double v = (up ? (double)xi : -(double)xi) / dmax;
+    if (!(v >= height)) continue;
+    int64_t j = i;
+    while (j + 1 < n && row[j + 1] == xi) ++j;
+    if (j + 1 >= n) continue;
+    const float xn = row[j + 1];
+    if (up ? (xn < xi) : (xn > xi)) {
+      const unsigned long long pk = (unsigned long long)((i + j) / 2);
+      if (pk < best) best = pk;
+    }
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    unsigned long long o = __shfl_xor(best, s, 64);
+    best = o < best ? o : best;
+    unsigned long long om = __shfl_xor(bestmax, s, 64);
+    bestmax = om < bestmax ? om : bestmax;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (best != ~0ull) atomicMin(&res[b].first_peak, best);
+    if (bestmax != ~0ull) atomicMin(&res[b].first_max, bestmax);
+  }
+}
+
+// layout-compatible with imp_window_params (include/impulse_hip.h)
+struct WindowParams {
+  float gain;
+  int64_t fade_in;
+  int64_t fade_out;
+  int64_t decay_start;
+  int64_t decay_half;
+  int64_t decay_knee;
+  float decay_level_db;
+};
+
+// scipy.signal.windows.hann(N, sym=True)[i] = 0.5 - 0.5 cos(2 pi i / (N - 1))
+__device__ __forceinline__ double hann_sym(int64_t i, int64_t N) {
+  if (N <= 1) return 1.0;
+  return 0.5 - 0.5 * cospi(2.0 * (double)i / (double)(N - 1));
+}
+
+__global__ __launch_bounds__(256) void apply_window_kernel(float* __restrict__ x,
+                                                           const int64_t* __restrict__ off,
+                                                           const int64_t* __restrict__ len,
+                                                           const WindowParams* __restrict__ par) {
+  const int b = blockIdx.y;
+  const int64_t n = len[b];
+  float* row = x + off[b];
+  const WindowParams p = par[b];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double g = (double)p.gain;
+    if (i < p.fade_in) g *= hann_sym(i, 2 * p.fade_in);                        // hann(2F)[:F]
+    if (p.fade_out > 0 && i >= n - p.fade_out)
+      g *= hann_sym(p.fade_out + (i - (n - p.fade_out)), 2 * p.fade_out);      // hann(2F)[F:]
+    if (p.decay_half >= 0) {
+      // window = concat(ones(start), hann(2h)[h:], zeros(n - knee)) - 1 ; x *= 10^(-level*window/20)
+      double w;
+      if (i < p.decay_start) w = 1.0;
+      else if (i < p.decay_knee) w = hann_sym(p.decay_half + (i - p.decay_start), 2 * p.decay_half);
+      else w = 0.0;
+      g *= pow(10.0, (w - 1.0) * (-(double)p.decay_level_db) / 20.0);
+    }
+    row[i] = (float)((double)row[i] * g);
+  }
+}
+
+}  // namespace imp

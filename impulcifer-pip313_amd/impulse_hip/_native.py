@@ -1,0 +1,329 @@
+"""ctypes binding of libimpulse_hip.so (C ABI: include/impulse_hip.h).
+
+The HIP library is the product path: there is NO CPU fallback.  If the shared object cannot be
+loaded, or no gfx950 device is present, every compute entry point raises ``NativeUnavailable``.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DEFAULT_LIB = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libimpulse_hip.so"))
+
+IMP_MODE_SAME = 0
+IMP_MODE_FULL = 1
+
+
+class NativeUnavailable(RuntimeError):
+    """libimpulse_hip.so is missing or no MI355X (gfx950) device is usable."""
+
+
+class NativeError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+    def __init__(self, code, message):
+        super().__init__(f"impulse_hip error {code}: {message}")
+        self.code = code
+
+
+class WindowParams(C.Structure):
+    _fields_ = [
+        ("gain", C.c_float),
+        ("fade_in", C.c_int64),
+        ("fade_out", C.c_int64),
+        ("decay_start", C.c_int64),
+        ("decay_half", C.c_int64),
+        ("decay_knee", C.c_int64),
+        ("decay_level_db", C.c_float),
+    ]
+
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_pf = C.POINTER(C.c_float)
+_pd = C.POINTER(C.c_double)
+_pi64 = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); mirrors include/impulse_hip.h one to one
+SIGNATURES = {
+    "imp_version": (C.c_char_p, []),
+    "imp_last_error": (C.c_char_p, []),
+    "imp_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "imp_ctx_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "imp_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "imp_ctx_synchronize": (C.c_int, [_vp]),
+    "imp_ctx_destroy": (None, [_vp]),
+    "imp_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "imp_free": (C.c_int, [_vp, _vp]),
+    "imp_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "imp_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "imp_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
+    "imp_conv_plan_create": (C.c_int, [_vp, _pd, _i64, _i64, _i64, _i64, C.c_int, _i64, C.POINTER(_vp)]),
+    "imp_conv_plan_create_empty": (C.c_int, [_vp, _i64, _i64, _i64, C.c_int, _i64, C.POINTER(_vp)]),
+    "imp_plan_destroy": (None, [_vp]),
+    "imp_plan_info": (C.c_int, [_vp, _pi64, _pi64, _pi64, _pi64]),
+    "imp_plan_spectrum": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "imp_conv_execute": (C.c_int, [_vp, _pf, _i64, _i64, _pf, _i64]),
+    "imp_conv_execute_interleaved": (C.c_int, [_vp, _pf, _i64, _pf, _i64]),
+    "imp_conv_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64]),
+    "imp_plan_set_timing": (C.c_int, [_vp, C.c_int]),
+    "imp_plan_get_timing": (C.c_int, [_vp, _pd, _pi64, C.c_int]),
+    "imp_plan_debug_run_stage": (C.c_int, [_vp, _pf, _i64, _i64, C.c_int, _pf]),
+    "imp_peak_index": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
+    "imp_peak_index_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
+    "imp_apply_window": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.POINTER(WindowParams)]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def library_path():
+    return os.environ.get("IMPULSE_HIP_LIB", _DEFAULT_LIB)
+
+
+def load_library():
+    """Load the shared object and declare every prototype. Raises NativeUnavailable if missing."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            raise NativeUnavailable(
+                f"{path} not found - build it with `python impulcifer-pip313_amd/build.py` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        try:
+            lib = C.CDLL(path)
+        except OSError as exc:
+            raise NativeUnavailable(f"cannot load {path}: {exc}") from exc
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load_library().imp_last_error()
+        raise NativeError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr_f(a):
+    return a.ctypes.data_as(_pf)
+
+
+def _ptr_i64(a):
+    return a.ctypes.data_as(_pi64)
+
+
+class Context:
+    """One GPU + one stream (imp_ctx)."""
+
+    def __init__(self, device=0):
+        lib = load_library()
+        n = C.c_int(0)
+        rc = lib.imp_device_count(C.byref(n))
+        if rc != 0 or n.value <= 0:
+            raise NativeUnavailable("no HIP device visible: the impulse_hip product path needs an MI355X (gfx950)")
+        h = _vp()
+        rc = lib.imp_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            msg = lib.imp_last_error().decode("utf-8", "replace")
+            raise NativeUnavailable(f"imp_ctx_create({device}) failed: {msg}")
+        self._lib = lib
+        self._h = h
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, stream_ptr):
+        _check(self._lib.imp_ctx_set_stream(self._h, _vp(int(stream_ptr))))
+
+    def synchronize(self):
+        _check(self._lib.imp_ctx_synchronize(self._h))
+
+    def malloc(self, nbytes):
+        p = _vp()
+        _check(self._lib.imp_malloc(self._h, int(nbytes), C.byref(p)))
+        return p.value or 0
+
+    def free(self, dptr):
+        _check(self._lib.imp_free(self._h, _vp(int(dptr))))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(self._lib.imp_memcpy_h2d(self._h, _vp(int(dptr)), arr.ctypes.data_as(_vp), arr.nbytes))
+
+    def d2h(self, arr, dptr):
+        assert arr.flags["C_CONTIGUOUS"]
+        _check(self._lib.imp_memcpy_d2h(self._h, arr.ctypes.data_as(_vp), _vp(int(dptr)), arr.nbytes))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.imp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- ragged helpers ------------------------------------------------------------------
+    @staticmethod
+    def _pack_rows(rows):
+        lens = np.array([len(r) for r in rows], dtype=np.int64)
+        offs = np.zeros(len(rows), dtype=np.int64)
+        if len(rows):
+            offs[1:] = np.cumsum(lens)[:-1]
+        flat = np.zeros(int(lens.sum()) if len(rows) else 0, dtype=np.float32)
+        for r, o, n in zip(rows, offs, lens):
+            flat[o:o + n] = r
+        return flat, offs, lens
+
+    def peak_index(self, rows, peak_height=0.12589):
+        """Batched ImpulseResponse.peak_index over a list of 1-D arrays. Returns (idx[int64], maxabs[f32])."""
+        rows = [np.asarray(r) for r in rows]
+        B = len(rows)
+        idx = np.zeros(B, dtype=np.int64)
+        mx = np.zeros(B, dtype=np.float32)
+        if B == 0:
+            return idx, mx
+        flat, offs, lens = self._pack_rows(rows)
+        if flat.size == 0:
+            return idx, mx
+        _check(self._lib.imp_peak_index(self._h, _ptr_f(flat), _ptr_i64(offs), _ptr_i64(lens), B,
+                                        float(peak_height), _ptr_i64(idx), _ptr_f(mx)))
+        return idx, mx
+
+    def apply_window(self, rows, params):
+        """In-place-style windowing of a list of rows; returns new float32 arrays."""
+        rows = [np.asarray(r) for r in rows]
+        B = len(rows)
+        if B == 0:
+            return []
+        flat, offs, lens = self._pack_rows(rows)
+        arr = (WindowParams * B)()
+        for i, p in enumerate(params):
+            arr[i] = WindowParams(float(p.get("gain", 1.0)), int(p.get("fade_in", 0)), int(p.get("fade_out", 0)),
+                                  int(p.get("decay_start", 0)), int(p.get("decay_half", -1)),
+                                  int(p.get("decay_knee", 0)), float(p.get("decay_level_db", 0.0)))
+        _check(self._lib.imp_apply_window(self._h, _ptr_f(flat), _ptr_i64(offs), _ptr_i64(lens), B, arr))
+        return [flat[o:o + n].copy() for o, n in zip(offs, lens)]
+
+
+class ConvPlan:
+    """Batched FFT convolution plan (imp_plan): scipy.signal.convolve(x, h, mode) for fixed (h, L)."""
+
+    def __init__(self, ctx, filt, L, mode="same", ws_channels=0, empty_M=None, n_filters=None):
+        self._lib = ctx._lib
+        self.ctx = ctx
+        self.L = int(L)
+        self.mode = {"same": IMP_MODE_SAME, "full": IMP_MODE_FULL}[mode]
+        h = _vp()
+        if filt is None:
+            _check(self._lib.imp_conv_plan_create_empty(ctx.handle, int(empty_M), int(n_filters or 1), self.L,
+                                                        self.mode, int(ws_channels), C.byref(h)))
+            self.M = int(empty_M)
+            self.n_filters = int(n_filters or 1)
+        else:
+            f = np.ascontiguousarray(filt, dtype=np.float64)
+            if f.ndim == 1:
+                f = f[None, :]
+            self.n_filters, self.M = int(f.shape[0]), int(f.shape[1])
+            _check(self._lib.imp_conv_plan_create(ctx.handle, f.ctypes.data_as(_pd), self.M, self.n_filters,
+                                                  self.M, self.L, self.mode, int(ws_channels), C.byref(h)))
+        self._h = h
+        nfft, out_len, wsc, n1 = _i64(), _i64(), _i64(), _i64()
+        _check(self._lib.imp_plan_info(self._h, C.byref(nfft), C.byref(out_len), C.byref(wsc), C.byref(n1)))
+        self.nfft, self.out_len, self.ws_channels, self.n1 = nfft.value, out_len.value, wsc.value, n1.value
+
+    @property
+    def handle(self):
+        return self._h
+
+    def spectrum_buffer(self):
+        p, n = _vp(), C.c_size_t()
+        _check(self._lib.imp_plan_spectrum(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def execute(self, x):
+        """x: [B, L] (or [L]) float -> [B, out_len] float32."""
+        x = _f32(x)
+        one = x.ndim == 1
+        if one:
+            x = x[None, :]
+        if x.shape[1] != self.L:
+            raise ValueError(f"plan was made for L={self.L}, got rows of {x.shape[1]}")
+        B = x.shape[0]
+        y = np.empty((B, self.out_len), dtype=np.float32)
+        _check(self._lib.imp_conv_execute(self._h, _ptr_f(x), B, x.shape[1], _ptr_f(y), y.shape[1]))
+        return y[0] if one else y
+
+    def execute_interleaved(self, frames):
+        """frames: [L, C] float (WAV wire order) -> [C, out_len] float32."""
+        frames = _f32(frames)
+        if frames.ndim != 2 or frames.shape[0] != self.L:
+            raise ValueError(f"frames must be [L={self.L}, C]")
+        Cn = frames.shape[1]
+        y = np.empty((Cn, self.out_len), dtype=np.float32)
+        _check(self._lib.imp_conv_execute_interleaved(self._h, _ptr_f(frames), Cn, _ptr_f(y), y.shape[1]))
+        return y
+
+    def execute_device(self, d_x, B, chan_stride_in, d_y, chan_stride_out, elem_stride_in=1):
+        _check(self._lib.imp_conv_execute_device(self._h, _vp(int(d_x)), int(B), int(chan_stride_in),
+                                                 int(elem_stride_in), _vp(int(d_y)), int(chan_stride_out)))
+
+    def set_timing(self, on):
+        _check(self._lib.imp_plan_set_timing(self._h, 1 if on else 0))
+
+    def get_timing(self, reset=True):
+        ms = (C.c_double * 3)()
+        n = _i64()
+        _check(self._lib.imp_plan_get_timing(self._h, ms, C.byref(n), 1 if reset else 0))
+        return [ms[0], ms[1], ms[2]], n.value
+
+    def debug_stage(self, x, stage):
+        x = _f32(x)
+        if x.ndim == 1:
+            x = x[None, :]
+        B = x.shape[0]
+        out = np.empty((B, self.n1, 4096), dtype=np.complex64)
+        _check(self._lib.imp_plan_debug_run_stage(self._h, _ptr_f(x), B, x.shape[1], int(stage),
+                                                  out.ctypes.data_as(_pf)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.imp_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+_default_lock = threading.Lock()
+
+
+def default_context():
+    """Process-wide context on IMPULSE_HIP_DEVICE (default 0)."""
+    global _default_ctx
+    with _default_lock:
+        if _default_ctx is None:
+            _default_ctx = Context(int(os.environ.get("IMPULSE_HIP_DEVICE", "0")))
+        return _default_ctx

@@ -1,0 +1,144 @@
+/* impulse_hip.h - C ABI of libimpulse_hip.so (MI355X / gfx950 impulse-response engine).
+ *
+ * Drop-in boundary for ONE hot path of 115dkk/Impulcifer-pip313 (reference paths are relative to
+ * the reference checkout): per-channel ESS sweep deconvolution, IR peak/crop/decay and
+ * minimum-phase FIR equalisation.  The reference is pure Python; what it calls on this path is
+ * SciPy/NumPy.  Each entry point below names the reference call site it replaces.  The Python
+ * host side (package impulse_hip, ctypes) keeps the reference's class surfaces on top of this.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative IMP_ERR_* code; the message for the
+ *     calling thread is available from imp_last_error()
+ *   - no exceptions and no torch / numpy types cross the boundary: plain pointers and sizes
+ *   - "host" pointers are ordinary process memory, "device" pointers are HIP device memory of
+ *     the context's GPU (e.g. obtained from imp_malloc or any other HIP allocator)
+ *   - a context owns one GPU and one stream; calls on one context are stream ordered; distinct
+ *     contexts may be used from distinct threads concurrently
+ *   - arithmetic is IEEE fp32 on the device; filter spectra of deconvolution plans are prepared
+ *     in fp64 on the host and rounded once
+ */
+#ifndef IMPULSE_HIP_H_
+#define IMPULSE_HIP_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMP_OK 0
+#define IMP_ERR_INVALID (-1)      /* bad argument */
+#define IMP_ERR_HIP (-2)          /* a HIP runtime call failed */
+#define IMP_ERR_UNSUPPORTED (-3)  /* size outside what the kernels cover */
+#define IMP_ERR_NO_DEVICE (-4)    /* no usable GPU */
+#define IMP_ERR_ALLOC (-5)
+
+#define IMP_MODE_SAME 0           /* scipy.signal.convolve(..., mode='same') window */
+#define IMP_MODE_FULL 1           /* mode='full' */
+
+typedef struct imp_ctx imp_ctx;
+typedef struct imp_plan imp_plan;
+
+/* ---- library / device ---------------------------------------------------------------------- */
+const char* imp_version(void);
+const char* imp_last_error(void);
+int imp_device_count(int* n);
+int imp_ctx_create(int device_id, imp_ctx** out);
+/* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int imp_ctx_set_stream(imp_ctx* ctx, void* hip_stream);
+int imp_ctx_synchronize(imp_ctx* ctx);
+void imp_ctx_destroy(imp_ctx* ctx);
+
+/* device memory helpers (so a NumPy-only host needs no other HIP binding) */
+int imp_malloc(imp_ctx* ctx, size_t bytes, void** dptr);
+int imp_free(imp_ctx* ctx, void* dptr);
+int imp_memcpy_h2d(imp_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+int imp_memcpy_d2h(imp_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
+int imp_memset(imp_ctx* ctx, void* dptr, int value, size_t bytes);
+
+/* ---- K1/K5: batched FFT convolution plans ---------------------------------------------------
+ * Replaces scipy.signal.convolve(x, h, mode, method='auto') for the sizes where SciPy picks the
+ * FFT method:
+ *   core/impulse_response_estimator.py:149-151  ImpulseResponseEstimator.estimate  (mode 'same',
+ *        h = inverse_filter, shared by every channel; called per column at core/hrir.py:336-354)
+ *   core/impulse_response.py:110-119, 126-135    ImpulseResponse.equalize / convolve (mode 'full')
+ *   core/parallel_workers.py:9-21                process_plot_worker (mode 'full')
+ *
+ * A plan fixes (filter, M, L, mode).  nfft = 2^k >= max(L+M-1, 2^17), at most 2^21.
+ * ws_channels = channels processed per launch group (0 = choose so that the workspace stays
+ * resident in the 256 MiB Infinity Cache).
+ */
+int imp_conv_plan_create(imp_ctx* ctx,
+                         const double* filter,      /* host, [n_filters][filter_ld] */
+                         int64_t M,                 /* taps per filter */
+                         int64_t n_filters,         /* 1 = shared by all channels, else one per channel */
+                         int64_t filter_ld,
+                         int64_t L,                 /* samples per input channel */
+                         int mode,                  /* IMP_MODE_SAME | IMP_MODE_FULL */
+                         int64_t ws_channels,
+                         imp_plan** out);
+/* Empty plan whose spectrum is filled later (imp_plan_spectrum + a broadcast from another GPU). */
+int imp_conv_plan_create_empty(imp_ctx* ctx, int64_t M, int64_t n_filters, int64_t L, int mode,
+                               int64_t ws_channels, imp_plan** out);
+void imp_plan_destroy(imp_plan* plan);
+/* geometry queries */
+int imp_plan_info(const imp_plan* plan, int64_t* nfft, int64_t* out_len, int64_t* ws_channels,
+                  int64_t* n1_rows);
+/* Device buffer holding the prepared filter spectrum (alpha/beta planes, fp32).  This is the only
+ * datum shared between GPUs: rank 0 builds it, the others receive it with an RCCL broadcast. */
+int imp_plan_spectrum(imp_plan* plan, void** dptr, size_t* bytes);
+
+/* host in / host out, planar: x[B][ld_in] -> y[B][ld_out] (first out_len samples of each row) */
+int imp_conv_execute(imp_plan* plan, const float* x, int64_t B, int64_t ld_in, float* y, int64_t ld_out);
+/* host in, interleaved frames[L][C] (WAV wire order, core/hrir.py:202-219 columns) -> planar y[C][ld_out] */
+int imp_conv_execute_interleaved(imp_plan* plan, const float* frames, int64_t C, float* y, int64_t ld_out);
+/* device in / device out, asynchronous on the context stream.
+ * x: channel b, sample i at d_x[b*chan_stride_in + i*elem_stride_in]; y: d_y[b*chan_stride_out + i]. */
+int imp_conv_execute_device(imp_plan* plan, const float* d_x, int64_t B, int64_t chan_stride_in,
+                            int64_t elem_stride_in, float* d_y, int64_t chan_stride_out);
+
+/* per-kernel timing with HIP events on the plan's stream (for bench.py's roofline block) */
+int imp_plan_set_timing(imp_plan* plan, int enable);
+/* Synchronises, then returns accumulated milliseconds of pass A / B / C and the number of launch
+ * groups measured since the last reset. */
+int imp_plan_get_timing(imp_plan* plan, double ms[3], int64_t* launches, int reset);
+
+/* debug: copy the workspace of the last launch group to the host (complex64 [chunk][N1][4096]) */
+int imp_plan_debug_run_stage(imp_plan* plan, const float* x, int64_t B, int64_t ld_in, int stage,
+                             float* ws_out_host);
+
+/* ---- K3: first significant peak ---------------------------------------------------------------
+ * core/impulse_response.py:32-70 ImpulseResponse.peak_index (twin core/decay.py:12-41):
+ * normalise by max|x| of the searched range, scipy.signal.find_peaks(+x and -x, height), minimum
+ * index; no peak -> argmax|x|; max|x| < 1e-20 -> 0.  Indices are relative to each row's start.
+ * The height test is done in fp64 (x/max >= peak_height) so it is exact for fp32 data.
+ * x: host, B rows at x + off[b], lengths len[b].
+ */
+int imp_peak_index(imp_ctx* ctx, const float* x, const int64_t* off, const int64_t* len, int64_t B,
+                   double peak_height, int64_t* idx_out, float* maxabs_out);
+int imp_peak_index_device(imp_ctx* ctx, const float* d_x, const int64_t* off, const int64_t* len,
+                          int64_t B, double peak_height, int64_t* idx_out, float* maxabs_out);
+
+/* ---- K4/K8: in-place gain, fades, decay window (elementwise) ---------------------------------
+ * core/hrir.py:530-544 (gain), :591-612 (Hann fade-in), :642-651 (crop + Hann fade-out),
+ * core/decay.py:383-403 apply_decay_window.
+ * y[i] = x[i] * gain * fade_in(i) * fade_out(i) * decay(i) for i < len[b]; any stage may be
+ * disabled (fade length 0, decay half_window < 0).
+ */
+typedef struct imp_window_params {
+  float gain;              /* linear */
+  int64_t fade_in;         /* samples: hann(2*fade_in)[:fade_in] on the head */
+  int64_t fade_out;        /* samples: hann(2*fade_out)[fade_out:] on the tail ending at len */
+  int64_t decay_start;     /* window_start */
+  int64_t decay_half;      /* half_window (< 0 disables) */
+  int64_t decay_knee;      /* knee_point_index: zero level beyond */
+  float decay_level_db;    /* window_level */
+} imp_window_params;
+int imp_apply_window(imp_ctx* ctx, float* x, const int64_t* off, const int64_t* len, int64_t B,
+                     const imp_window_params* params /* [B] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMPULSE_HIP_H_ */
