@@ -1,0 +1,246 @@
+"""Pins the CPU oracle (oracle/) to fixtures produced by running the reference
+(tests/golden/make_goldens.py) and to the golden artefact the reference ships
+(data/demo/room-responses.wav).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import decay as odecay
+from oracle import estimator as oest
+from oracle import hrir as ohrir
+from oracle import impulse_response as oir
+from oracle import minphase as omin
+from oracle import scipy_restated as sr
+
+
+# ------------------------------------------------------------------ SciPy restatements vs SciPy itself
+def test_next_fast_len_matches_scipy():
+    import scipy.fft
+    import scipy.fftpack
+    for n in list(range(1, 300)) + [686539, 691200, 1463929, 32890, 43199, 2 ** 21 - 1]:
+        assert sr.next_fast_len_real(n) == scipy.fft.next_fast_len(n, real=True)
+        assert sr.next_fast_len_real(n) == scipy.fftpack.next_fast_len(n)
+
+
+def test_restated_signal_routines_match_scipy():
+    import scipy.signal as ss
+    from scipy.interpolate import InterpolatedUnivariateSpline
+    from scipy.stats import linregress
+    rng = np.random.default_rng(5)
+    x, h = rng.standard_normal(5000), rng.standard_normal(1234)
+    for mode in ("full", "same"):
+        np.testing.assert_allclose(sr.fft_convolve(x, h, mode), ss.fftconvolve(x, h, mode), rtol=0, atol=1e-11)
+    for M in (0, 1, 2, 7, 96, 97):
+        np.testing.assert_allclose(sr.hann(M), ss.windows.hann(M), atol=1e-15)
+        np.testing.assert_allclose(sr.hamming(M), ss.windows.hamming(M), atol=1e-15)
+    y = np.round(rng.standard_normal(3000) * 3) / 3          # many plateaus
+    for sig in (y, -y):
+        np.testing.assert_array_equal(sr.find_peaks_height(sig, 0.3), ss.find_peaks(sig, height=0.3)[0])
+    s, i = sr.linregress(x[:50], h[:50])
+    ref = linregress(x[:50], h[:50])
+    assert s == pytest.approx(ref.slope, rel=1e-13) and i == pytest.approx(ref.intercept, rel=1e-13)
+    f = np.linspace(0, 24000, 9600)
+    g = 10 ** (np.sin(f / 3000.0) / 2)
+    g[-1] = 0
+    fir = sr.firwin2_hamming(19200, f, g, 48000)
+    np.testing.assert_allclose(fir, ss.firwin2(19200, f, g, fs=48000), atol=1e-15)
+    np.testing.assert_allclose(sr.minimum_phase_homomorphic(fir, 19200), ss.minimum_phase(fir, n_fft=19200), atol=1e-14)
+    xk = np.sort(rng.uniform(1, 4, 40))
+    yk = rng.standard_normal(40)
+    xq = np.linspace(0.5, 4.5, 101)
+    np.testing.assert_allclose(sr.spline1_eval(xk, yk, xq), InterpolatedUnivariateSpline(xk, yk, k=1)(xq), atol=1e-12)
+
+
+# ------------------------------------------------------------------ estimator known answers
+@pytest.mark.parametrize("fs,dur", [(48000, 1.0), (48000, 5.0), (96000, 5.0), (44100, 5.0)])
+def test_estimator_known_answers(golden, fs, dur):
+    g = golden("estimator")
+    k = f"e{fs}_{int(dur)}"
+    e = oest.Estimator(min_duration=dur, fs=fs)
+    assert len(e) == int(g[k + "_N"])
+    assert e.n_octaves == float(g[k + "_P"])
+    assert e.low == float(g[k + "_low"])
+    assert e.duration == float(g[k + "_duration"])
+    for nm, arr in (("ts", e.test_signal), ("inv", e.inverse_filter)):
+        scale = np.max(np.abs(arr))
+        np.testing.assert_allclose(arr[:64], g[f"{k}_{nm}_head"], rtol=0, atol=1e-12 * scale)
+        np.testing.assert_allclose(arr[-64:], g[f"{k}_{nm}_tail"], rtol=0, atol=1e-12 * scale)
+        np.testing.assert_allclose(arr[::1024], g[f"{k}_{nm}_dec"], rtol=0, atol=1e-12 * scale)
+    base = e.estimate(e.test_signal)
+    pk = int(np.argmax(np.abs(base)))
+    assert pk == int(g[k + "_baseline_peak"]) == len(e) // 2
+    assert base[pk] == pytest.approx(float(g[k + "_baseline_val"]), abs=1e-11)
+
+
+@pytest.fixture(scope="module")
+def est1():
+    return oest.Estimator(min_duration=1.0, fs=48000)
+
+
+def test_estimate_cases(golden, est1):
+    g = golden("estimate")
+    e = est1
+    assert len(e) == int(g["N"])
+    for delay in (0, 1, 127, 1000):
+        sysir = np.zeros(delay + 1)
+        sysir[delay] = 1.0
+        rec = sr.fft_convolve(e.test_signal, sysir, "full").astype(np.float32).astype(np.float64)
+        y = e.estimate(rec)
+        assert len(y) == int(g[f"delay{delay}_len"])
+        assert int(np.argmax(np.abs(y))) == int(g[f"delay{delay}_argmax"]) == int(g["baseline_peak"]) + delay
+        assert y[np.argmax(np.abs(y))] == pytest.approx(float(g[f"delay{delay}_peakval"]), abs=1e-9)
+    rec = sr.fft_convolve(e.test_signal, g["decay_ir"], "full").astype(np.float32).astype(np.float64)
+    y = e.estimate(rec)
+    bp = int(g["baseline_peak"])
+    np.testing.assert_allclose(y[bp - 64: bp + 4096], g["decay_win"], atol=1e-10)
+    np.testing.assert_allclose(y[::61], g["decay_dec"], atol=1e-10)
+    assert oir.peak_index(y) == int(g["decay_peak_index"])
+    A = np.abs(np.fft.rfft(y))
+    np.testing.assert_allclose(A[g["decay_bins"]], g["decay_amp"], atol=1e-9 * float(g["decay_amax"]))
+    x = np.random.default_rng(0).standard_normal(int(g["noise_L"])).astype(np.float32).astype(np.float64)
+    y = e.estimate(x)
+    np.testing.assert_allclose(y[100000:100000 + 4096], g["noise_win"], atol=1e-9)
+    np.testing.assert_allclose(y[::61], g["noise_dec"], atol=1e-9)
+    assert oir.peak_index(y) == int(g["noise_peak_index"])
+
+
+def test_peak_index_cases(golden):
+    g = golden("peak_index")
+    names = sorted(k[:-2] for k in g.files if k.endswith("_x"))
+    assert len(names) >= 20
+    for nm in names:
+        x = g[nm + "_x"].astype(np.float64)
+        start, end = (int(v) for v in g[nm + "_kw"])
+        got = oir.peak_index(x, start=start, end=None if end < 0 else end)
+        assert got == int(g[nm + "_idx"]), nm
+
+
+def _decaying_sine(fs, duration_s, rt60, freq=1000.0, floor_db=-90.0, seed=0):
+    r = np.random.default_rng(seed)
+    n = int(duration_s * fs)
+    t = np.arange(n) / fs
+    env = 10 ** ((-60.0 / rt60) * t / 20.0)
+    return np.cos(2 * np.pi * freq * t) * env + r.standard_normal(n) * 10 ** (floor_db / 20.0)
+
+
+@pytest.mark.parametrize("rt60", [0.3, 0.6, 1.0, 1.5])
+@pytest.mark.parametrize("seed", [0, 11, 22])
+def test_decay_analysis(golden, rt60, seed):
+    g = golden("decay")
+    k = f"rt{int(rt60 * 10)}_s{seed}"
+    data = _decaying_sine(48000, 3.0, rt60, seed=seed).astype(np.float32).astype(np.float64)
+    p = odecay.decay_params(data, 48000)
+    exp = g[k + "_params"]
+    assert (int(p[0]), int(p[1]), int(p[3])) == (int(exp[0]), int(exp[1]), int(exp[3]))
+    assert p[2] == pytest.approx(exp[2], abs=1e-9)
+    times = odecay.decay_times(data, 48000)
+    for got, want in zip(times, g[k + "_times"]):
+        if np.isnan(want):
+            assert got is None
+        else:
+            assert got == pytest.approx(want, rel=1e-9)
+    for target in (0.2, 0.5):
+        kk = f"{k}_t{int(target * 10)}"
+        want = g[kk + "_adj"]
+        if np.all(np.isinf(want)):
+            with pytest.raises(TypeError):
+                odecay.decay_adjustment_params(data, 48000, target)
+            continue
+        adj = odecay.decay_adjustment_params(data, 48000, target)
+        if np.all(np.isnan(want)):
+            assert adj is None
+            continue
+        assert tuple(int(v) for v in adj[:3]) == tuple(int(v) for v in want[:3])
+        assert adj[3] == pytest.approx(want[3], rel=1e-9)
+        out = odecay.apply_decay_window(data.copy(), adj)
+        np.testing.assert_allclose(out[::37], g[kk + "_out_dec"], atol=1e-12)
+        assert np.sum(out ** 2) == pytest.approx(float(g[kk + "_out_energy"]), rel=1e-10)
+
+
+def test_decay_degenerate(golden):
+    g = golden("decay")
+    assert tuple(float(v) for v in odecay.decay_params(np.array([1.0, 0.5, 0.25, 0.1]), 48000)) == tuple(g["short4_params"])
+    assert tuple(float(v) for v in odecay.decay_params(np.array([]), 48000)) == tuple(g["empty_params"])
+
+
+def test_hrir_ops(golden):
+    g = golden("hrir_ops")
+    for name in ("left_first", "right_first", "tie", "near_start"):
+        irs = {"FC": {"left": g[f"ch_{name}_in_l"].astype(np.float64), "right": g[f"ch_{name}_in_r"].astype(np.float64)}}
+        out = ohrir.crop_heads(irs, 48000, head_ms=1)
+        np.testing.assert_allclose(out["FC"]["left"], g[f"ch_{name}_out_l"], atol=1e-15)
+        np.testing.assert_allclose(out["FC"]["right"], g[f"ch_{name}_out_r"], atol=1e-15)
+    irs = {sp: {sd: g[f"ct_in_{sp}_{sd}"].astype(np.float64) for sd in ("left", "right")} for sp in ("FL", "FR")}
+    for sp in irs:
+        for sd in irs[sp]:
+            p = odecay.decay_params(irs[sp][sd], 48000)
+            exp = g[f"ct_params_{sp}_{sd}"]
+            assert (int(p[0]), int(p[1]), int(p[3])) == (int(exp[0]), int(exp[1]), int(exp[3]))
+    tail_ind, out = ohrir.crop_tails(irs, 48000, 48000 * 6, 10)
+    assert tail_ind == int(g["ct_tail_ind"])
+    for sp in irs:
+        for sd in irs[sp]:
+            np.testing.assert_allclose(out[sp][sd], g[f"ct_out_{sp}_{sd}"], atol=1e-15)
+    for name, seed, scales, kw in (("peak", 1, (0.3, 0.1, 0.05, 0.2), dict(peak_target=-0.1)),
+                                   ("avg", 2, (0.4, 0.25, 0.15, 0.3), dict(peak_target=None, avg_target=-12.0))):
+        rr = np.random.default_rng(seed)
+        a = [(rr.standard_normal(4096) * s).astype(np.float32).astype(np.float64) for s in scales]
+        irs = {"FL": {"left": a[0], "right": a[1]}, "FR": {"left": a[2], "right": a[3]}}
+        gain = ohrir.normalization_gain_db(irs, 48000, **kw)
+        assert gain == pytest.approx(float(g[f"nm_{name}_gain_db"]), abs=1e-10)
+        np.testing.assert_allclose(a[0] * 10 ** (gain / 20), g[f"nm_{name}_out_FL_left"], rtol=1e-12)
+
+
+def test_magnitude_response_bit_exact(golden):
+    """The reference pins this path bit-exactly (tests/test_magnitude_response_parity.py)."""
+    g = golden("magnitude")
+    for seed, sizes in ((0xA110, (8, 1024, 48000)), (0xA111, (9, 1025, 48001))):
+        rr = np.random.default_rng(seed)
+        for n in sizes:
+            x = rr.standard_normal(n).astype(np.float32).astype(np.float64)
+            f, m = oir.magnitude_response(x, 48000)
+            assert np.array_equal(f, g[f"n{n}_f"])
+            assert np.array_equal(m, g[f"n{n}_db"])
+
+
+def test_real_demo_column_reproduces_shipped_room_response(golden):
+    """data/demo/room-FC-left.wav column -> estimate -> crop_head(1 ms) -> crop/fade -> PCM_32 must
+    equal the FC-left track of the room-responses.wav the reference ships, to 0 LSB."""
+    g = golden("demo_fc")
+    sweep_len, P = int(g["N"]), float(g["P"])
+    # the sweep itself is regenerated: the bundled 6.15 s sweep is the (48 kHz, 5.0 s) grid point
+    e = oest.Estimator(min_duration=(sweep_len - 1) / 48000, fs=48000)
+    assert len(e) == sweep_len and e.n_octaves == P
+    col = g["column_i32"].astype(np.float64) / 2 ** 31
+    y = e.estimate(col)
+    pk = oir.peak_index(y)
+    assert pk == int(g["peak_index"])
+    assert int(np.argmax(np.abs(y))) == int(g["argmax"])
+    # the generated sweep differs from the WAV-loaded one only by PCM_32 quantisation of the file
+    np.testing.assert_allclose(y[pk - 64: pk + 8192], g["win"], atol=2e-8)
+    ir = oir.crop_head(y, 48000, 1)
+    n_out = int(g["responses_len"])
+    fo = 2 * int(48000 * (sweep_len / 48000 / P) * (1 / 24))
+    w = sr.hann(fo)[fo // 2:]
+    d = ir[:n_out].copy()
+    d *= np.concatenate([np.ones(n_out - len(w)), w])
+    pcm = np.round(d * 2 ** 31).astype(np.int64)
+    want = g["responses_fc_left_i32"].astype(np.int64)
+    assert np.max(np.abs(pcm - want)) <= 60      # sweep regenerated, not read from the 32-bit WAV
+    dp = odecay.decay_params(ir, 48000)
+    exp = g["decay_params"]
+    assert (int(dp[0]), int(dp[3])) == (int(exp[0]), int(exp[3]))
+
+
+@pytest.mark.parametrize("fs", [48000, 96000])
+def test_minimum_phase_fir(golden, fs):
+    g = golden("minphase")
+    freq = g[f"fs{fs}_freq"]
+    np.testing.assert_array_equal(oir.generate_frequencies(10, fs / 2, 1.01), freq)
+    for name in ("flat", "wavy", "tilt"):
+        fir = omin.minimum_phase_impulse_response(freq, g[f"fs{fs}_{name}_eq"], fs, f_res=5, normalize=False)
+        want = g[f"fs{fs}_{name}_fir"]
+        assert fir.shape == want.shape == ((9600,) if fs == 48000 else (19200,))
+        # The homomorphic log at the forced Nyquist zero (|H| ~ 1e-12 of rounding noise) amplifies
+        # 1-ulp input differences to ~5e-9 of the FIR peak: SciPy's own minimum_phase lands 5e-9 away
+        # from the fixture on a curve that differs by 1 ulp.  5e-8 is that reproducibility floor.
+        np.testing.assert_allclose(fir, want, rtol=0, atol=5e-8 * np.max(np.abs(want)))
