@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py - IRs/s of the batched ESS deconvolution on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch: every rank deconvolves one 7.1 x 2-ear
+measurement (BASELINE.json configs[1], "C2": 16 channels, 6.15 s sweep @48 kHz, column
+L = N + 2 fs = 391 270) that is already resident in HBM.  Channels shard across ranks with no
+data-path collective ("weak" scaling: one measurement per GPU per step); the only collective is
+the one-off RCCL broadcast of the prepared inverse-sweep spectrum from rank 0.
+
+The JSON line carries `roofline` (HIP-event time of the dominant kernel over the timed steps,
+priced in ALGORITHMIC bytes 8*L per IR) and `cpu_baseline` (the NumPy oracle of the reference's
+scipy.signal.convolve(x, inverse_filter, 'same') timed on this box's host cores, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "impulcifer-pip313_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = "impulse responses/sec (sweep deconv+FIR), 7.1×2-ear @48kHz, 1/2/4/8 GPU"
+
+WORKLOADS = {
+    # name: (fs, min_duration, channels per rank per step, description)
+    "c2": (48000, 5.0, 16, "C2: 7.1 layout (8 spk x 2 ear = 16 IRs), 6.15 s ESS sweep @48 kHz"),
+    "c3": (96000, 5.0, 26, "C3: 13-ch TrueHD layout x 2 ear @96 kHz (deconvolution stage only)"),
+}
+
+
+def synth_recordings(est, n_channels, seed0):
+    """SURVEY 8(d) recipe: per channel a sparse-tap room (direct sound at 64+37c, three later
+    taps) excited by the sweep, plus -70 dBFS noise; fp32, pitch padded to an even length."""
+    N, fs = len(est), est.fs
+    L = N + 2 * fs
+    pitch = (L + 1) & ~1
+    sweep = est.test_signal.astype(np.float32)
+    rec = np.zeros((n_channels, pitch), dtype=np.float32)
+    delays = []
+    for c in range(n_channels):
+        rng = np.random.default_rng(seed0 + c)
+        d0 = (64 + 37 * c) % 2048
+        taps = [(d0, 1.0)]
+        for d in rng.integers(100, 24000, size=3):
+            taps.append((d0 + int(d), float(0.3 * np.exp(-d / 9600.0) * rng.standard_normal())))
+        for d, gain in taps:
+            n = min(N, L - d)
+            rec[c, d:d + n] += np.float32(0.5 * gain) * sweep[:n]
+        rec[c, :L] += (rng.standard_normal(L) * 10 ** (-70 / 20)).astype(np.float32)
+        delays.append(d0)
+    return rec, L, pitch, delays
+
+
+def cpu_baseline(est, rec, L, budget_s=12.0):
+    """The oracle's restatement of estimate() (float64, nfft = next_fast_len, rfft(h) recomputed per
+    call exactly like core/impulse_response_estimator.py:149-151), serial over channels as the
+    reference ingests them (core/hrir.py:307-355).  Bounded sample of the same workload."""
+    from oracle.estimator import estimate
+    inv = np.asarray(est.inverse_filter, dtype=np.float64)
+    done, t0 = 0, time.perf_counter()
+    outs = {}
+    while True:
+        c = done % rec.shape[0]
+        y = estimate(rec[c, :L].astype(np.float64), inv)
+        if c not in outs:
+            outs[c] = y
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 512:
+            break
+    return dict(value=done / el, unit="IR/s", cores=1, kind="port",
+                sample=f"{done} IRs of the same synthetic batch, serial float64 NumPy pocketfft "
+                       f"(host has {os.cpu_count()} logical cores, {len(os.sched_getaffinity(0))} usable)"), outs
+
+
+def cpu_pooled(est, rec, L, budget_s=8.0):
+    """Same work through a thread pool of min(2*cpu, 32) workers - the reference's
+    core/parallel_processing.py:31-48 heuristic (pocketfft releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.estimator import estimate
+    inv = np.asarray(est.inverse_filter, dtype=np.float64)
+    workers = min(2 * (os.cpu_count() or 1), 32)
+    xs = [rec[c, :L].astype(np.float64) for c in range(rec.shape[0])]
+    done, t0 = 0, time.perf_counter()
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        while time.perf_counter() - t0 < budget_s:
+            list(pool.map(lambda x: estimate(x, inv), xs * max(1, (2 * workers) // len(xs))))
+            done += len(xs) * max(1, (2 * workers) // len(xs))
+    el = time.perf_counter() - t0
+    return dict(value=done / el, unit="IR/s", cores=workers, kind="port", sample=f"{done} IRs, thread pool")
+
+
+def load_traffic_profile(workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary
+    (profiles/), or None.  bench.py cannot collect PMC counters itself."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh).get(workload, {}).get("rows_kernel_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+
+    from impulse_hip import Context, ConvPlan
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.sharding import broadcast_plan_spectrum
+
+    fs, dur, B, desc = WORKLOADS[args.workload]
+    est = ImpulseResponseEstimator(min_duration=dur, fs=fs)
+    rec, L, pitch, delays = synth_recordings(est, B, seed0=0xC2 + 1000 * rank)
+    M = len(est)
+
+    ctx = Context(local_rank)
+    if rank == 0:
+        plan = ConvPlan(ctx, np.asarray(est.inverse_filter, dtype=np.float64), L, "same")
+    else:
+        plan = ConvPlan(ctx, None, L, "same", empty_M=M, n_filters=1)
+    bcast_bytes = 0
+    if world > 1:
+        bcast_bytes = broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0)   # RCCL over xGMI
+
+    # inputs/outputs resident in HBM before the clock starts (torch = device memory plumbing only)
+    d_x = torch.from_numpy(rec).to(device)
+    d_y = torch.empty((B, pitch), dtype=torch.float32, device=device)
+    torch.cuda.synchronize(device)
+
+    def step():
+        plan.execute_device(d_x.data_ptr(), B, pitch, d_y.data_ptr(), pitch)
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    plan.set_timing(not args.no_events)
+    plan.get_timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.barrier()
+    kernel_ms, launches = plan.get_timing(reset=True)
+    plan.set_timing(False)
+
+    # parity gate on what the timed loop produced (outside the timed region)
+    y = d_y.cpu().numpy()[:, :L]
+    peaks_ok = all(int(np.argmax(np.abs(y[c]))) == M // 2 + delays[c] for c in range(B))
+
+    result = None
+    if rank == 0:
+        irs_per_step = B * world
+        value = irs_per_step * args.steps / elapsed
+        alg_bytes_per_launch = 8.0 * L * min(B, plan.ws_channels)
+        names = ("cols_kernel<fwd> (pass A)", "rows_kernel (pass B)", "cols_kernel<inv> (pass C)")
+        roof = None
+        if launches > 0:
+            avg_ms = [m / launches for m in kernel_ms]
+            dom = int(np.argmax(avg_ms))
+            achieved = alg_bytes_per_launch / (avg_ms[dom] * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel=names[dom], achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=load_traffic_profile(args.workload),
+                        avg_kernel_ms=dict(zip(("pass_a", "pass_b", "pass_c"), avg_ms)),
+                        algorithmic_bytes_per_launch=alg_bytes_per_launch,
+                        path_achieved=value / world * 8.0 * L / 1e9,
+                        path_frac=value / world * 8.0 * L / 1e9 / HBM_PEAK_GBS)
+        cpu = None
+        parity = dict(peak_indices_exact=bool(peaks_ok))
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, outs = cpu_baseline(est, rec, L)
+            errs = []
+            for c, ref in outs.items():
+                A, R = np.abs(np.fft.rfft(y[c].astype(np.float64))), np.abs(np.fft.rfft(ref))
+                errs.append(float(np.max(np.abs(A - R)) / np.max(R)))
+                peaks_ok &= int(np.argmax(np.abs(ref))) == int(np.argmax(np.abs(y[c])))
+            parity = dict(peak_indices_exact=bool(peaks_ok), spectrum_max_rel_err=max(errs), tolerance=1e-6,
+                          channels_checked=len(errs))
+            cpu["pooled"] = cpu_pooled(est, rec, L)
+        result = {
+            "metric": METRIC, "value": value, "unit": "IR/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "stage": "K1 batched sweep deconvolution incl. 'same' crop "
+                       "(inverse-filter spectrum prepared once, outside the timed region)",
+                       "channels_per_gpu_per_step": B, "sweep_samples": M, "column_samples": L,
+                       "nfft": plan.nfft, "sharding": f"channels x{world}, no data-path collective; "
+                       f"one RCCL broadcast of {bcast_bytes} B spectrum at plan creation"},
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+        }
+        print(json.dumps(result))
+        sys.stdout.flush()
+    plan.close()
+    del d_x, d_y
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and not peaks_ok:
+        raise SystemExit("parity gate failed: deconvolved peak indices do not match the analytic truth")
+
+
+if __name__ == "__main__":
+    main()

@@ -242,6 +242,15 @@ extern "C" int imp_memcpy_d2h(imp_ctx* ctx, void* dst, const void* src, size_t b
   return IMP_OK;
 }
 
+extern "C" int imp_memcpy_d2d(imp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || (!dst && bytes) || (!src && bytes)) return fail(IMP_ERR_INVALID, "imp_memcpy_d2d: null argument");
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (!bytes) return IMP_OK;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return IMP_OK;
+}
+
 extern "C" int imp_memset(imp_ctx* ctx, void* dptr, int value, size_t bytes) {
   if (!ctx || (!dptr && bytes)) return fail(IMP_ERR_INVALID, "imp_memset: null argument");
   int rc = ctx_bind(ctx);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "imp_free": (C.c_int, [_vp, _vp]),
     "imp_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "imp_memcpy_d2h": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "imp_memcpy_d2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "imp_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
     "imp_conv_plan_create": (C.c_int, [_vp, _pd, _i64, _i64, _i64, _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "imp_conv_plan_create_empty": (C.c_int, [_vp, _i64, _i64, _i64, C.c_int, _i64, C.POINTER(_vp)]),
@@ -168,6 +169,9 @@ class Context:
     def d2h(self, arr, dptr):
         assert arr.flags["C_CONTIGUOUS"]
         _check(self._lib.imp_memcpy_d2h(self._h, arr.ctypes.data_as(_vp), _vp(int(dptr)), arr.nbytes))
+
+    def d2d(self, dst, src, nbytes):
+        _check(self._lib.imp_memcpy_d2d(self._h, _vp(int(dst)), _vp(int(src)), int(nbytes)))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -1,0 +1,218 @@
+"""Decay analysis (Lundeby knee, Schroeder decay times) and decay-window adjustment.
+
+Surface of reference core/decay.py:12-403.  The analysis is scalar control flow over at most
+~70 window levels plus reductions over <= 2 s of samples; it runs on the host in float64 (SURVEY
+section 2.2 row K7 keeps this control flow host-side).  The first-peak search (K3) and the
+application of the decay window (K8) run on the device.
+"""
+import numpy as np
+
+from . import _native
+from .audio_io import running_mean
+
+EPSILON = 1e-20
+
+
+def _peak_index(data, start=0, end=None, peak_height=0.12589):
+    """First local extremum within -18 dB of the maximum (device kernel K3)."""
+    n = len(data)
+    if n == 0:
+        return 0
+    if end is None:
+        end = n
+    seg = np.asarray(data)[start:end]
+    if len(seg) == 0:
+        return start
+    idx, _ = _native.default_context().peak_index([seg], peak_height)
+    return int(idx[0]) + start
+
+
+class _Levels:
+    """Window-mean levels of the squared, peak-normalised analysis segment."""
+
+    def __init__(self, sq, fs):
+        self.sq = sq
+        self.fs = fs
+        self.t = np.linspace(0, len(sq) / fs, len(sq))
+
+    def windows(self, n, w, wd):
+        lv = 10 * np.log10(np.maximum(self.sq[: n * w].reshape(n, w).mean(axis=1), EPSILON))
+        return np.arange(n) * wd + wd / 2, lv
+
+    def mean_db(self, a, b):
+        return 10 * np.log10(np.maximum(np.mean(self.sq[a:b]), EPSILON))
+
+    def nearest(self, time):
+        return int(np.argmin(np.abs(self.t - time)))
+
+
+def _fit_line(x, y):
+    """Least-squares slope/intercept exactly as scipy.stats.linregress forms them."""
+    xm, ym = np.mean(x), np.mean(y)
+    c = np.cov(x, y, bias=1)
+    slope = c[0, 1] / c[0, 0]
+    return slope, ym - slope * xm
+
+
+def _first_le(values, level):
+    hit = np.flatnonzero(values <= level)
+    return int(hit[0]) if hit.size else None
+
+
+def decay_params(data, fs):
+    """(peak_index, knee_point_index, noise_floor_dB, window_size) by the Lundeby method."""
+    ir = np.asarray(data, dtype=np.float64)
+    n_ir = len(ir)
+    if n_ir < 10:
+        return 0, n_ir, -200.0, n_ir if n_ir > 0 else 1
+
+    peak = _peak_index(ir)
+    end = min(peak + int(2 * fs), n_ir)
+    if peak >= end:
+        peak = min(max(peak, 0), n_ir - 1)
+        seg = ir[peak:peak + 1].copy()
+    else:
+        seg = ir[peak:end].copy()
+    top = np.max(np.abs(seg))
+    if top >= EPSILON:
+        seg = seg / top
+    lv = _Levels(seg ** 2, fs)
+    n_sq = len(lv.sq)
+    whole_db = lambda: 10 * np.log10(max(np.mean(lv.sq), EPSILON))   # noqa: E731
+
+    wd = 0.03
+    n = int(n_sq / fs / wd) if fs > 0 else 0
+    if n == 0:
+        return peak, peak + n_sq, whole_db(), max(1, n_sq)
+    w0 = max(int(n_sq / n), 1)
+    t_win, levels = lv.windows(n, w0, wd)
+
+    tail_from = int(n_sq * 0.9)
+    floor = lv.mean_db(tail_from, n_sq) if tail_from < n_sq else lv.mean_db(0, n_sq)
+
+    close = np.flatnonzero(levels <= floor + 10.0)
+    stop = int(close[0]) if close.size and close[0] > 0 else len(levels)
+    if stop < 2:
+        if len(levels) < 2:
+            return peak, peak + n_sq, floor, w0
+        stop = len(levels)
+    slope, icpt = _fit_line(t_win[:stop], levels[:stop])
+    if np.isnan(slope) or abs(slope) < EPSILON:
+        return peak, peak + n_sq, floor, w0
+    knee_time = np.clip((floor - icpt) / slope, lv.t[0], lv.t[-1])
+
+    # re-window: three windows per 10 dB of decay
+    per10 = abs(slope) * 3
+    wd = lv.t[-1] / 3.0 if per10 < EPSILON else 10 / per10
+    n = int(n_sq / fs / wd) if (fs > 0 and wd > EPSILON) else 1
+    n = max(n, 1)
+    w = max(int(n_sq / n), 1)
+    t_win, levels = lv.windows(n, w, wd)
+
+    after = np.flatnonzero(t_win >= knee_time)
+    if after.size:
+        k_idx = int(after[0])
+    else:
+        k_idx = len(t_win) - 1
+        knee_time = t_win[-1]
+    k_level = levels[k_idx]
+
+    total = lv.t[-1]
+    for _ in range(5):
+        i0 = _first_le(levels, k_level - 5)
+        if i0 is None:
+            break
+        t0 = max(t_win[i0], 0.1 * total)
+        if t0 > t_win[-1]:
+            break
+        a, b = lv.nearest(t0), lv.nearest(min(t0 + knee_time, total))
+        if a >= b:
+            break
+        floor = lv.mean_db(a, b)
+        hi = _first_le(levels, floor + 8)
+        lo = _first_le(levels, floor + 28)
+        if hi is None or lo is None:
+            break
+        hi, lo = hi - 1, max(lo - 1, 0)
+        if hi <= lo + 1:
+            break
+        s2, i2 = _fit_line(t_win[lo:hi], levels[lo:hi])
+        if np.isnan(s2) or abs(s2) < EPSILON:
+            break
+        t_new = np.clip((floor - i2) / s2, t_win[0], t_win[-1])
+        after = np.flatnonzero(t_win >= t_new)
+        new_idx = int(after[0]) if after.size else len(t_win) - 1
+        same = new_idx == k_idx
+        k_idx = new_idx
+        knee_time = t_win[k_idx]
+        if same:
+            break
+        k_level = levels[k_idx]
+
+    return peak, peak + lv.nearest(knee_time), floor, w
+
+
+def decay_times(data, fs, peak_ind=None, knee_point_ind=None, noise_floor=None, window_size=None):
+    """EDT, RT20, RT30, RT60 from the Schroeder backward integral (None where the dynamic range
+    above the noise floor is insufficient)."""
+    ir = np.asarray(data, dtype=np.float64)
+    if peak_ind is None or knee_point_ind is None or noise_floor is None:
+        peak_ind, knee_point_ind, noise_floor, window_size = decay_params(ir, fs)
+    t = np.linspace(0, len(ir) / fs, len(ir))
+    knee = knee_point_ind - peak_ind
+    env = np.abs(ir[peak_ind:] / np.max(np.abs(ir[peak_ind:])))
+    energy = env ** 2
+    sch = 10 * np.log10(np.cumsum(energy[knee::-1] / np.sum(energy[:knee]))[:0:-1])
+
+    half = window_size // 2
+    lead = min(half, peak_ind)
+    trail = min(half, len(ir) - (peak_ind + knee))
+    skew = half - lead
+    part = ir[peak_ind - lead: peak_ind + knee + trail].copy()
+    part /= np.max(np.abs(part))
+    smooth = 10 * np.log10(running_mean(part ** 2, window_size) + 1e-18)
+    a = max(int(len(sch) * 0.1), skew)
+    b = min(int(len(sch) * 0.9), skew + len(smooth))
+    offset = np.mean(sch[a:b] - smooth[a - skew: b - skew])
+
+    result = []
+    for top, bottom, span in ((-1, -10, -10), (-5, -25, -20), (-5, -35, -30), (-5, -65, -60)):
+        value = None
+        if bottom >= noise_floor + offset + 10:
+            i_top, i_bot = _first_le(sch, top), _first_le(sch, bottom)
+            if i_top is not None and i_bot is not None and i_bot - i_top >= 2:
+                slope, _ = _fit_line(t[i_top:i_bot], sch[i_top:i_bot])
+                value = span / slope
+        result.append(value)
+    return tuple(result)
+
+
+def decay_adjustment_params(data, fs, target):
+    """(window_start, half_window, knee_point_index, window_level) or None when the measured
+    decay is already faster than ``target`` seconds per 60 dB."""
+    peak, knee, _, _ = decay_params(data, fs)
+    measured = None
+    for rt, span in zip(decay_times(data, fs), (-10, -20, -30, -60)):
+        if not rt:
+            break
+        measured = span / rt                     # dB/s from the longest defined decay time
+    wanted = -60 / target
+    if wanted > measured:                        # TypeError when nothing is defined, as the reference
+        return None
+    knee_s = knee / fs
+    start = peak + 2 * (fs // 1000)
+    return start, knee - start, knee, wanted * knee_s - measured * knee_s
+
+
+def apply_decay_window(data, params):
+    """In-place ``data *= 10**(-level*(window-1)/20)`` with window = ones | falling Hann | zeros
+    (device kernel K8)."""
+    if params is None:
+        return data
+    start, half, knee, level = params
+    if start + half != knee or knee > len(data) or start < 0 or half < 0:
+        raise ValueError("operands could not be broadcast together: decay window does not tile the data")
+    out = _native.default_context().apply_window(
+        [data], [dict(gain=1.0, decay_start=start, decay_half=half, decay_knee=knee, decay_level_db=level)])[0]
+    data[:] = out
+    return data

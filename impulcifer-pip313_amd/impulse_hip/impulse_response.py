@@ -1,0 +1,95 @@
+"""ImpulseResponse: one measured channel (class surface of reference core/impulse_response.py:15-188).
+
+``data`` stays a public, writable NumPy array at all times (callers mutate and re-bind it); the
+array work - first-peak search, FIR filtering, decay windows - is sent to the device per call.
+"""
+from copy import deepcopy
+
+import numpy as np
+
+from . import _native, decay
+from .audio_io import magnitude_response
+
+try:                                            # plot mixin is optional (matplotlib-free workers)
+    from .plotting import ImpulseResponsePlotter as _PlotBase   # pragma: no cover
+except Exception:                               # noqa: BLE001
+    class _PlotBase(object):
+        pass
+
+EPSILON = 1e-20
+
+
+def fir_convolve_full(x, taps):
+    """scipy.signal.convolve(x, taps, 'full') on the device (K5)."""
+    x = np.asarray(x)
+    taps = np.asarray(taps, dtype=np.float64)
+    if len(x) == 0 or len(taps) == 0:
+        return np.zeros(0)
+    ctx = _native.default_context()
+    plan = _native.ConvPlan(ctx, taps, len(x), "full")
+    try:
+        return plan.execute(x).astype(np.float64)
+    finally:
+        plan.close()
+
+
+class ImpulseResponse(_PlotBase):
+    def __init__(self, data, fs, recording=None):
+        self.fs = fs
+        self.data = data
+        self.recording = recording
+
+    def copy(self):
+        return deepcopy(self)
+
+    def __len__(self):
+        return len(self.data)
+
+    def duration(self):
+        return len(self) / self.fs
+
+    def peak_index(self, start=0, end=None, peak_height=0.12589):
+        """Index of the first positive or negative peak within -18 dB of the largest sample."""
+        return decay._peak_index(self.data, start, end, peak_height)
+
+    def decay_params(self):
+        return decay.decay_params(self.data, self.fs)
+
+    def decay_times(self, peak_ind=None, knee_point_ind=None, noise_floor=None, window_size=None):
+        return decay.decay_times(self.data, self.fs, peak_ind, knee_point_ind, noise_floor, window_size)
+
+    def crop_head(self, head_ms=1):
+        if len(self.data) == 0:
+            return
+        first = self.peak_index() - int(self.fs * head_ms / 1000)
+        self.data = self.data[max(first, 0):]
+
+    def shift(self, samples):
+        """Delay (samples > 0) or advance (samples < 0) keeping the length."""
+        n = len(self.data)
+        if samples > 0:
+            self.data = np.concatenate((np.zeros(samples), self.data))[:n]
+        elif samples < 0:
+            rest = self.data[-samples:]
+            self.data = np.pad(rest, (0, n - len(rest))) if len(rest) < n else rest
+
+    def equalize(self, fir):
+        """Filter with a FIR: data becomes the full convolution (length n + taps - 1)."""
+        self.data = fir_convolve_full(self.data, fir)
+
+    def resample(self, fs):
+        raise NotImplementedError(
+            "resample depends on nnresample, which has no oracle in this build (parity unpinned); "
+            "out of scope for the device path")
+
+    def convolve(self, x):
+        return fir_convolve_full(x, self.data)
+
+    def decay_adjustment_params(self, target):
+        return decay.decay_adjustment_params(self.data, self.fs, target)
+
+    def adjust_decay(self, target):
+        decay.apply_decay_window(self.data, self.decay_adjustment_params(target))
+
+    def magnitude_response(self):
+        return magnitude_response(self.data, self.fs)

@@ -1,0 +1,49 @@
+"""Channel sharding across the GPUs of one node: one process per GPU, no data-path collective.
+
+Every speaker x ear channel is independent; the only shared datum is the prepared inverse-sweep
+spectrum, which rank 0 builds (fp64 host FFT) and every other rank receives through ONE broadcast
+(RCCL over xGMI when the process group backend is "nccl"; gloo in the CPU tests).
+The reference's counterpart is the thread/process pool over channels
+(core/parallel_utils.py:97-152, core/parallel_processing.py:84-140).
+"""
+import numpy as np
+
+
+def shard_channels(n_channels, world_size, rank, keep_pairs=True):
+    """Contiguous block [lo, hi) of channels for ``rank``.  With ``keep_pairs`` the unit is a
+    left/right pair, so interleaved stereo frames never straddle two devices."""
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError("bad rank/world_size")
+    unit = 2 if keep_pairs and n_channels % 2 == 0 else 1
+    units = n_channels // unit
+    base, extra = divmod(units, world_size)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo * unit, hi * unit
+
+
+def broadcast_bytes(buf, dist, src=0):
+    """Broadcast a torch uint8 tensor in place from ``src`` (thin wrapper so tests can use gloo)."""
+    dist.broadcast(buf, src=src)
+    return buf
+
+
+def broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0):
+    """Rank ``src`` sends its plan's prepared spectrum; the others load it into their (empty) plan."""
+    dptr, nbytes = plan.spectrum_buffer()
+    staging = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    if dist.get_rank() == src:
+        ctx.d2d(staging.data_ptr(), dptr, nbytes)
+        ctx.synchronize()
+    dist.broadcast(staging, src=src)
+    if dist.get_rank() != src:
+        torch.cuda.synchronize(device)
+        ctx.d2d(dptr, staging.data_ptr(), nbytes)
+        ctx.synchronize()
+    return nbytes
+
+
+def split_evenly(total, parts):
+    """Sizes of ``parts`` near-equal chunks of ``total`` items."""
+    base, extra = divmod(int(total), int(parts))
+    return np.array([base + (1 if i < extra else 0) for i in range(parts)], dtype=np.int64)

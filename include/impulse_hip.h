@@ -55,6 +55,7 @@ int imp_malloc(imp_ctx* ctx, size_t bytes, void** dptr);
 int imp_free(imp_ctx* ctx, void* dptr);
 int imp_memcpy_h2d(imp_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
 int imp_memcpy_d2h(imp_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
+int imp_memcpy_d2d(imp_ctx* ctx, void* dst_device, const void* src_device, size_t bytes);  /* async on the ctx stream */
 int imp_memset(imp_ctx* ctx, void* dptr, int value, size_t bytes);
 
 /* ---- K1/K5: batched FFT convolution plans ---------------------------------------------------

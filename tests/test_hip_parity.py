@@ -1,0 +1,433 @@
+"""GPU parity tests: the HIP path (through the ctypes C-ABI and the product classes) against the
+CPU oracle on the same seeded inputs, against the reference-generated golden fixtures, and - at
+BASELINE.json's full sizes - through size-independent properties.
+
+Tolerances (north_star): magnitude spectra within 1e-6 of the spectrum peak in fp32
+(max|dA| / max|A| <= 1e-6), IR peak indices sample-exact.  Time-domain samples are held to
+1e-6 of the IR peak as well.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SPEC_TOL = 1e-6      # max |dA| / max |A| on |rfft(ir)|
+TIME_TOL = 1e-6      # max |dy| / max |y|
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - b)) / np.max(np.abs(b)))
+
+
+def spec_rel(y, ref):
+    A = np.abs(np.fft.rfft(np.asarray(y, dtype=np.float64)))
+    R = np.abs(np.fft.rfft(ref))
+    return float(np.max(np.abs(A - R)) / np.max(R))
+
+
+# ------------------------------------------------------------------------------------------------
+# K1/K5: convolution plans against the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,M", [(1, 1), (17, 5), (1000, 999), (70001, 61000), (150000, 100001),
+                                 (243635, 147635), (391270, 295270)])
+@pytest.mark.parametrize("mode", ["same", "full"])
+def test_conv_matches_oracle(gpu_ctx, L, M, mode):
+    from impulse_hip import ConvPlan
+    from oracle.scipy_restated import fft_convolve
+    rng = np.random.default_rng(L * 31 + M)
+    x = rng.standard_normal((3, L)).astype(np.float32)
+    x[2] = 0.0                                                   # an all-zero (silent) channel
+    h = rng.standard_normal(M) * np.exp(-np.arange(M) / max(M / 5.0, 1.0))
+    plan = ConvPlan(gpu_ctx, h, L, mode)
+    y = plan.execute(x)
+    plan.close()
+    assert y.shape == (3, L if mode == "same" else L + M - 1)
+    assert not np.any(y[2])                                      # zero in -> exactly zero out
+    for b in range(2):
+        ref = fft_convolve(x[b].astype(np.float64), h, mode)
+        assert rel(y[b], ref) <= TIME_TOL
+        if len(ref) > 8:
+            assert spec_rel(y[b], ref) <= SPEC_TOL
+
+
+def test_conv_full_size_c5_properties(gpu_ctx):
+    """C4/C5 shape (L = M = 2^20, nfft 2^21): identity filter, linearity, delay equivariance."""
+    from impulse_hip import ConvPlan
+    L = M = 1 << 20
+    rng = np.random.default_rng(0xC5)
+    x = rng.standard_normal((4, L)).astype(np.float32)
+    x[2] = (2.0 * x[0] - 0.5 * x[1])                             # exact in fp32? not exactly; use oracle-free bound
+    delta = np.zeros(M)
+    delta[(M - 1) // 2] = 1.0                                    # 'same' window of a centred delta = identity
+    plan = ConvPlan(gpu_ctx, delta, L, "same")
+    y = plan.execute(x)
+    plan.close()
+    for b in range(4):
+        assert rel(y[b], x[b].astype(np.float64)) <= TIME_TOL
+    h = rng.standard_normal(M) * np.exp(-np.arange(M) / 50000.0)
+    plan = ConvPlan(gpu_ctx, h, L, "same")
+    y = plan.execute(x)
+    xd = np.zeros_like(x[:1])
+    xd[0, 1000:] = x[0, :-1000]                                  # delayed copy of channel 0
+    yd = plan.execute(xd)
+    y2 = plan.execute(x)                                         # determinism: bit-identical reruns
+    plan.close()
+    assert np.array_equal(y, y2)
+    lin = 2.0 * y[0].astype(np.float64) - 0.5 * y[1].astype(np.float64)
+    scale = np.max(np.abs(lin))
+    assert np.max(np.abs(y[2] - lin)) / scale <= 3e-6            # three fp32 results combined
+    assert np.max(np.abs(yd[0, 1000:] - y[0, :-1000].astype(np.float64))) / scale <= 2e-6
+
+
+def test_conv_interleaved_and_per_channel_filters(gpu_ctx):
+    from impulse_hip import ConvPlan
+    from oracle.scipy_restated import fft_convolve
+    rng = np.random.default_rng(77)
+    L, M = 100001, 9600                                          # odd L, even taps -> odd crop offset
+    frames = rng.standard_normal((L, 4)).astype(np.float32)
+    firs = rng.standard_normal((4, M)) * 0.05
+    p = ConvPlan(gpu_ctx, firs[0], L, "same")
+    yi = p.execute_interleaved(frames)
+    yp = p.execute(np.ascontiguousarray(frames.T))
+    p.close()
+    assert np.array_equal(yi, yp)                                # wire-order loader == planar loader
+    for c in range(4):
+        assert rel(yi[c], fft_convolve(frames[:, c].astype(np.float64), firs[0], "same")) <= TIME_TOL
+    p = ConvPlan(gpu_ctx, firs, L, "full")
+    y = p.execute(np.ascontiguousarray(frames.T))
+    p.close()
+    for c in range(4):
+        assert rel(y[c], fft_convolve(frames[:, c].astype(np.float64), firs[c], "full")) <= TIME_TOL
+
+
+def test_conv_many_channels_cross_workspace_groups(gpu_ctx):
+    """More channels than one launch group: chunking must not mix channels."""
+    from impulse_hip import ConvPlan
+    from oracle.scipy_restated import fft_convolve
+    rng = np.random.default_rng(5)
+    L, M, B = 50000, 30000, 11
+    x = rng.standard_normal((B, L)).astype(np.float32) * (1 + np.arange(B))[:, None]
+    h = rng.standard_normal(M)
+    p = ConvPlan(gpu_ctx, h, L, "same", ws_channels=4)
+    y = p.execute(x)
+    p.close()
+    for b in (0, 3, 4, 7, 10):
+        assert rel(y[b], fft_convolve(x[b].astype(np.float64), h, "same")) <= TIME_TOL
+
+
+def test_conv_error_paths(gpu_ctx):
+    from impulse_hip import ConvPlan, NativeError
+    with pytest.raises(NativeError):
+        ConvPlan(gpu_ctx, np.ones(4), 3_000_000, "same")         # nfft > 2^21: unsupported, loud
+    p = ConvPlan(gpu_ctx, np.ones(4), 100, "same")
+    with pytest.raises(ValueError):
+        p.execute(np.zeros((2, 99), np.float32))
+    p.close()
+    with pytest.raises(NativeError):
+        ConvPlan(gpu_ctx, np.ones((2, 4)), 100, "same").execute(np.zeros((3, 100), np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# estimator: the reference's own round-trip tests (tests/test_estimator_roundtrip.py) on the GPU
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def est1(gpu_ctx):
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    return ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+
+
+@pytest.fixture(scope="module")
+def oracle_est1():
+    from oracle.estimator import Estimator
+    return Estimator(min_duration=1.0, fs=48000)
+
+
+def test_estimator_setup_matches_oracle(est1, oracle_est1):
+    assert len(est1) == len(oracle_est1) == 147635
+    np.testing.assert_allclose(est1.test_signal, oracle_est1.test_signal, atol=1e-15)
+    np.testing.assert_allclose(est1.inverse_filter, oracle_est1.inverse_filter,
+                               atol=1e-13 * np.max(np.abs(oracle_est1.inverse_filter)))
+
+
+@pytest.mark.parametrize("delay", [0, 1, 127, 1000])
+def test_estimate_recovers_delayed_unit_impulse_peak(est1, golden, delay):
+    from oracle.scipy_restated import fft_convolve
+    g = golden("estimate")
+    sysir = np.zeros(delay + 1)
+    sysir[delay] = 1.0
+    rec = fft_convolve(est1.test_signal, sysir, "full").astype(np.float32)
+    y = est1.estimate(rec)
+    assert len(y) == len(rec) == int(g[f"delay{delay}_len"])
+    assert int(np.argmax(np.abs(y))) == int(g[f"delay{delay}_argmax"]) == len(est1) // 2 + delay
+    assert y[np.argmax(np.abs(y))] == pytest.approx(float(g[f"delay{delay}_peakval"]), abs=1e-6)
+
+
+def test_estimate_unit_impulse_has_low_noise_floor(est1):
+    y = est1.estimate(est1.test_signal)
+    peak = int(np.argmax(np.abs(y)))
+    assert peak == len(est1) // 2
+    outside = np.concatenate((y[: peak - 50], y[peak + 50:]))
+    assert np.abs(y[peak]) == pytest.approx(1.0, abs=0.05)
+    assert 20 * np.log10(np.abs(y[peak]) / np.max(np.abs(outside))) > 40.0
+
+
+def test_estimate_golden_cases(est1, golden):
+    from impulse_hip.impulse_response import ImpulseResponse
+    from oracle.scipy_restated import fft_convolve
+    g = golden("estimate")
+    bp = int(g["baseline_peak"])
+    rec = fft_convolve(est1.test_signal, g["decay_ir"], "full").astype(np.float32)
+    y = est1.estimate(rec)
+    pkv = np.max(np.abs(g["decay_win"]))
+    assert np.max(np.abs(y[bp - 64: bp + 4096] - g["decay_win"])) / pkv <= TIME_TOL
+    assert np.max(np.abs(y[::61] - g["decay_dec"])) / pkv <= TIME_TOL
+    A = np.abs(np.fft.rfft(y))
+    assert np.max(np.abs(A[g["decay_bins"]] - g["decay_amp"])) / float(g["decay_amax"]) <= SPEC_TOL
+    assert ImpulseResponse(y, 48000).peak_index() == int(g["decay_peak_index"])
+    # recovered waveform correlates with the system IR (reference test :75-85)
+    got = y[bp: bp + 600]
+    corr = np.dot(got, g["decay_ir"]) / (np.linalg.norm(got) * np.linalg.norm(g["decay_ir"]))
+    assert corr > 0.99 and int(np.argmax(np.abs(got))) == 31
+    x = np.random.default_rng(0).standard_normal(int(g["noise_L"])).astype(np.float32)
+    y = est1.estimate(x)
+    pkv = np.max(np.abs(g["noise_dec"]))
+    assert np.max(np.abs(y[100000:100000 + 4096] - g["noise_win"])) / pkv <= TIME_TOL
+    assert np.max(np.abs(y[::61] - g["noise_dec"])) / pkv <= TIME_TOL
+    A = np.abs(np.fft.rfft(y))
+    assert np.max(np.abs(A[g["noise_bins"]] - g["noise_amp"])) / float(g["noise_amax"]) <= SPEC_TOL
+    assert ImpulseResponse(y, 48000).peak_index() == int(g["noise_peak_index"])
+
+
+def test_estimate_batch_c2_full_size_analytic_peaks(gpu_ctx):
+    """BASELINE config 2: 8 speakers x 2 ears, 6.15 s sweep @48 kHz, column L = N + 2 fs.
+    Analytic truth, no oracle needed: a sweep delayed by d deconvolves to a peak at N//2 + d."""
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    e = ImpulseResponseEstimator(min_duration=5.0, fs=48000)
+    N, L = len(e), len(e) + 96000
+    assert (N, L) == (295270, 391270)
+    sweep = e.test_signal.astype(np.float32)
+    rec = np.zeros((16, L), dtype=np.float32)
+    delays = [64 + 37 * c for c in range(16)]
+    for c, d in enumerate(delays):
+        rec[c, d:d + N] += (0.5 + 0.03 * c) * sweep
+        rec[c, d + 700:d + 700 + N] += 0.02 * sweep[: min(N, L - d - 700)]     # a weak later reflection
+    y = e.estimate_batch(rec, dtype=np.float32)
+    assert y.shape == (16, L)
+    for c, d in enumerate(delays):
+        assert int(np.argmax(np.abs(y[c]))) == N // 2 + d
+    # batched == one-by-one, bit for bit; frames path == planar path
+    assert np.array_equal(y[5], e.estimate(rec[5]).astype(np.float32))
+    yf = e.estimate_frames(np.ascontiguousarray(rec[:4].T), dtype=np.float32)
+    assert np.array_equal(yf, y[:4])
+
+
+# ------------------------------------------------------------------------------------------------
+# K3 peak index, K4/K8 windows, decay, container ops - against goldens from the reference
+# ------------------------------------------------------------------------------------------------
+def test_peak_index_golden_cases(gpu_ctx, golden):
+    from impulse_hip.impulse_response import ImpulseResponse
+    g = golden("peak_index")
+    names = sorted(k[:-2] for k in g.files if k.endswith("_x"))
+    rows, want = [], []
+    for nm in names:
+        start, end = (int(v) for v in g[nm + "_kw"])
+        got = ImpulseResponse(g[nm + "_x"], 48000).peak_index(start=start, end=None if end < 0 else end)
+        assert got == int(g[nm + "_idx"]), nm
+        if start == 0 and end < 0 and len(g[nm + "_x"]):
+            rows.append(g[nm + "_x"])
+            want.append(int(g[nm + "_idx"]))
+    idx, _ = gpu_ctx.peak_index(rows)                            # ragged batch in one call
+    assert list(idx) == want
+
+
+def test_peak_index_matches_oracle_on_long_rows(gpu_ctx):
+    from oracle.impulse_response import peak_index
+    rng = np.random.default_rng(9)
+    rows = []
+    for n in (391270, 33750, 4097):
+        x = (rng.standard_normal(n) * 0.01).astype(np.float32)
+        p = int(n * 0.44)
+        x[p:p + 400] += (np.sin(np.arange(400) / 3.0) * np.exp(-np.arange(400) / 60.0)).astype(np.float32)
+        rows.append(x)
+    idx, mx = gpu_ctx.peak_index(rows)
+    for r, i, m in zip(rows, idx, mx):
+        assert int(i) == peak_index(r.astype(np.float64))
+        assert m == np.max(np.abs(r))
+
+
+def _decaying_sine(fs, duration_s, rt60, freq=1000.0, floor_db=-90.0, seed=0):
+    r = np.random.default_rng(seed)
+    n = int(duration_s * fs)
+    t = np.arange(n) / fs
+    env = 10 ** ((-60.0 / rt60) * t / 20.0)
+    return np.cos(2 * np.pi * freq * t) * env + r.standard_normal(n) * 10 ** (floor_db / 20.0)
+
+
+@pytest.mark.parametrize("rt60", [0.3, 0.6, 1.0, 1.5])
+def test_decay_analysis_and_window_golden(gpu_ctx, golden, rt60):
+    from impulse_hip import decay
+    from impulse_hip.parallel_workers import process_decay_worker
+    g = golden("decay")
+    for seed in (0, 11, 22):
+        k = f"rt{int(rt60 * 10)}_s{seed}"
+        data = _decaying_sine(48000, 3.0, rt60, seed=seed).astype(np.float32).astype(np.float64)
+        p = decay.decay_params(data, 48000)
+        exp = g[k + "_params"]
+        assert (int(p[0]), int(p[1]), int(p[3])) == (int(exp[0]), int(exp[1]), int(exp[3]))
+        assert p[2] == pytest.approx(exp[2], abs=1e-9)
+        for got, want in zip(decay.decay_times(data, 48000), g[k + "_times"]):
+            assert (got is None) if np.isnan(want) else got == pytest.approx(want, rel=1e-9)
+        for target in (0.2, 0.5):
+            kk = f"{k}_t{int(target * 10)}"
+            want = g[kk + "_adj"]
+            if np.all(np.isinf(want)):
+                with pytest.raises(TypeError):
+                    decay.decay_adjustment_params(data, 48000, target)
+                continue
+            adj = decay.decay_adjustment_params(data, 48000, target)
+            if np.all(np.isnan(want)):
+                assert adj is None
+                continue
+            assert tuple(int(v) for v in adj[:3]) == tuple(int(v) for v in want[:3])
+            _, _, out = process_decay_worker(("FL", "left", data, 48000, target))
+            assert np.max(np.abs(out[::37] - g[kk + "_out_dec"])) <= 2e-7     # fp32 store of a <= 1.0 signal
+            assert np.sum(out ** 2) == pytest.approx(float(g[kk + "_out_energy"]), rel=1e-6)
+            direct = data.copy()
+            decay.apply_decay_window(direct, adj)
+            assert np.array_equal(direct, out)                                  # worker == direct call
+
+
+def test_hrir_container_ops_golden(gpu_ctx, golden):
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.impulse_response import ImpulseResponse
+    g = golden("hrir_ops")
+
+    class Est:
+        fs = 48000
+        n_octaves = 10
+
+        def __len__(self):
+            return 48000 * 6
+
+    def mk(chs):
+        h = HRIR(Est())
+        h.irs = {sp: {sd: ImpulseResponse(np.asarray(v, dtype=np.float64), 48000) for sd, v in pr.items()}
+                 for sp, pr in chs.items()}
+        return h
+
+    for name in ("left_first", "right_first", "tie", "near_start"):
+        h = mk({"FC": {"left": g[f"ch_{name}_in_l"], "right": g[f"ch_{name}_in_r"]}})
+        h.crop_heads(head_ms=1)
+        for sd, key in (("left", "l"), ("right", "r")):
+            want = g[f"ch_{name}_out_{key}"]
+            assert h.irs["FC"][sd].data.shape == want.shape
+            assert np.max(np.abs(h.irs["FC"][sd].data - want)) <= 1e-7 * np.max(np.abs(want))
+    h = mk({sp: {sd: g[f"ct_in_{sp}_{sd}"] for sd in ("left", "right")} for sp in ("FL", "FR")})
+    assert h.crop_tails() == int(g["ct_tail_ind"])
+    for sp in ("FL", "FR"):
+        for sd in ("left", "right"):
+            want = g[f"ct_out_{sp}_{sd}"]
+            got = h.irs[sp][sd].data
+            assert got.shape == want.shape and abs(got[-1]) < 1e-6
+            assert np.max(np.abs(got - want)) <= 1e-7 * np.max(np.abs(want))
+    for name, seed, scales, kw in (("peak", 1, (0.3, 0.1, 0.05, 0.2), dict(peak_target=-0.1)),
+                                   ("avg", 2, (0.4, 0.25, 0.15, 0.3), dict(peak_target=None, avg_target=-12.0))):
+        rr = np.random.default_rng(seed)
+        a = [(rr.standard_normal(4096) * s).astype(np.float32) for s in scales]
+        h = mk({"FL": {"left": a[0], "right": a[1]}, "FR": {"left": a[2], "right": a[3]}})
+        gain = h.normalize(**kw)
+        assert gain == pytest.approx(float(g[f"nm_{name}_gain_db"]), abs=1e-9)
+        np.testing.assert_allclose(h.irs["FL"]["left"].data, g[f"nm_{name}_out_FL_left"], rtol=1e-12)
+    with pytest.raises(ValueError):
+        mk({"FL": {"left": [1.0, 0.0], "right": [1.0, 0.0]}}).normalize(peak_target=-0.1, avg_target=-12.0)
+
+
+def test_real_demo_column_against_shipped_golden(gpu_ctx, golden):
+    """The one real-data case that can travel: data/demo/room-FC-left.wav column (int32 PCM) ->
+    estimate -> crop_head(1 ms) -> crop to 21 600 + fade-out, against the FC-left track of the
+    room-responses.wav that the reference ships."""
+    from impulse_hip.hrir import _hann
+    from impulse_hip.impulse_response import ImpulseResponse
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    g = golden("demo_fc")
+    N = int(g["N"])
+    e = ImpulseResponseEstimator(min_duration=(N - 1) / 48000, fs=48000)
+    assert len(e) == N and e.n_octaves == float(g["P"])
+    col = (g["column_i32"].astype(np.float64) / 2 ** 31).astype(np.float32)
+    y = e.estimate(col)
+    ir = ImpulseResponse(y, 48000)
+    pk = ir.peak_index()
+    assert pk == int(g["peak_index"])
+    assert int(np.argmax(np.abs(y))) == int(g["argmax"])
+    peak_val = np.max(np.abs(g["win"]))
+    assert np.max(np.abs(y[pk - 64: pk + 8192] - g["win"])) / peak_val <= TIME_TOL
+    A = np.abs(np.fft.rfft(y))
+    assert np.max(np.abs(A[g["bins"]] - g["amp"])) / float(g["amax"]) <= SPEC_TOL
+    ir.crop_head()
+    n_out = int(g["responses_len"])
+    fo = 2 * int(48000 * (N / 48000 / float(g["P"])) * (1 / 24))
+    w = _hann(fo)[fo // 2:]
+    d = ir.data[:n_out].copy()
+    d[n_out - len(w):] *= w
+    want = g["responses_fc_left_i32"].astype(np.float64)
+    lsb = np.abs(np.rint(d * 2 ** 31) - want)
+    assert np.max(lsb) <= max(1.0, 1e-6 * np.max(np.abs(want)))        # <= 1e-6 of the track's peak, in LSB
+
+
+def test_ingest_recording_matches_oracle_split(gpu_ctx, tmp_path):
+    """HRIR.open_recording on a synthetic FL,FR measurement (recipe of the reference's
+    tests/test_pipeline_direct.py:175-204: delays 0/12/12/0, gains 1/.6/.6/.9), through the WAV
+    writer/reader, against the oracle's column split + per-channel estimate."""
+    from impulse_hip.audio_io import write_wav
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from oracle import hrir as ohrir
+    from oracle.estimator import Estimator
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+    oe = Estimator(min_duration=1.0, fs=48000)
+    N, fs = len(e), 48000
+    tracks = np.zeros((2, 2 * fs + 2 * (N + 2 * fs)))
+    # track 0 = left ear, track 1 = right ear; columns FL then FR
+    for col, (dl, gl, dr, gr) in enumerate(((0, 1.0, 12, 0.6), (12, 0.6, 0, 0.9))):
+        base = 2 * fs + col * (N + 2 * fs)
+        tracks[0, base + dl: base + dl + N] += gl * e.test_signal
+        tracks[1, base + dr: base + dr + N] += gr * e.test_signal
+    tracks *= 0.5
+    path = str(tmp_path / "FL,FR.wav")
+    write_wav(path, fs, tracks, bit_depth=32)
+    h = HRIR(e)
+    h.open_recording(path, ["FL", "FR"])
+    assert list(h.irs) == ["FL", "FR"] and all(set(p) == {"left", "right"} for p in h.irs.values())
+    pcm = np.rint(tracks * 2 ** 31) / 2 ** 31                       # what PCM_32 stored
+    jobs = ohrir.split_recording(pcm, ["FL", "FR"], N, fs)
+    assert [(sp, sd) for sp, sd, _ in jobs] == [("FL", "left"), ("FL", "right"), ("FR", "left"), ("FR", "right")]
+    for sp, sd, col in jobs:
+        ref = oe.estimate(col)
+        got = h.irs[sp][sd]
+        assert len(got.data) == len(ref) == N + 2 * fs
+        assert np.array_equal(got.recording, col)
+        assert rel(got.data, ref) <= TIME_TOL and spec_rel(got.data, ref) <= SPEC_TOL
+    peaks = {(sp, sd): h.irs[sp][sd].peak_index() for sp in h.irs for sd in ("left", "right")}
+    assert peaks[("FL", "left")] == N // 2 and peaks[("FL", "right")] == N // 2 + 12
+    assert peaks[("FR", "left")] == N // 2 + 12 and peaks[("FR", "right")] == N // 2
+    h2 = HRIR(e)
+    h2.fs = 44100
+    with pytest.raises(ValueError):
+        h2.open_recording(path, ["FL", "FR"])
+
+
+def test_equalize_and_plot_worker_full_convolution(gpu_ctx):
+    from impulse_hip.impulse_response import ImpulseResponse
+    from impulse_hip.parallel_workers import process_plot_worker
+    from oracle.scipy_restated import fft_convolve
+    rng = np.random.default_rng(21)
+    ir = (rng.standard_normal(33600) * np.exp(-np.arange(33600) / 4000.0)).astype(np.float32)
+    fir = rng.standard_normal(9600) * np.exp(-np.arange(9600) / 800.0)
+    obj = ImpulseResponse(ir.astype(np.float64), 48000)
+    obj.equalize(fir)
+    ref = fft_convolve(ir.astype(np.float64), fir, "full")
+    assert len(obj.data) == 33600 + 9600 - 1
+    assert rel(obj.data, ref) <= TIME_TOL and spec_rel(obj.data, ref) <= SPEC_TOL
+    sweep = np.sin(np.arange(147635) ** 1.3 / 500.0).astype(np.float32)
+    _, _, rec = process_plot_worker(("FL", "left", ir.astype(np.float64), sweep, 48000))
+    assert rel(rec, fft_convolve(sweep.astype(np.float64), ir.astype(np.float64), "full")) <= TIME_TOL

@@ -1,0 +1,214 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/*.h declares, the
+host-side logic of the product (set-up, recording geometry, WAV codec, sharding) agrees with the
+oracle/goldens, and the NumPy dataflow model of the kernels reproduces a linear convolution.
+No compute call is made on the native library here (there is no GPU)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    sys.path.insert(0, os.path.join(ROOT, "impulcifer-pip313_amd"))
+    import build
+    build.build_library()
+    from impulse_hip import _native
+    return _native.load_library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from impulse_hip import _native
+    declared = set()
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        if fn.endswith(".h"):
+            text = open(os.path.join(ROOT, "include", fn)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            declared |= set(re.findall(r"\b(imp_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    # the ctypes table mirrors the header one to one
+    assert declared == set(_native.SIGNATURES)
+    assert lib.imp_version().startswith(b"impulse_hip")
+
+
+def test_no_device_fails_loudly(lib):
+    """Without a GPU the product path must raise - never fall back to a CPU implementation."""
+    from impulse_hip import Context, NativeUnavailable
+    import ctypes as C
+    n = C.c_int(-1)
+    lib.imp_device_count(C.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(NativeUnavailable):
+        Context(0)
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    e = ImpulseResponseEstimator(min_duration=0.2, fs=8000)      # set-up is host-only and works
+    with pytest.raises(NativeUnavailable):
+        e.estimate(np.zeros(1000))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "impulcifer-pip313_amd", "impulse_hip")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+
+
+@pytest.mark.parametrize("fs,dur", [(48000, 1.0), (48000, 5.0), (96000, 5.0), (44100, 5.0)])
+def test_product_estimator_setup_golden(golden, fs, dur):
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    g = golden("estimator")
+    k = f"e{fs}_{int(dur)}"
+    e = ImpulseResponseEstimator(min_duration=dur, fs=fs)
+    assert len(e) == int(g[k + "_N"]) and e.n_octaves == float(g[k + "_P"])
+    assert e.low == float(g[k + "_low"]) and e.duration == float(g[k + "_duration"])
+    for nm, arr in (("ts", e.test_signal), ("inv", e.inverse_filter)):
+        s = np.max(np.abs(arr))
+        np.testing.assert_allclose(arr[:64], g[f"{k}_{nm}_head"], rtol=0, atol=1e-12 * s)
+        np.testing.assert_allclose(arr[-64:], g[f"{k}_{nm}_tail"], rtol=0, atol=1e-12 * s)
+        np.testing.assert_allclose(arr[::1024], g[f"{k}_{nm}_dec"], rtol=0, atol=1e-12 * s)
+    with pytest.raises(ValueError):
+        ImpulseResponseEstimator(fs=44100.5)
+
+
+def test_sweep_sequence_and_split_roundtrip():
+    from impulse_hip.hrir import split_recording
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from oracle import hrir as ohrir
+    from oracle.estimator import sweep_sequence_layout
+    e = ImpulseResponseEstimator(min_duration=0.25, fs=8000)
+    N, fs = len(e), 8000
+    seq = e.sweep_sequence(["FL", "FC", "FR"], "7.1")
+    total, starts = sweep_sequence_layout(3, N, fs)
+    assert seq.shape == (8, total)
+    for sp_idx, (track, s) in enumerate(zip((0, 2, 1), starts)):
+        assert np.array_equal(seq[track, s:s + N], e.test_signal)
+        assert not seq[track, :s].any()
+    for bad in (dict(speakers=["FL", "FL"], tracks="7.1"), dict(speakers=["FL"], tracks="9.9"),
+                dict(speakers=["FL", "FR", "FC"], tracks="stereo"), dict(speakers=["XX"], tracks="stereo")):
+        with pytest.raises(ValueError):
+            e.sweep_sequence(**bad)
+    # binaural recording: 2 tracks (left/right ear), 3 speakers in time
+    rec = np.random.default_rng(0).standard_normal((2, total))
+    _, jobs = split_recording(rec, ["FL", "FC", "FR"], N, fs)
+    ojobs = ohrir.split_recording(rec, ["FL", "FC", "FR"], N, fs)
+    assert [(j[0], j[1]) for j in jobs] == [(o[0], o[1]) for o in ojobs]
+    for (sp, sd, tr, a, b), (_, _, col) in zip(jobs, ojobs):
+        assert np.array_equal(rec[:, 2 * fs:][tr, a:b], col)
+    # one-sided room recording: one track, side given
+    _, jobs = split_recording(rec[:1], ["FL", "FC", "FR"], N, fs, side="left")
+    assert [(j[0], j[1]) for j in jobs] == [("FL", "left"), ("FC", "left"), ("FR", "left")]
+    # short recording: falls back to a reduced lead silence / partial column, or raises
+    short = rec[:, : 2 * fs + N + fs // 2]
+    _, jobs = split_recording(short, ["FL"], N, fs)
+    assert len(jobs) == 2
+    with pytest.raises(ValueError):
+        split_recording(rec[:, : fs], ["FL"], N, fs)
+    with pytest.raises(ValueError):
+        split_recording(rec, ["FL"], N, fs, silence_length=0.00001)
+
+
+def test_wav_codec_roundtrip(tmp_path):
+    from impulse_hip.audio_io import read_wav, write_wav
+    rng = np.random.default_rng(4)
+    x = rng.uniform(-0.9, 0.9, size=(3, 1000))
+    for bits, tol in ((16, 2.0 ** -15), (24, 2.0 ** -23), (32, 2.0 ** -31)):
+        p = str(tmp_path / f"t{bits}.wav")
+        write_wav(p, 48000, x, bit_depth=bits)
+        fs, y = read_wav(p)
+        assert fs == 48000 and y.shape == x.shape
+        assert np.max(np.abs(y - x)) <= tol
+        # scipy reads the same integers
+        from scipy.io import wavfile
+        if bits != 24:
+            _, raw = wavfile.read(p)
+            assert np.array_equal(raw.T.astype(np.float64) / 2.0 ** (bits - 1), y)
+    p = str(tmp_path / "mono.wav")
+    write_wav(p, 8000, x[0], bit_depth=32)
+    fs, y = read_wav(p)
+    assert y.ndim == 1
+    fs, y = read_wav(p, expand=True)
+    assert y.shape == (1, 1000)
+    with pytest.raises(ValueError):
+        write_wav(p, 8000, x, bit_depth=20)
+
+
+def test_shard_channels():
+    from impulse_hip.sharding import shard_channels, split_evenly
+    for B in (16, 26, 256, 1024, 7):
+        for W in (1, 2, 4, 8):
+            spans = [shard_channels(B, W, r) for r in range(W)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c
+            if B % 2 == 0:
+                assert all(a % 2 == 0 and b % 2 == 0 for a, b in spans)   # stereo pairs stay together
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= (2 if B % 2 == 0 else 1)
+    assert list(split_evenly(10, 4)) == [3, 3, 2, 2]
+    with pytest.raises(ValueError):
+        shard_channels(8, 2, 2)
+
+
+def test_kernel_dataflow_model_is_a_linear_convolution():
+    import fourstep_model as fm
+    from oracle.scipy_restated import fft_convolve
+    rng = np.random.default_rng(0)
+    r = rng.standard_normal(4096) + 1j * rng.standard_normal(4096)
+    assert np.abs(fm.regs_to_natural(fm.fft4096_fwd(r)) - np.fft.fft(r)).max() < 1e-10
+    assert np.abs(fm.ifft4096_inv(fm.natural_to_regs(np.fft.fft(r))) / 4096 - r).max() < 1e-12
+    for L, M in ((70001, 61000), (150000, 100001)):
+        x, h = rng.standard_normal(L), rng.standard_normal(M)
+        y = fm.convolve_same_model(x, h)
+        ref = fft_convolve(x, h, "same")
+        assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-12
+
+
+def test_two_rank_gloo_broadcast_and_sharding(tmp_path):
+    """world_size 2 on CPU (gloo): rank 0's prepared spectrum bytes reach rank 1 through the same
+    broadcast helper bench.py uses with RCCL, and the two shards tile the channel range."""
+    script = tmp_path / "rank.py"
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {os.path.join(ROOT, "impulcifer-pip313_amd")!r})
+import numpy as np, torch, torch.distributed as dist
+from impulse_hip.sharding import shard_channels, broadcast_bytes
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + os.environ["PORT"],
+                        rank=int(os.environ["RANK"]), world_size=2)
+rank = dist.get_rank()
+want = torch.from_numpy(np.random.default_rng(123).integers(0, 255, 1 << 16, dtype=np.uint8))
+buf = want.clone() if rank == 0 else torch.zeros_like(want)
+broadcast_bytes(buf, dist, src=0)
+assert torch.equal(buf, want)
+lo, hi = shard_channels(16, 2, rank)
+spans = [None, None]
+dist.all_gather_object(spans, (lo, hi))
+assert spans == [(0, 8), (8, 16)]
+t = torch.tensor([float(hi - lo)])
+dist.all_reduce(t, op=dist.ReduceOp.SUM)
+assert t.item() == 16
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+''')
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

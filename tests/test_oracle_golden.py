@@ -215,17 +215,17 @@ def test_real_demo_column_reproduces_shipped_room_response(golden):
     pk = oir.peak_index(y)
     assert pk == int(g["peak_index"])
     assert int(np.argmax(np.abs(y))) == int(g["argmax"])
-    # the generated sweep differs from the WAV-loaded one only by PCM_32 quantisation of the file
-    np.testing.assert_allclose(y[pk - 64: pk + 8192], g["win"], atol=2e-8)
+    # from_wav keeps the GENERATED sweep (the WAV differs from it by < 1e-4, impulse_response_estimator.py:256-260)
+    np.testing.assert_allclose(y[pk - 64: pk + 8192], g["win"], rtol=0, atol=1e-15)
     ir = oir.crop_head(y, 48000, 1)
     n_out = int(g["responses_len"])
     fo = 2 * int(48000 * (sweep_len / 48000 / P) * (1 / 24))
     w = sr.hann(fo)[fo // 2:]
     d = ir[:n_out].copy()
     d *= np.concatenate([np.ones(n_out - len(w)), w])
-    pcm = np.round(d * 2 ** 31).astype(np.int64)
+    pcm = np.rint(d * 2 ** 31).astype(np.int64)
     want = g["responses_fc_left_i32"].astype(np.int64)
-    assert np.max(np.abs(pcm - want)) <= 60      # sweep regenerated, not read from the 32-bit WAV
+    assert np.max(np.abs(pcm - want)) == 0       # 0 LSB against the file the reference ships
     dp = odecay.decay_params(ir, 48000)
     exp = g["decay_params"]
     assert (int(dp[0]), int(dp[3])) == (int(exp[0]), int(exp[3]))
