@@ -22,21 +22,34 @@ constexpr int kLogN2 = 12;
 constexpr int kRowPad = 272;     // LDS row pitch (float2) of the 16x256 exchange planes
 
 // ---------------------------------------------------------------------------------------------
-// Twiddle tables (device, fp32 rounded from fp64 on the host):
-//   tw_lo[m]  = exp(-2 pi i m / Nc),        m < 1024
-//   tw_hi[m]  = exp(-2 pi i 1024 m / Nc),   m < Nc/1024     (also gives w_N1^j = tw_hi[4 j])
-//   tw_row[m] = exp(-2 pi i m / 4096),      m < 4096
+// Twiddle tables (device, fp32 rounded from fp64 on the host).  Every table is laid out in the
+// order the lanes read it, so a wave's read is one contiguous segment (no gathers):
+//   full[k1*4096 + n2] = exp(-2 pi i (k1 n2 mod Nc) / Nc)      four-step twiddle, tiled like ws[]
+//   hi[m]              = exp(-2 pi i 1024 m / Nc), m < Nc/1024  (w_N1^j = hi[4 j], wave-uniform reads)
+//   t1[a*256 + t]      = w4096^(t a)                            row pass, stage after the 1st FFT16
+//   t2[q*16 + l]       = w4096^(16 l q)   (= w256^(l q))        row pass, stage after the 2nd FFT16
+//   t4[j*256 + t]      = w4096^((16 j + (t&15)) (t>>4))         row pass, inverse 2nd twiddle
+//   row[m]             = w4096^m                                 (spectrum kernel only)
 // ---------------------------------------------------------------------------------------------
 struct Twiddles {
-  const cf* __restrict__ lo;
+  const cf* __restrict__ full;
   const cf* __restrict__ hi;
+  const cf* __restrict__ t1;
+  const cf* __restrict__ t2;
+  const cf* __restrict__ t4;
   const cf* __restrict__ row;
 };
 
-__device__ __forceinline__ cf tw_nc(const Twiddles& tw, unsigned idx) {
-  cf a = tw.lo[idx & 1023u];
-  cf b = tw.hi[idx >> 10];
-  return cmul(a, b);
+// Blocks b and b+8 share an XCD (round-robin dispatch; a speed assumption only).  Work items are
+// (tile, channel) with the SAME tile on the same XCD for every channel, channels fastest, so the
+// tile's shared tables (twiddles, alpha/beta) are fetched once per XCD and then hit its L2.
+// Requires tiles % 8 == 0 (always true here: 64/128 column tiles, N1/2 in {8..128} row pairs).
+__device__ __forceinline__ void xcd_work_item(int nchan, int& tile, int& chan) {
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int tl = slot / nchan;
+  chan = slot - tl * nchan;
+  tile = tl * 8 + xcd;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -130,7 +143,7 @@ struct ColsCfg {
 
 template <int R2, int DIR, class Load, class Store>
 __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st, Twiddles tw,
-                                                                int tiles_per_chan) {
+                                                                int nchan) {
   using Cfg = ColsCfg<R2>;
   constexpr int TC = Cfg::TC, T = Cfg::T, G = Cfg::G;
   constexpr int N1 = 16 * R2;
@@ -140,8 +153,8 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
   const int tid = threadIdx.x;
   const int c = tid % TC;
   const int g = tid / TC;
-  const int b = blockIdx.x / tiles_per_chan;
-  const int tile = blockIdx.x - b * tiles_per_chan;
+  int b, tile;
+  xcd_work_item(nchan, tile, b);
   const int n2 = tile * TC + c;
 
   cf v[16];
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
     cf z = make_float2(0.f, 0.f);
     if (row < live) {
       z = ld(b, row, n2);
-      if constexpr (DIR > 0) z = cmulc(z, tw_nc(tw, (unsigned)n2 * (unsigned)row));
+      if constexpr (DIR > 0) z = cmulc(z, tw.full[row * kN2 + n2]);
     }
     v[j] = z;
   }
@@ -160,9 +173,10 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
   fft16<DIR>(v);   // index a
 
   if constexpr (R2 > 1) {
-    // w_N1^(g a) = tw_hi[4 g a]  (Nc/1024 = 4 N1 entries)
+    // w_N1^(g a) = hi[4 g a]  (Nc/1024 = 4 N1 entries); g is wave-uniform for 64-column tiles
+    const int gu = (TC == 64) ? __builtin_amdgcn_readfirstlane(g) : g;
 #pragma unroll
-    for (int a = 1; a < 16; ++a) v[a] = ctw<DIR>(v[a], tw.hi[4 * g * a]);
+    for (int a = 1; a < 16; ++a) v[a] = ctw<DIR>(v[a], tw.hi[4 * gu * a]);
 #pragma unroll
     for (int a = 0; a < 16; ++a) buf[a * T + tid] = v[a];
     __syncthreads();
@@ -178,14 +192,14 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
       for (int kb = 0; kb < R2; ++kb) {
         const int row = (g * G + i) + 16 * kb;
         cf z = v[i * R2 + kb];
-        if constexpr (DIR < 0) z = cmul(z, tw_nc(tw, (unsigned)n2 * (unsigned)row));
+        if constexpr (DIR < 0) z = cmul(z, tw.full[row * kN2 + n2]);
         st(b, row, n2, z);
       }
   } else {
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
       cf z = v[a];
-      if constexpr (DIR < 0) z = cmul(z, tw_nc(tw, (unsigned)n2 * (unsigned)a));
+      if constexpr (DIR < 0) z = cmul(z, tw.full[a * kN2 + n2]);
       st(b, a, n2, z);
     }
   }
@@ -209,9 +223,10 @@ struct RowsArgs {
   int n1_total;
   int log_n1;
   int npairs;                      // N1/2: pair 0 = rows (0, N1/2), pair p = rows (p, N1-p)
+  int nchan;                       // channels in this launch group
 };
 
-__global__ __launch_bounds__(512) void rows_kernel(RowsArgs args, Twiddles tw) {
+__global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cf* lds = reinterpret_cast<cf*>(smem_raw);
 
@@ -219,8 +234,8 @@ __global__ __launch_bounds__(512) void rows_kernel(RowsArgs args, Twiddles tw) {
   const int half = tid >> 8;
   const int t = tid & 255;
   const int N1 = args.n1_total;
-  const int b = blockIdx.x / args.npairs;
-  const int pair = blockIdx.x - b * args.npairs;
+  int b, pair;
+  xcd_work_item(args.nchan, pair, b);
   const int rowA = pair;
   const int rowB = (pair == 0) ? (N1 >> 1) : (N1 - pair);
   const int k1 = half ? rowB : rowA;
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(512) void rows_kernel(RowsArgs args, Twiddles tw) {
   // ---- forward FFT4096 ----
   fft16<-1>(v);                                            // over j -> a
 #pragma unroll
-  for (int a = 1; a < 16; ++a) v[a] = cmul(v[a], tw.row[t * a]);
+  for (int a = 1; a < 16; ++a) v[a] = cmul(v[a], tw.t1[a * 256 + t]);
 #pragma unroll
   for (int a = 0; a < 16; ++a) buf[a * kRowPad + t] = v[a];
   __syncthreads();
@@ -247,7 +262,7 @@ __global__ __launch_bounds__(512) void rows_kernel(RowsArgs args, Twiddles tw) {
   for (int j2 = 0; j2 < 16; ++j2) u[j2] = buf[hi4 * kRowPad + 16 * j2 + lo4];
   fft16<-1>(u);                                            // over j2 -> kb1
 #pragma unroll
-  for (int q = 1; q < 16; ++q) u[q] = cmul(u[q], tw.row[16 * lo4 * q]);
+  for (int q = 1; q < 16; ++q) u[q] = cmul(u[q], tw.t2[q * 16 + lo4]);
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 16; ++q) buf[hi4 * kRowPad + lo4 * 17 + q] = u[q];
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(512) void rows_kernel(RowsArgs args, Twiddles tw) {
   // ---- inverse FFT4096 (mirror) ----
   fft16<+1>(u);                                            // over kb2 -> t2
 #pragma unroll
-  for (int q = 1; q < 16; ++q) u[q] = cmulc(u[q], tw.row[16 * q * lo4]);
+  for (int q = 1; q < 16; ++q) u[q] = cmulc(u[q], tw.t2[q * 16 + lo4]);
 #pragma unroll
   for (int t2 = 0; t2 < 16; ++t2) buf[hi4 * kRowPad + t2 * 17 + lo4] = u[t2];
   __syncthreads();
@@ -302,10 +317,7 @@ __global__ __launch_bounds__(512) void rows_kernel(RowsArgs args, Twiddles tw) {
   for (int q = 0; q < 16; ++q) v[q] = buf[hi4 * kRowPad + lo4 * 17 + q];
   fft16<+1>(v);                                            // over kb1 -> j2
 #pragma unroll
-  for (int j2 = 0; j2 < 16; ++j2) {
-    const int tt = 16 * j2 + lo4;
-    v[j2] = cmulc(v[j2], tw.row[tt * hi4]);
-  }
+  for (int j2 = 0; j2 < 16; ++j2) v[j2] = cmulc(v[j2], tw.t4[j2 * 256 + t]);
   __syncthreads();
 #pragma unroll
   for (int j2 = 0; j2 < 16; ++j2) buf[hi4 * kRowPad + 16 * j2 + lo4] = v[j2];

@@ -49,7 +49,7 @@ static int fail(int code, const char* fmt, ...) {
 // context
 // ------------------------------------------------------------------------------------------------
 struct TwSet {
-  cf* lo = nullptr;       // exp(-2 pi i m / Nc), m < 1024
+  cf* full = nullptr;     // exp(-2 pi i (k1 n2 mod Nc) / Nc) at [k1*4096 + n2]
   cf* hi = nullptr;       // exp(-2 pi i 1024 m / Nc), m < Nc/1024
   cf* nfft_lo = nullptr;  // exp(-2 pi i m / nfft), m < 2048
   cf* nfft_hi = nullptr;  // exp(-2 pi i 2048 m / nfft), m < Nc/1024 (only Nc/2048 used)
@@ -60,6 +60,9 @@ struct imp_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = true;
   cf* tw_row = nullptr;                 // exp(-2 pi i m / 4096)
+  cf* tw_t1 = nullptr;                  // row-pass stage tables, see conv_kernels.hip.h
+  cf* tw_t2 = nullptr;
+  cf* tw_t4 = nullptr;
   std::map<int, TwSet> tw_by_log_n1;    // keyed by log2(N1)
   std::mutex mu;
   // scratch for the small ragged kernels
@@ -86,6 +89,34 @@ static int upload_twiddle(cf** dptr, size_t n, double step_num, double denom, hi
   return IMP_OK;
 }
 
+static int upload_table(cf** dptr, const std::vector<cf>& h, hipStream_t s) {
+  HIP_TRY(hipMalloc((void**)dptr, h.size() * sizeof(cf)));
+  HIP_TRY(hipMemcpyAsync(*dptr, h.data(), h.size() * sizeof(cf), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return IMP_OK;
+}
+
+static cf unit_root(int64_t num, int64_t den) {          // exp(-2 pi i num/den), num reduced mod den
+  const double ang = -2.0 * M_PI * (double)(num % den) / (double)den;
+  return make_float2((float)std::cos(ang), (float)std::sin(ang));
+}
+
+static int ctx_row_tables(imp_ctx* ctx) {
+  std::vector<cf> t1(16 * 256), t2(16 * 16), t4(16 * 256);
+  for (int a = 0; a < 16; ++a)
+    for (int t = 0; t < 256; ++t) {
+      t1[(size_t)a * 256 + t] = unit_root((int64_t)t * a, 4096);
+      t4[(size_t)a * 256 + t] = unit_root((int64_t)(16 * a + (t & 15)) * (t >> 4), 4096);
+    }
+  for (int q = 0; q < 16; ++q)
+    for (int l = 0; l < 16; ++l) t2[(size_t)q * 16 + l] = unit_root((int64_t)16 * l * q, 4096);
+  int rc;
+  if ((rc = upload_table(&ctx->tw_t1, t1, ctx->stream))) return rc;
+  if ((rc = upload_table(&ctx->tw_t2, t2, ctx->stream))) return rc;
+  if ((rc = upload_table(&ctx->tw_t4, t4, ctx->stream))) return rc;
+  return IMP_OK;
+}
+
 static int ctx_twiddles(imp_ctx* ctx, int log_n1, TwSet* out) {
   std::lock_guard<std::mutex> lk(ctx->mu);
   auto it = ctx->tw_by_log_n1.find(log_n1);
@@ -96,7 +127,13 @@ static int ctx_twiddles(imp_ctx* ctx, int log_n1, TwSet* out) {
   const double Nc = (double)((int64_t)1 << (log_n1 + imp::kLogN2));
   TwSet t;
   int rc;
-  if ((rc = upload_twiddle(&t.lo, 1024, 1.0, Nc, ctx->stream))) return rc;
+  {
+    const int64_t nc = (int64_t)Nc, n1 = nc >> imp::kLogN2;
+    std::vector<cf> full((size_t)nc);
+    for (int64_t k1 = 0; k1 < n1; ++k1)
+      for (int64_t n2 = 0; n2 < imp::kN2; ++n2) full[(size_t)(k1 * imp::kN2 + n2)] = unit_root(k1 * n2, nc);
+    if ((rc = upload_table(&t.full, full, ctx->stream))) return rc;
+  }
   if ((rc = upload_twiddle(&t.hi, (size_t)(Nc / 1024), 1024.0, Nc, ctx->stream))) return rc;
   if ((rc = upload_twiddle(&t.nfft_lo, 2048, 1.0, 2.0 * Nc, ctx->stream))) return rc;
   if ((rc = upload_twiddle(&t.nfft_hi, (size_t)(Nc / 1024), 2048.0, 2.0 * Nc, ctx->stream))) return rc;
@@ -157,6 +194,7 @@ extern "C" int imp_ctx_create(int device_id, imp_ctx** out) {
     return fail(IMP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
   }
   int rc = upload_twiddle(&ctx->tw_row, 4096, 1.0, 4096.0, ctx->stream);
+  if (!rc) rc = ctx_row_tables(ctx);
   if (rc) {
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -190,12 +228,15 @@ extern "C" void imp_ctx_destroy(imp_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->tw_by_log_n1) {
-    (void)hipFree(kv.second.lo);
+    (void)hipFree(kv.second.full);
     (void)hipFree(kv.second.hi);
     (void)hipFree(kv.second.nfft_lo);
     (void)hipFree(kv.second.nfft_hi);
   }
   if (ctx->tw_row) (void)hipFree(ctx->tw_row);
+  if (ctx->tw_t1) (void)hipFree(ctx->tw_t1);
+  if (ctx->tw_t2) (void)hipFree(ctx->tw_t2);
+  if (ctx->tw_t4) (void)hipFree(ctx->tw_t4);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -358,7 +399,9 @@ struct imp_plan {
   float* d_out = nullptr;
   size_t d_in_bytes = 0, d_out_bytes = 0;
   // timing
-  bool timing = false;
+  int timing = 0;                    // 0 = off, n = record every n-th launch group
+  int64_t group_counter = 0;
+  bool group_timed = false;
   std::vector<hipEvent_t> events;   // 4 per launch group
   int64_t timed = 0;
   double acc_ms[3] = {0, 0, 0};
@@ -376,9 +419,9 @@ static int launch_cols(imp_plan* p, int64_t nchan, Load ld, Store st) {
     attr_set = true;
   }
   const int tiles = imp::kN2 / Cfg::TC;
-  imp::Twiddles tw{p->tw.lo, p->tw.hi, p->ctx->tw_row};
+  imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4, p->ctx->tw_row};
   dim3 grid((unsigned)(nchan * tiles)), block(Cfg::T);
-  hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->ctx->stream, ld, st, tw, tiles);
+  hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->ctx->stream, ld, st, tw, (int)nchan);
   HIP_TRY(hipGetLastError());
   return IMP_OK;
 }
@@ -412,7 +455,8 @@ static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan) {
   a.n1_total = p->N1;
   a.log_n1 = p->log_n1;
   a.npairs = p->N1 / 2;
-  imp::Twiddles tw{p->tw.lo, p->tw.hi, p->ctx->tw_row};
+  a.nchan = (int)nchan;
+  imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4, p->ctx->tw_row};
   dim3 grid((unsigned)(nchan * a.npairs)), block(512);
   hipLaunchKernelGGL(imp::rows_kernel, grid, block, kRowsLds, p->ctx->stream, a, tw);
   HIP_TRY(hipGetLastError());
@@ -541,7 +585,8 @@ extern "C" int imp_plan_set_timing(imp_plan* p, int enable) {
   if (!p) return fail(IMP_ERR_INVALID, "null plan");
   int rc = ctx_bind(p->ctx);
   if (rc) return rc;
-  p->timing = enable != 0;
+  p->timing = enable < 0 ? 0 : enable;
+  p->group_counter = 0;
   return IMP_OK;
 }
 
@@ -576,6 +621,8 @@ extern "C" int imp_plan_get_timing(imp_plan* p, double ms[3], int64_t* launches,
 
 static int timing_event(imp_plan* p, int slot) {
   if (!p->timing) return IMP_OK;
+  if (slot == 0) p->group_timed = (p->group_counter++ % p->timing) == 0;
+  if (!p->group_timed) return IMP_OK;
   if (p->timed >= kMaxTimed) {
     int rc = plan_collect_timing(p);   // drains the stream; only every kMaxTimed launch groups
     if (rc) return rc;
@@ -596,6 +643,13 @@ static int run_group(imp_plan* p, const float* d_x, int64_t nchan, int64_t chan_
                      int64_t elem_stride_in, float* d_y, int64_t chan_stride_out, int64_t first_chan,
                      int last_stage) {
   int rc;
+  // every kernel indexes ws[] by the group-local channel and ab[] by the global one: check both
+  if (nchan < 1 || nchan > p->ws_channels)
+    return fail(IMP_ERR_INVALID, "launch group of %lld channels exceeds the workspace (%lld)", (long long)nchan,
+                (long long)p->ws_channels);
+  if (p->n_filters > 1 && first_chan + nchan > p->n_filters)
+    return fail(IMP_ERR_INVALID, "channel %lld has no filter: the plan holds %lld per-channel filters",
+                (long long)(first_chan + nchan - 1), (long long)p->n_filters);
   imp::LoadRealPacked ld{d_x, chan_stride_in, elem_stride_in, p->L};
   imp::StoreWorkspace stw{p->ws, p->N1};
   if ((rc = timing_event(p, 0))) return rc;

@@ -289,8 +289,9 @@ class ConvPlan:
         _check(self._lib.imp_conv_execute_device(self._h, _vp(int(d_x)), int(B), int(chan_stride_in),
                                                  int(elem_stride_in), _vp(int(d_y)), int(chan_stride_out)))
 
-    def set_timing(self, on):
-        _check(self._lib.imp_plan_set_timing(self._h, 1 if on else 0))
+    def set_timing(self, every_n):
+        """0/False = off; n = bracket the three passes of every n-th launch group with HIP events."""
+        _check(self._lib.imp_plan_set_timing(self._h, int(every_n)))
 
     def get_timing(self, reset=True):
         ms = (C.c_double * 3)()

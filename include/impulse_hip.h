@@ -99,8 +99,9 @@ int imp_conv_execute_interleaved(imp_plan* plan, const float* frames, int64_t C,
 int imp_conv_execute_device(imp_plan* plan, const float* d_x, int64_t B, int64_t chan_stride_in,
                             int64_t elem_stride_in, float* d_y, int64_t chan_stride_out);
 
-/* per-kernel timing with HIP events on the plan's stream (for bench.py's roofline block) */
-int imp_plan_set_timing(imp_plan* plan, int enable);
+/* per-kernel timing with HIP events on the plan's stream (for bench.py's roofline block):
+ * every_n = 0 switches it off, n >= 1 brackets the three passes of every n-th launch group. */
+int imp_plan_set_timing(imp_plan* plan, int every_n);
 /* Synchronises, then returns accumulated milliseconds of pass A / B / C and the number of launch
  * groups measured since the last reset. */
 int imp_plan_get_timing(imp_plan* plan, double ms[3], int64_t* launches, int reset);
