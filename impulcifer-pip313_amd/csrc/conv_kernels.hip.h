@@ -226,12 +226,37 @@ struct RowsArgs {
   int nchan;                       // channels in this launch group
 };
 
+// Raw buffer (SRSRC) addressing: one 32-bit VGPR offset per thread + scalar offsets per element,
+// instead of sixteen 64-bit VGPR address pairs that would otherwise stay live from the first load
+// to the last store of the row (measured: 138 VGPRs -> spills under the 2-workgroups/CU bound).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ cf bload_cf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
+}
+__device__ __forceinline__ float4 bload_f4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+}
+__device__ __forceinline__ void bstore_cf(cf v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  u32x2 x;
+  x.x = __float_as_uint(v.x);
+  x.y = __float_as_uint(v.y);
+  __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
+}
+
 __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cf* lds = reinterpret_cast<cf*>(smem_raw);
 
   const int tid = threadIdx.x;
-  const int half = tid >> 8;
+  // a wave never straddles the two rows: everything derived from `half` is wave-uniform (SGPRs)
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
   const int t = tid & 255;
   const int N1 = args.n1_total;
   int b, pair;
@@ -241,19 +266,27 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   const int k1 = half ? rowB : rowA;
   cf* buf = lds + half * (16 * kRowPad);
 
-  cf* wsrow = args.ws + ((long long)b * N1 + k1) * kN2;
+  const __amdgpu_buffer_rsrc_t r_row = make_rsrc(args.ws + ((long long)b * N1 + k1) * kN2, kN2 * sizeof(cf));
+  const __amdgpu_buffer_rsrc_t r_ab =
+      make_rsrc(args.ab + (long long)b * args.ab_chan_stride + (long long)k1 * kN2, kN2 * sizeof(float4));
+  const __amdgpu_buffer_rsrc_t r_t1 = make_rsrc(tw.t1, 16 * 256 * sizeof(cf));
+  const __amdgpu_buffer_rsrc_t r_t2 = make_rsrc(tw.t2, 16 * 16 * sizeof(cf));
+  const __amdgpu_buffer_rsrc_t r_t4 = make_rsrc(tw.t4, 16 * 256 * sizeof(cf));
 
   const int hi4 = t >> 4;   // "ka" of the (ka, x) thread naming
   const int lo4 = t & 15;
+  const unsigned vo8 = (unsigned)t * 8u;       // byte offset of element t in a [..][256] cf table / the row
+  const unsigned vo16 = (unsigned)t * 16u;     // same for float4
+  const unsigned vl8 = (unsigned)lo4 * 8u;
 
   cf v[16], u[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) v[j] = wsrow[t + 256 * j];
+  for (int j = 0; j < 16; ++j) v[j] = bload_cf(r_row, vo8, j * 256 * 8);
 
   // ---- forward FFT4096 ----
   fft16<-1>(v);                                            // over j -> a
 #pragma unroll
-  for (int a = 1; a < 16; ++a) v[a] = cmul(v[a], tw.t1[a * 256 + t]);
+  for (int a = 1; a < 16; ++a) v[a] = cmul(v[a], bload_cf(r_t1, vo8, a * 256 * 8));
 #pragma unroll
   for (int a = 0; a < 16; ++a) buf[a * kRowPad + t] = v[a];
   __syncthreads();
@@ -262,7 +295,7 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   for (int j2 = 0; j2 < 16; ++j2) u[j2] = buf[hi4 * kRowPad + 16 * j2 + lo4];
   fft16<-1>(u);                                            // over j2 -> kb1
 #pragma unroll
-  for (int q = 1; q < 16; ++q) u[q] = cmul(u[q], tw.t2[q * 16 + lo4]);
+  for (int q = 1; q < 16; ++q) u[q] = cmul(u[q], bload_cf(r_t2, vl8, q * 16 * 8));
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 16; ++q) buf[hi4 * kRowPad + lo4 * 17 + q] = u[q];
@@ -278,55 +311,61 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   for (int q = 0; q < 16; ++q) buf[q * kRowPad + t] = v[q];
   __syncthreads();
 
-  const float4* abrow = args.ab + (long long)b * args.ab_chan_stride + (long long)k1 * kN2;
   const unsigned ncmask = ((unsigned)N1 << kLogN2) - 1u;
+  // partner bins conj Z[Nc-k] (u[] is free here)
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const unsigned k2 = (unsigned)hi4 + 16u * (unsigned)lo4 + 256u * (unsigned)q;
-    const unsigned k = (unsigned)k1 + ((unsigned)k2 << args.log_n1);
+    const unsigned k = (unsigned)k1 + (k2 << args.log_n1);
     const unsigned kp = (0u - k) & ncmask;                 // (Nc - k) mod Nc
     const unsigned prow = kp & (unsigned)(N1 - 1);
     const unsigned pk2 = kp >> args.log_n1;
     const int phalf = (prow == (unsigned)rowA) ? 0 : 1;
-    const cf zp = lds[phalf * (16 * kRowPad) + (pk2 >> 8) * kRowPad + 16 * (pk2 & 15u) + ((pk2 >> 4) & 15u)];
-    const float4 ab = abrow[q * 256 + t];
-    const cf z = v[q];
+    u[q] = lds[phalf * (16 * kRowPad) + (pk2 >> 8) * kRowPad + 16 * (pk2 & 15u) + ((pk2 >> 4) & 15u)];
+  }
+  // bin 0 of the packed transform carries DC and Nyquist: ab.x = H[0]/Nc, ab.z = H[Nc]/Nc
+  const bool dc_lane = (k1 == 0) && (t == 0);
+  cf w_dc = make_float2(0.f, 0.f);
+  if (dc_lane) {
+    const float4 ab = bload_f4(r_ab, 0u, 0u);
+    const float x0 = v[0].x + v[0].y, xn = v[0].x - v[0].y;
+    w_dc = make_float2(0.5f * (x0 * ab.x + xn * ab.z), 0.5f * (x0 * ab.x - xn * ab.z));
+  }
+  // W = alpha Z + beta conj(Z[Nc-k]), in place
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float4 ab = bload_f4(r_ab, vo16, q * 256 * 16);
+    const cf z = v[q], zp = u[q];
     cf w;
-    // alpha*z + beta*conj(zp)
     w.x = ab.x * z.x - ab.y * z.y + ab.z * zp.x + ab.w * zp.y;
     w.y = ab.x * z.y + ab.y * z.x + ab.w * zp.x - ab.z * zp.y;
-    if (k == 0u) {
-      // DC / Nyquist share bin 0 of the packed transform: ab.x = H[0]/Nc, ab.z = H[Nc]/Nc
-      const float x0 = z.x + z.y, xn = z.x - z.y;
-      w.x = 0.5f * (x0 * ab.x + xn * ab.z);
-      w.y = 0.5f * (x0 * ab.x - xn * ab.z);
-    }
-    u[q] = w;
+    v[q] = w;
   }
+  if (dc_lane) v[0] = w_dc;
   __syncthreads();
 
   // ---- inverse FFT4096 (mirror) ----
-  fft16<+1>(u);                                            // over kb2 -> t2
+  fft16<+1>(v);                                            // over kb2 -> t2
 #pragma unroll
-  for (int q = 1; q < 16; ++q) u[q] = cmulc(u[q], tw.t2[q * 16 + lo4]);
+  for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], bload_cf(r_t2, vl8, q * 16 * 8));
 #pragma unroll
-  for (int t2 = 0; t2 < 16; ++t2) buf[hi4 * kRowPad + t2 * 17 + lo4] = u[t2];
+  for (int t2 = 0; t2 < 16; ++t2) buf[hi4 * kRowPad + t2 * 17 + lo4] = v[t2];
   __syncthreads();
   // thread (ka = hi4, t2 = lo4) gathers kb1 = 0..15
 #pragma unroll
-  for (int q = 0; q < 16; ++q) v[q] = buf[hi4 * kRowPad + lo4 * 17 + q];
-  fft16<+1>(v);                                            // over kb1 -> j2
+  for (int q = 0; q < 16; ++q) u[q] = buf[hi4 * kRowPad + lo4 * 17 + q];
+  fft16<+1>(u);                                            // over kb1 -> j2
 #pragma unroll
-  for (int j2 = 0; j2 < 16; ++j2) v[j2] = cmulc(v[j2], tw.t4[j2 * 256 + t]);
+  for (int j2 = 0; j2 < 16; ++j2) u[j2] = cmulc(u[j2], bload_cf(r_t4, vo8, j2 * 256 * 8));
   __syncthreads();
 #pragma unroll
-  for (int j2 = 0; j2 < 16; ++j2) buf[hi4 * kRowPad + 16 * j2 + lo4] = v[j2];
+  for (int j2 = 0; j2 < 16; ++j2) buf[hi4 * kRowPad + 16 * j2 + lo4] = u[j2];
   __syncthreads();
 #pragma unroll
-  for (int a = 0; a < 16; ++a) u[a] = buf[a * kRowPad + t];
-  fft16<+1>(u);                                            // over ka -> j
+  for (int a = 0; a < 16; ++a) v[a] = buf[a * kRowPad + t];
+  fft16<+1>(v);                                            // over ka -> j
 #pragma unroll
-  for (int j = 0; j < 16; ++j) wsrow[t + 256 * j] = u[j];
+  for (int j = 0; j < 16; ++j) bstore_cf(v[j], r_row, vo8, j * 256 * 8);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -390,7 +390,11 @@ def test_real_demo_column_against_shipped_golden(gpu_ctx, golden):
     want = g["responses_fc_left_i32"].astype(np.float64)
     lsb = np.abs(np.rint(d * 2 ** 31) - want)
     assert np.max(lsb) <= max(1.0, 1e-6 * np.max(np.abs(want)))        # <= 1e-6 of the track's peak, in LSB
-    assert spec_rel(d, want / 2 ** 31) <= SPEC_TOL                      # the cropped IR's magnitude spectrum
+    # magnitude spectrum of the cropped IR against the reference's own float64 output (the shipped
+    # track is PCM_32-quantised: the float64 oracle itself is 2.5e-6 away from it on this metric)
+    d_ref = g["cropped_head"].copy()
+    d_ref[n_out - len(w):] *= w
+    assert spec_rel(d, d_ref) <= SPEC_TOL
 
 
 def test_ingest_recording_matches_oracle_split(gpu_ctx, tmp_path):
