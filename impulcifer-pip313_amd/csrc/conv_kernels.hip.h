@@ -5,7 +5,8 @@
 //   core/impulse_response.py:119,135        (equalize / convolve: 'full')
 //
 // One real channel x[L] is packed even/odd into z[n] = x[2n] + i x[2n+1] (Nc = nfft/2 complex
-// points, Nc = N1*N2, N2 = 4096, N1 = 16*R2) and transformed with a four-step FFT:
+// points, Nc = N1*N2, N2 = 4096, N1 = 16*R2, R2 in {1,2,3,4,5,6,8,10,12,16}) and transformed with a
+// four-step FFT:
 //   pass A  cols_kernel<fwd>   : length-N1 column FFTs (stride N2), x w_Nc^(n2 k1)     -> ws[k1][n2]
 //   pass B  rows_kernel        : length-4096 row FFT -> real-FFT unpack * H * repack
 //                                (W = alpha Z[k] + beta conj Z[Nc-k]) -> row IFFT, in place
@@ -207,6 +208,73 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Column pass for N1 = 16*R2 with an odd factor, R2 in {3, 5, 6, 10, 12}.  Same first stage as
+// cols_kernel (FFT16 over j); the second stage is 16 DFTs of R2 points per column, dealt to the R2
+// threads of the column as ka = g, g + R2, ... (< 16), so a thread holds up to G = ceil(16/R2)
+// butterflies.  These sizes exist because the circular length only has to cover
+// L + ceil((M-1)/2) in 'same' mode: 5*2^17 instead of 2^20 for the 7.1 / 6.15 s case.
+// ---------------------------------------------------------------------------------------------
+template <int R2>
+struct MixCfg {
+  static constexpr int TC = (R2 <= 6) ? 64 : 32;
+  static constexpr int T = TC * R2;
+  static constexpr int G = (16 + R2 - 1) / R2;
+  static constexpr size_t lds_bytes = sizeof(cf) * 16 * T;
+};
+
+template <int R2, int DIR, class Load, class Store>
+__global__ __launch_bounds__(MixCfg<R2>::T) void cols_mixed_kernel(Load ld, Store st, Twiddles tw, int nchan) {
+  using Cfg = MixCfg<R2>;
+  constexpr int TC = Cfg::TC, T = Cfg::T, G = Cfg::G;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cf* buf = reinterpret_cast<cf*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int c = tid % TC;
+  const int g = tid / TC;
+  int b, tile;
+  xcd_work_item(nchan, tile, b);
+  const int n2 = tile * TC + c;
+
+  cf v[16];
+  const int live = ld.live_rows();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int row = g + R2 * j;
+    cf z = make_float2(0.f, 0.f);
+    if (row < live) {
+      z = ld(b, row, n2);
+      if constexpr (DIR > 0) z = cmulc(z, tw.full[row * kN2 + n2]);
+    }
+    v[j] = z;
+  }
+  fft16<DIR>(v);   // index a
+  const int gu = (TC == 64) ? __builtin_amdgcn_readfirstlane(g) : g;
+#pragma unroll
+  for (int a = 1; a < 16; ++a) v[a] = ctw<DIR>(v[a], tw.hi[4 * gu * a]);   // w_N1^(g a)
+#pragma unroll
+  for (int a = 0; a < 16; ++a) buf[a * T + tid] = v[a];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    const int ka = g + R2 * i;
+    if (ka < 16) {
+      cf y[R2];
+#pragma unroll
+      for (int gp = 0; gp < R2; ++gp) y[gp] = buf[ka * T + gp * TC + c];
+      fft_small<DIR, R2>(y);
+#pragma unroll
+      for (int kb = 0; kb < R2; ++kb) {
+        const int row = ka + 16 * kb;
+        cf z = y[kb];
+        if constexpr (DIR < 0) z = cmul(z, tw.full[row * kN2 + n2]);
+        st(b, row, n2, z);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row pass (pass B).  One workgroup = 512 threads = two rows (k1, N1-k1), or the two
 // self-paired rows (0, N1/2) when pair == 0.  Everything between the load and the store of a
 // row happens in registers + 68 KiB of LDS:
@@ -220,8 +288,7 @@ struct RowsArgs {
   cf* __restrict__ ws;             // [B][N1][4096], in place
   const float4* __restrict__ ab;   // [HB][N1][4096] (alpha.x, alpha.y, beta.x, beta.y)
   long long ab_chan_stride;        // 0: one spectrum shared by all channels; N1*4096: per channel
-  int n1_total;
-  int log_n1;
+  int n1_total;                    // N1 (even; need not be a power of two)
   int npairs;                      // N1/2: pair 0 = rows (0, N1/2), pair p = rows (p, N1-p)
   int nchan;                       // channels in this launch group
 };
@@ -311,17 +378,17 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   for (int q = 0; q < 16; ++q) buf[q * kRowPad + t] = v[q];
   __syncthreads();
 
-  const unsigned ncmask = ((unsigned)N1 << kLogN2) - 1u;
-  // partner bins conj Z[Nc-k] (u[] is free here)
+  // partner bins conj Z[Nc-k] (u[] is free here).  With k = k1 + N1 k2:
+  //   k1 != 0: Nc - k = (N1 - k1) + N1 (4095 - k2)  -> the other row of the pair, column 4095 - k2
+  //   k1 == 0: Nc - k = N1 (4096 - k2) mod Nc       -> row 0 itself, column (4096 - k2) mod 4096
+  // In the self-paired workgroup (rows 0 and N1/2) the partner row is the thread's own row.
+  const int phalf = (pair == 0) ? half : 1 - half;
+  const cf* pbuf = lds + phalf * (16 * kRowPad);
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const unsigned k2 = (unsigned)hi4 + 16u * (unsigned)lo4 + 256u * (unsigned)q;
-    const unsigned k = (unsigned)k1 + (k2 << args.log_n1);
-    const unsigned kp = (0u - k) & ncmask;                 // (Nc - k) mod Nc
-    const unsigned prow = kp & (unsigned)(N1 - 1);
-    const unsigned pk2 = kp >> args.log_n1;
-    const int phalf = (prow == (unsigned)rowA) ? 0 : 1;
-    u[q] = lds[phalf * (16 * kRowPad) + (pk2 >> 8) * kRowPad + 16 * (pk2 & 15u) + ((pk2 >> 4) & 15u)];
+    const unsigned pk2 = (k1 != 0) ? (4095u - k2) : ((4096u - k2) & 4095u);
+    u[q] = pbuf[(pk2 >> 8) * kRowPad + 16 * (pk2 & 15u) + ((pk2 >> 4) & 15u)];
   }
   // bin 0 of the packed transform carries DC and Nyquist: ab.x = H[0]/Nc, ab.z = H[Nc]/Nc
   const bool dc_lane = (k1 == 0) && (t == 0);
@@ -366,106 +433,6 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   fft16<+1>(v);                                            // over ka -> j
 #pragma unroll
   for (int j = 0; j < 16; ++j) bstore_cf(v[j], r_row, vo8, j * 256 * 8);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Spectrum pass: same forward row FFT, but instead of filtering it turns the packed transform
-// of a real filter h into the alpha/beta planes (device-side plan build for per-channel FIRs,
-// reference core/impulse_response.py:110-119 equalize).  scale = 1/Nc.
-//   H[k]    = E + w^k O,  conj(H[Nc-k]) = E - w^k O,  E = (Z[k]+conj Z[Nc-k])/2, O = -i (Z[k]-conj Z[Nc-k])/2
-//   alpha   = (H[k](1+s) + conj(H[Nc-k])(1-s)) / 2 * scale,  s = Im w^k = -sin(2 pi k / nfft)
-//   beta    = i c (H[k] - conj(H[Nc-k])) / 2 * scale,          c = Re w^k
-// ---------------------------------------------------------------------------------------------
-struct SpectrumArgs {
-  const cf* __restrict__ ws;       // [HB][N1][4096] pass-A output of the filters
-  float4* __restrict__ ab;         // [HB][N1][4096]
-  const cf* __restrict__ tw_nfft_lo;   // exp(-2 pi i m / nfft), m < 2048
-  const cf* __restrict__ tw_nfft_hi;   // exp(-2 pi i 2048 m / nfft), m < Nc/1024
-  int n1_total;
-  int log_n1;
-  int npairs;
-  float scale;
-};
-
-__global__ __launch_bounds__(512) void spectrum_kernel(SpectrumArgs args, Twiddles tw) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  cf* lds = reinterpret_cast<cf*>(smem_raw);
-
-  const int tid = threadIdx.x;
-  const int half = tid >> 8;
-  const int t = tid & 255;
-  const int N1 = args.n1_total;
-  const int b = blockIdx.x / args.npairs;
-  const int pair = blockIdx.x - b * args.npairs;
-  const int rowA = pair;
-  const int rowB = (pair == 0) ? (N1 >> 1) : (N1 - pair);
-  const int k1 = half ? rowB : rowA;
-  cf* buf = lds + half * (16 * kRowPad);
-  const cf* wsrow = args.ws + ((long long)b * N1 + k1) * kN2;
-  const int hi4 = t >> 4;
-  const int lo4 = t & 15;
-
-  cf v[16], u[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) v[j] = wsrow[t + 256 * j];
-  fft16<-1>(v);
-#pragma unroll
-  for (int a = 1; a < 16; ++a) v[a] = cmul(v[a], tw.row[t * a]);
-#pragma unroll
-  for (int a = 0; a < 16; ++a) buf[a * kRowPad + t] = v[a];
-  __syncthreads();
-#pragma unroll
-  for (int j2 = 0; j2 < 16; ++j2) u[j2] = buf[hi4 * kRowPad + 16 * j2 + lo4];
-  fft16<-1>(u);
-#pragma unroll
-  for (int q = 1; q < 16; ++q) u[q] = cmul(u[q], tw.row[16 * lo4 * q]);
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) buf[hi4 * kRowPad + lo4 * 17 + q] = u[q];
-  __syncthreads();
-#pragma unroll
-  for (int t2 = 0; t2 < 16; ++t2) v[t2] = buf[hi4 * kRowPad + t2 * 17 + lo4];
-  fft16<-1>(v);
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) buf[q * kRowPad + t] = v[q];
-  __syncthreads();
-
-  float4* abrow = args.ab + ((long long)b * N1 + k1) * kN2;
-  const unsigned ncmask = ((unsigned)N1 << kLogN2) - 1u;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const unsigned k2 = (unsigned)hi4 + 16u * (unsigned)lo4 + 256u * (unsigned)q;
-    const unsigned k = (unsigned)k1 + ((unsigned)k2 << args.log_n1);
-    const unsigned kp = (0u - k) & ncmask;
-    const unsigned prow = kp & (unsigned)(N1 - 1);
-    const unsigned pk2 = kp >> args.log_n1;
-    const int phalf = (prow == (unsigned)rowA) ? 0 : 1;
-    const cf zp = lds[phalf * (16 * kRowPad) + (pk2 >> 8) * kRowPad + 16 * (pk2 & 15u) + ((pk2 >> 4) & 15u)];
-    const cf z = v[q];
-    const cf zc = make_float2(zp.x, -zp.y);                 // conj Z[Nc-k]
-    const cf E = make_float2(0.5f * (z.x + zc.x), 0.5f * (z.y + zc.y));
-    const cf D = make_float2(0.5f * (z.x - zc.x), 0.5f * (z.y - zc.y));
-    const cf O = make_float2(D.y, -D.x);                    // -i D
-    const cf wk = cmul(args.tw_nfft_lo[k & 2047u], args.tw_nfft_hi[k >> 11]);
-    const cf wO = cmul(wk, O);
-    const cf Hk = cadd(E, wO);
-    const cf Gk = csub(E, wO);                              // conj(H[Nc-k])
-    const float s = wk.y, c = wk.x;
-    float4 out;
-    out.x = 0.5f * args.scale * (Hk.x * (1.f + s) + Gk.x * (1.f - s));
-    out.y = 0.5f * args.scale * (Hk.y * (1.f + s) + Gk.y * (1.f - s));
-    const cf dH = csub(Hk, Gk);
-    out.z = 0.5f * args.scale * (-c * dH.y);                // i c dH
-    out.w = 0.5f * args.scale * (c * dH.x);
-    if (k == 0u) {
-      out.x = args.scale * (z.x + z.y);                     // H[0]
-      out.y = 0.f;
-      out.z = args.scale * (z.x - z.y);                     // H[Nc]
-      out.w = 0.f;
-    }
-    abrow[q * 256 + t] = out;
-  }
 }
 
 }  // namespace imp

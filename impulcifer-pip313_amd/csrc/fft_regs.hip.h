@@ -8,30 +8,30 @@ namespace imp {
 
 typedef float2 cf;  // complex fp32: .x = re, .y = im
 
-__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ cf cmul(cf a, cf b) {
+__host__ __device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__host__ __device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+__host__ __device__ __forceinline__ cf cmul(cf a, cf b) {
   return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
 }
 // a * conj(b)
-__device__ __forceinline__ cf cmulc(cf a, cf b) {
+__host__ __device__ __forceinline__ cf cmulc(cf a, cf b) {
   return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
 }
-__device__ __forceinline__ cf cconj(cf a) { return make_float2(a.x, -a.y); }
+__host__ __device__ __forceinline__ cf cconj(cf a) { return make_float2(a.x, -a.y); }
 // multiply by twiddle w (forward table value); DIR<0 -> a*w, DIR>0 -> a*conj(w)
 template <int DIR>
-__device__ __forceinline__ cf ctw(cf a, cf w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
+__host__ __device__ __forceinline__ cf ctw(cf a, cf w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
 
 // DIR = -1: forward kernel exp(-2 pi i nk/N); DIR = +1: inverse (unnormalised).
 template <int DIR>
-__device__ __forceinline__ void bfly2(cf& a, cf& b) {
+__host__ __device__ __forceinline__ void bfly2(cf& a, cf& b) {
   cf t = a;
   a = cadd(t, b);
   b = csub(t, b);
 }
 
 template <int DIR>
-__device__ __forceinline__ void bfly4(cf& a, cf& b, cf& c, cf& d) {
+__host__ __device__ __forceinline__ void bfly4(cf& a, cf& b, cf& c, cf& d) {
   cf t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
   // forward: (-i)*t3 ; inverse: (+i)*t3
   cf r3 = DIR < 0 ? make_float2(t3.y, -t3.x) : make_float2(-t3.y, t3.x);
@@ -43,7 +43,7 @@ __device__ __forceinline__ void bfly4(cf& a, cf& b, cf& c, cf& d) {
 
 // multiply by exp(DIR * 2 pi i * m / 16) with compile-time m
 template <int DIR, int M>
-__device__ __forceinline__ cf mul_w16(cf a) {
+__host__ __device__ __forceinline__ cf mul_w16(cf a) {
   constexpr float C1 = 0.92387953251128675613f;  // cos(pi/8)
   constexpr float S1 = 0.38268343236508977173f;  // sin(pi/8)
   constexpr float R = 0.70710678118654752440f;   // sqrt(1/2)
@@ -68,7 +68,7 @@ __device__ __forceinline__ cf mul_w16(cf a) {
 
 // 16-point DFT, natural order in / natural order out.
 template <int DIR>
-__device__ __forceinline__ void fft16(cf (&v)[16]) {
+__host__ __device__ __forceinline__ void fft16(cf (&v)[16]) {
   // n = 4*n1 + n2 ; k = k1 + 4*k2
 #pragma unroll
   for (int n2 = 0; n2 < 4; ++n2) bfly4<DIR>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
@@ -97,7 +97,7 @@ __device__ __forceinline__ void fft16(cf (&v)[16]) {
 
 // 8-point DFT on v[0..7] (natural in / natural out).
 template <int DIR>
-__device__ __forceinline__ void fft8(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4, cf& x5, cf& x6, cf& x7) {
+__host__ __device__ __forceinline__ void fft8(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4, cf& x5, cf& x6, cf& x7) {
   // n = 2*n1 + n2 ; k = k1 + 4*k2
   bfly4<DIR>(x0, x2, x4, x6);   // n2 = 0 -> A[0][k1] in x0,x2,x4,x6
   bfly4<DIR>(x1, x3, x5, x7);   // n2 = 1 -> A[1][k1] in x1,x3,x5,x7
@@ -115,7 +115,7 @@ __device__ __forceinline__ void fft8(cf& x0, cf& x1, cf& x2, cf& x3, cf& x4, cf&
 
 // R-point DFT applied to the G = 16/R independent groups v[i*R .. i*R+R-1].
 template <int DIR, int R>
-__device__ __forceinline__ void fft_groups(cf (&v)[16]) {
+__host__ __device__ __forceinline__ void fft_groups(cf (&v)[16]) {
   if constexpr (R == 16) {
     fft16<DIR>(v);
   } else if constexpr (R == 8) {
@@ -127,6 +127,100 @@ __device__ __forceinline__ void fft_groups(cf (&v)[16]) {
   } else if constexpr (R == 2) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) bfly2<DIR>(v[2 * i], v[2 * i + 1]);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Odd radices for the mixed column lengths N1 = 16*R2, R2 in {3, 5, 6, 10, 12}.
+// 6, 10 and 12 use the prime-factor (Good-Thomas) mapping: no twiddles between the two factors.
+// ---------------------------------------------------------------------------------------------
+template <int DIR>
+__host__ __device__ __forceinline__ void bfly3(cf& a, cf& b, cf& c) {
+  constexpr float S = 0.86602540378443864676f;      // sin(2 pi / 3)
+  const cf t1 = cadd(b, c);
+  const cf m1 = make_float2(a.x - 0.5f * t1.x, a.y - 0.5f * t1.y);
+  const cf d = csub(b, c);
+  // forward: -i*S*d ; inverse: +i*S*d
+  const cf t2 = DIR < 0 ? make_float2(S * d.y, -S * d.x) : make_float2(-S * d.y, S * d.x);
+  a = cadd(a, t1);
+  b = cadd(m1, t2);
+  c = csub(m1, t2);
+}
+
+template <int DIR>
+__host__ __device__ __forceinline__ void bfly5(cf& a, cf& b, cf& c, cf& d, cf& e) {
+  constexpr float C1 = 0.30901699437494742410f;     // cos(2 pi / 5)
+  constexpr float C2 = -0.80901699437494742410f;    // cos(4 pi / 5)
+  constexpr float S1 = 0.95105651629515357212f;     // sin(2 pi / 5)
+  constexpr float S2 = 0.58778525229247312917f;     // sin(4 pi / 5)
+  const cf t1 = cadd(b, e), t2 = cadd(c, d), t3 = csub(b, e), t4 = csub(c, d);
+  const cf m1 = make_float2(a.x + C1 * t1.x + C2 * t2.x, a.y + C1 * t1.y + C2 * t2.y);
+  const cf m2 = make_float2(a.x + C2 * t1.x + C1 * t2.x, a.y + C2 * t1.y + C1 * t2.y);
+  const cf n1 = make_float2(S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y);
+  const cf n2 = make_float2(S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y);
+  // forward: X1 = m1 - i n1, X4 = m1 + i n1, X2 = m2 - i n2, X3 = m2 + i n2 ; inverse: signs swapped
+  const cf r1 = DIR < 0 ? make_float2(n1.y, -n1.x) : make_float2(-n1.y, n1.x);   // (-/+ i) n1
+  const cf r2 = DIR < 0 ? make_float2(n2.y, -n2.x) : make_float2(-n2.y, n2.x);
+  a = cadd(a, cadd(t1, t2));
+  b = cadd(m1, r1);
+  e = csub(m1, r1);
+  c = cadd(m2, r2);
+  d = csub(m2, r2);
+}
+
+// R-point DFT of x[0..R-1] in place, natural order in and out, R in {3, 5, 6, 10, 12}.
+template <int DIR, int R>
+__host__ __device__ __forceinline__ void fft_small(cf* x) {
+  if constexpr (R == 3) {
+    bfly3<DIR>(x[0], x[1], x[2]);
+  } else if constexpr (R == 5) {
+    bfly5<DIR>(x[0], x[1], x[2], x[3], x[4]);
+  } else if constexpr (R == 6) {
+    // N1 = 2, N2 = 3: n = (3 n1 + 2 n2) mod 6 ; k = (3 k1 + 4 k2) mod 6
+    cf a[2][3];
+#pragma unroll
+    for (int n1 = 0; n1 < 2; ++n1)
+#pragma unroll
+      for (int n2 = 0; n2 < 3; ++n2) a[n1][n2] = x[(3 * n1 + 2 * n2) % 6];
+#pragma unroll
+    for (int n1 = 0; n1 < 2; ++n1) bfly3<DIR>(a[n1][0], a[n1][1], a[n1][2]);
+#pragma unroll
+    for (int k2 = 0; k2 < 3; ++k2) bfly2<DIR>(a[0][k2], a[1][k2]);
+#pragma unroll
+    for (int k1 = 0; k1 < 2; ++k1)
+#pragma unroll
+      for (int k2 = 0; k2 < 3; ++k2) x[(3 * k1 + 4 * k2) % 6] = a[k1][k2];
+  } else if constexpr (R == 10) {
+    // N1 = 2, N2 = 5: n = (5 n1 + 2 n2) mod 10 ; k = (5 k1 + 6 k2) mod 10
+    cf a[2][5];
+#pragma unroll
+    for (int n1 = 0; n1 < 2; ++n1)
+#pragma unroll
+      for (int n2 = 0; n2 < 5; ++n2) a[n1][n2] = x[(5 * n1 + 2 * n2) % 10];
+#pragma unroll
+    for (int n1 = 0; n1 < 2; ++n1) bfly5<DIR>(a[n1][0], a[n1][1], a[n1][2], a[n1][3], a[n1][4]);
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) bfly2<DIR>(a[0][k2], a[1][k2]);
+#pragma unroll
+    for (int k1 = 0; k1 < 2; ++k1)
+#pragma unroll
+      for (int k2 = 0; k2 < 5; ++k2) x[(5 * k1 + 6 * k2) % 10] = a[k1][k2];
+  } else if constexpr (R == 12) {
+    // N1 = 4, N2 = 3: n = (3 n1 + 4 n2) mod 12 ; k = (9 k1 + 4 k2) mod 12
+    cf a[4][3];
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1)
+#pragma unroll
+      for (int n2 = 0; n2 < 3; ++n2) a[n1][n2] = x[(3 * n1 + 4 * n2) % 12];
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) bfly3<DIR>(a[n1][0], a[n1][1], a[n1][2]);
+#pragma unroll
+    for (int k2 = 0; k2 < 3; ++k2) bfly4<DIR>(a[0][k2], a[1][k2], a[2][k2], a[3][k2]);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+      for (int k2 = 0; k2 < 3; ++k2) x[(9 * k1 + 4 * k2) % 12] = a[k1][k2];
   }
 }
 

@@ -50,9 +50,7 @@ static int fail(int code, const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------------
 struct TwSet {
   cf* full = nullptr;     // exp(-2 pi i (k1 n2 mod Nc) / Nc) at [k1*4096 + n2]
-  cf* hi = nullptr;       // exp(-2 pi i 1024 m / Nc), m < Nc/1024
-  cf* nfft_lo = nullptr;  // exp(-2 pi i m / nfft), m < 2048
-  cf* nfft_hi = nullptr;  // exp(-2 pi i 2048 m / nfft), m < Nc/1024 (only Nc/2048 used)
+  cf* hi = nullptr;       // exp(-2 pi i 1024 m / Nc), m < Nc/1024 = 4 N1   (w_N1^j = hi[4 j])
 };
 
 struct imp_ctx {
@@ -63,7 +61,7 @@ struct imp_ctx {
   cf* tw_t1 = nullptr;                  // row-pass stage tables, see conv_kernels.hip.h
   cf* tw_t2 = nullptr;
   cf* tw_t4 = nullptr;
-  std::map<int, TwSet> tw_by_log_n1;    // keyed by log2(N1)
+  std::map<int, TwSet> tw_by_n1;        // keyed by N1
   std::mutex mu;
   // scratch for the small ragged kernels
   void* scratch = nullptr;
@@ -117,27 +115,28 @@ static int ctx_row_tables(imp_ctx* ctx) {
   return IMP_OK;
 }
 
-static int ctx_twiddles(imp_ctx* ctx, int log_n1, TwSet* out) {
+static int ctx_twiddles(imp_ctx* ctx, int n1, TwSet* out) {
   std::lock_guard<std::mutex> lk(ctx->mu);
-  auto it = ctx->tw_by_log_n1.find(log_n1);
-  if (it != ctx->tw_by_log_n1.end()) {
+  auto it = ctx->tw_by_n1.find(n1);
+  if (it != ctx->tw_by_n1.end()) {
     *out = it->second;
     return IMP_OK;
   }
-  const double Nc = (double)((int64_t)1 << (log_n1 + imp::kLogN2));
+  const int64_t nc = (int64_t)n1 * imp::kN2;
   TwSet t;
   int rc;
   {
-    const int64_t nc = (int64_t)Nc, n1 = nc >> imp::kLogN2;
     std::vector<cf> full((size_t)nc);
     for (int64_t k1 = 0; k1 < n1; ++k1)
       for (int64_t n2 = 0; n2 < imp::kN2; ++n2) full[(size_t)(k1 * imp::kN2 + n2)] = unit_root(k1 * n2, nc);
     if ((rc = upload_table(&t.full, full, ctx->stream))) return rc;
   }
-  if ((rc = upload_twiddle(&t.hi, (size_t)(Nc / 1024), 1024.0, Nc, ctx->stream))) return rc;
-  if ((rc = upload_twiddle(&t.nfft_lo, 2048, 1.0, 2.0 * Nc, ctx->stream))) return rc;
-  if ((rc = upload_twiddle(&t.nfft_hi, (size_t)(Nc / 1024), 2048.0, 2.0 * Nc, ctx->stream))) return rc;
-  ctx->tw_by_log_n1[log_n1] = t;
+  {
+    std::vector<cf> hi((size_t)(4 * n1));
+    for (int64_t m = 0; m < 4 * n1; ++m) hi[(size_t)m] = unit_root(1024 * m, nc);
+    if ((rc = upload_table(&t.hi, hi, ctx->stream))) return rc;
+  }
+  ctx->tw_by_n1[n1] = t;
   *out = t;
   return IMP_OK;
 }
@@ -227,11 +226,9 @@ extern "C" void imp_ctx_destroy(imp_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  for (auto& kv : ctx->tw_by_log_n1) {
+  for (auto& kv : ctx->tw_by_n1) {
     (void)hipFree(kv.second.full);
     (void)hipFree(kv.second.hi);
-    (void)hipFree(kv.second.nfft_lo);
-    (void)hipFree(kv.second.nfft_hi);
   }
   if (ctx->tw_row) (void)hipFree(ctx->tw_row);
   if (ctx->tw_t1) (void)hipFree(ctx->tw_t1);
@@ -306,29 +303,45 @@ extern "C" int imp_memset(imp_ctx* ctx, void* dptr, int value, size_t bytes) {
 // ------------------------------------------------------------------------------------------------
 typedef std::complex<double> cd;
 
-static void host_fft_pow2(std::vector<cd>& a) {
-  const size_t n = a.size();
-  if (n < 2) return;
-  for (size_t i = 1, j = 0; i < n; ++i) {   // bit reversal
-    size_t bit = n >> 1;
-    for (; j & bit; bit >>= 1) j ^= bit;
-    j ^= bit;
-    if (i < j) std::swap(a[i], a[j]);
+// Recursive decimation-in-time FFT for lengths 2^a 3^b 5^c (plan preparation only, fp64).
+// w holds exp(-2 pi i k / N) for the top-level N; stride selects the sub-transform's roots.
+static void host_fft_rec(const cd* in, cd* out, size_t n, size_t in_stride, const std::vector<cd>& w, size_t w_stride,
+                         cd* scratch) {
+  if (n == 1) {
+    out[0] = in[0];
+    return;
   }
-  std::vector<cd> w(n / 2);
-  for (size_t k = 0; k < n / 2; ++k) {
-    double ang = -2.0 * M_PI * (double)k / (double)n;
+  const size_t p = (n % 2 == 0) ? 2 : (n % 3 == 0) ? 3 : 5;
+  const size_t m = n / p;
+  for (size_t r = 0; r < p; ++r)
+    host_fft_rec(in + r * in_stride, scratch + r * m, m, in_stride * p, w, w_stride * p, out + r * m);
+  // scratch[r*m + k] = DFT_m of the r-th decimated sequence; combine
+  const size_t wn = w.size();
+  for (size_t k = 0; k < m; ++k) {
+    cd t[5];
+    for (size_t r = 0; r < p; ++r) t[r] = scratch[r * m + k] * w[(r * k * w_stride) % wn];
+    for (size_t q = 0; q < p; ++q) {
+      cd acc = t[0];
+      for (size_t r = 1; r < p; ++r) acc += t[r] * w[(r * q * m * w_stride) % wn];
+      out[k + q * m] = acc;
+    }
+  }
+}
+
+static bool host_fft(std::vector<cd>& a) {
+  const size_t n = a.size();
+  size_t r = n;
+  for (size_t p : {2u, 3u, 5u})
+    while (r % p == 0) r /= p;
+  if (r != 1) return false;
+  std::vector<cd> w(n), out(n), scratch(n);
+  for (size_t k = 0; k < n; ++k) {
+    const double ang = -2.0 * M_PI * (double)k / (double)n;
     w[k] = cd(std::cos(ang), std::sin(ang));
   }
-  for (size_t len = 2; len <= n; len <<= 1) {
-    const size_t half = len >> 1, step = n / len;
-    for (size_t i = 0; i < n; i += len)
-      for (size_t k = 0; k < half; ++k) {
-        cd u = a[i + k], v = a[i + k + half] * w[k * step];
-        a[i + k] = u + v;
-        a[i + k + half] = u - v;
-      }
-  }
+  host_fft_rec(a.data(), out.data(), n, 1, w, 1, scratch.data());
+  a.swap(out);
+  return true;
 }
 
 // H[0..Nc] = rfft(h zero-padded to nfft = 2 Nc) via one Nc-point complex FFT
@@ -339,7 +352,7 @@ static void host_rfft(const double* h, int64_t M, int64_t Nc, std::vector<cd>& H
     double im = (2 * n + 1 < M) ? h[2 * n + 1] : 0.0;
     z[(size_t)n] = cd(re, im);
   }
-  host_fft_pow2(z);
+  host_fft(z);
   H.assign((size_t)Nc + 1, cd(0, 0));
   const double nfft = 2.0 * (double)Nc;
   for (int64_t k = 0; k <= Nc; ++k) {
@@ -353,12 +366,12 @@ static void host_rfft(const double* h, int64_t M, int64_t Nc, std::vector<cd>& H
 }
 
 // alpha/beta planes in the row kernel's register order, fp32 (see conv_kernels.hip.h)
-static void host_alpha_beta(const std::vector<cd>& H, int64_t Nc, int N1, int log_n1, float4* ab) {
+static void host_alpha_beta(const std::vector<cd>& H, int64_t Nc, int N1, float4* ab) {
   const double nfft = 2.0 * (double)Nc;
   const double inv = 1.0 / (double)Nc;
   for (int k1 = 0; k1 < N1; ++k1) {
     for (int k2 = 0; k2 < imp::kN2; ++k2) {
-      const int64_t k = (int64_t)k1 + ((int64_t)k2 << log_n1);
+      const int64_t k = (int64_t)k1 + (int64_t)N1 * k2;
       const int u = 16 * (k2 & 15) + ((k2 >> 4) & 15);
       const int q = k2 >> 8;
       float4 o;
@@ -389,7 +402,7 @@ struct imp_plan {
   int mode = IMP_MODE_SAME;
   int64_t out_start = 0, out_len = 0;
   int64_t nfft = 0, Nc = 0;
-  int N1 = 0, log_n1 = 0, R2 = 0;
+  int N1 = 0, R2 = 0;
   int64_t ws_channels = 0;
   TwSet tw;
   float4* ab = nullptr;    // [n_filters][N1][4096]
@@ -426,6 +439,24 @@ static int launch_cols(imp_plan* p, int64_t nchan, Load ld, Store st) {
   return IMP_OK;
 }
 
+template <int R2, int DIR, class Load, class Store>
+static int launch_cols_mixed(imp_plan* p, int64_t nchan, Load ld, Store st) {
+  using Cfg = imp::MixCfg<R2>;
+  auto kern = imp::cols_mixed_kernel<R2, DIR, Load, Store>;
+  static bool attr_set = false;   // per instantiation
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes));
+    attr_set = true;
+  }
+  const int tiles = imp::kN2 / Cfg::TC;
+  imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4, p->ctx->tw_row};
+  dim3 grid((unsigned)(nchan * tiles)), block(Cfg::T);
+  hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->ctx->stream, ld, st, tw, (int)nchan);
+  HIP_TRY(hipGetLastError());
+  return IMP_OK;
+}
+
 template <int DIR, class Load, class Store>
 static int launch_cols_any(imp_plan* p, int64_t nchan, Load ld, Store st) {
   switch (p->R2) {
@@ -434,6 +465,11 @@ static int launch_cols_any(imp_plan* p, int64_t nchan, Load ld, Store st) {
     case 4: return launch_cols<4, DIR>(p, nchan, ld, st);
     case 8: return launch_cols<8, DIR>(p, nchan, ld, st);
     case 16: return launch_cols<16, DIR>(p, nchan, ld, st);
+    case 3: return launch_cols_mixed<3, DIR>(p, nchan, ld, st);
+    case 5: return launch_cols_mixed<5, DIR>(p, nchan, ld, st);
+    case 6: return launch_cols_mixed<6, DIR>(p, nchan, ld, st);
+    case 10: return launch_cols_mixed<10, DIR>(p, nchan, ld, st);
+    case 12: return launch_cols_mixed<12, DIR>(p, nchan, ld, st);
   }
   return fail(IMP_ERR_UNSUPPORTED, "unsupported column radix %d", p->R2);
 }
@@ -453,7 +489,6 @@ static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan) {
   a.ab = p->ab + (p->n_filters > 1 ? first_chan * plane : 0);
   a.ab_chan_stride = p->n_filters > 1 ? plane : 0;
   a.n1_total = p->N1;
-  a.log_n1 = p->log_n1;
   a.npairs = p->N1 / 2;
   a.nchan = (int)nchan;
   imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4, p->ctx->tw_row};
@@ -467,27 +502,35 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   if (M < 1 || L < 1) return fail(IMP_ERR_INVALID, "M and L must be >= 1 (M=%lld L=%lld)", (long long)M, (long long)L);
   if (n_filters < 1) return fail(IMP_ERR_INVALID, "n_filters must be >= 1");
   if (mode != IMP_MODE_SAME && mode != IMP_MODE_FULL) return fail(IMP_ERR_INVALID, "mode must be IMP_MODE_SAME or IMP_MODE_FULL");
-  const int64_t need = L + M - 1;
-  int log_nfft = 17;
-  while (((int64_t)1 << log_nfft) < need) ++log_nfft;
-  if (log_nfft > 21)
-    return fail(IMP_ERR_UNSUPPORTED, "L+M-1 = %lld needs nfft > 2^21, beyond the two-level plan", (long long)need);
+  // Circular length the transform must cover.  'full' needs every sample of the linear
+  // convolution: L+M-1.  'same' keeps only [s0, s0+L) with s0 = (M-1)/2, so wrap-around may land in
+  // the discarded part: P >= L + ceil((M-1)/2) = L + M/2 is enough (and P >= M so the filter fits).
+  const int64_t full = L + M - 1;
+  const int64_t need = (mode == IMP_MODE_SAME) ? std::max(L + M / 2, M) : full;
+  static const int kR2[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};      // N1 = 16*R2 rows of 4096
+  int r2 = 0;
+  for (int cand : kR2)
+    if ((int64_t)cand * 2 * 16 * imp::kN2 >= need) {
+      r2 = cand;
+      break;
+    }
+  if (!r2)
+    return fail(IMP_ERR_UNSUPPORTED, "needs a transform of %lld points, beyond 2^21 (two-level plan)", (long long)need);
   p->L = L;
   p->M = M;
   p->n_filters = n_filters;
   p->mode = mode;
-  p->nfft = (int64_t)1 << log_nfft;
-  p->Nc = p->nfft / 2;
-  p->log_n1 = log_nfft - 1 - imp::kLogN2;
-  p->N1 = 1 << p->log_n1;
-  p->R2 = p->N1 / 16;
+  p->R2 = r2;
+  p->N1 = 16 * r2;
+  p->Nc = (int64_t)p->N1 * imp::kN2;
+  p->nfft = 2 * p->Nc;
   if (mode == IMP_MODE_SAME) {
     // scipy.signal._signaltools._centered: start = (full - L) // 2 with full = L + M - 1
     p->out_start = (M - 1) / 2;
     p->out_len = L;
   } else {
     p->out_start = 0;
-    p->out_len = need;
+    p->out_len = full;
   }
   if (ws_channels <= 0) {
     // keep the workspace within ~128 MiB so A->B->C hand-offs stay in the 256 MiB Infinity Cache
@@ -500,7 +543,7 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
 static int plan_alloc(imp_plan* p) {
   int rc = ctx_bind(p->ctx);
   if (rc) return rc;
-  if ((rc = ctx_twiddles(p->ctx, p->log_n1, &p->tw))) return rc;
+  if ((rc = ctx_twiddles(p->ctx, p->N1, &p->tw))) return rc;
   const size_t plane = (size_t)p->N1 * imp::kN2;
   hipError_t e = hipMalloc((void**)&p->ab, plane * (size_t)p->n_filters * sizeof(float4));
   if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(spectrum): %s", hipGetErrorString(e));
@@ -551,7 +594,7 @@ extern "C" int imp_conv_plan_create(imp_ctx* ctx, const double* filter, int64_t 
   std::vector<cd> H;
   for (int64_t f = 0; f < n_filters; ++f) {
     host_rfft(filter + f * filter_ld, M, p->Nc, H);
-    host_alpha_beta(H, p->Nc, p->N1, p->log_n1, ab.data());
+    host_alpha_beta(H, p->Nc, p->N1, ab.data());
     hipError_t e = hipMemcpyAsync(p->ab + (size_t)f * plane, ab.data(), plane * sizeof(float4),
                                   hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -561,6 +604,27 @@ extern "C" int imp_conv_plan_create(imp_ctx* ctx, const double* filter, int64_t 
     }
   }
   *out = p;
+  return IMP_OK;
+}
+
+extern "C" int imp_debug_plan_geometry(int64_t M, int64_t L, int mode, int64_t* nfft, int64_t* out_start,
+                                       int64_t* out_len) {
+  imp_plan tmp;
+  int rc = plan_geometry(&tmp, M, 1, L, mode, 1);
+  if (rc) return rc;
+  if (nfft) *nfft = tmp.nfft;
+  if (out_start) *out_start = tmp.out_start;
+  if (out_len) *out_len = tmp.out_len;
+  return IMP_OK;
+}
+
+extern "C" int imp_debug_host_spectrum(const double* filter, int64_t M, int n1_rows, float* ab_out) {
+  if (!filter || !ab_out || M < 1 || n1_rows < 16 || n1_rows % 16) return fail(IMP_ERR_INVALID, "imp_debug_host_spectrum: bad argument");
+  const int64_t Nc = (int64_t)n1_rows * imp::kN2;
+  if (M > 2 * Nc) return fail(IMP_ERR_INVALID, "filter longer than the transform");
+  std::vector<cd> H;
+  host_rfft(filter, M, Nc, H);
+  host_alpha_beta(H, Nc, n1_rows, reinterpret_cast<float4*>(ab_out));
   return IMP_OK;
 }
 

@@ -71,6 +71,8 @@ SIGNATURES = {
     "imp_conv_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64]),
     "imp_plan_set_timing": (C.c_int, [_vp, C.c_int]),
     "imp_plan_get_timing": (C.c_int, [_vp, _pd, _pi64, C.c_int]),
+    "imp_debug_plan_geometry": (C.c_int, [_i64, _i64, C.c_int, _pi64, _pi64, _pi64]),
+    "imp_debug_host_spectrum": (C.c_int, [_pd, _i64, C.c_int, _pf]),
     "imp_plan_debug_run_stage": (C.c_int, [_vp, _pf, _i64, _i64, C.c_int, _pf]),
     "imp_peak_index": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
     "imp_peak_index_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
@@ -319,6 +321,24 @@ class ConvPlan:
             self.close()
         except Exception:
             pass
+
+
+def plan_geometry(M, L, mode="same"):
+    """(nfft, out_start, out_len) the library picks for a plan; needs no GPU."""
+    lib = load_library()
+    a, b, c = _i64(), _i64(), _i64()
+    _check(lib.imp_debug_plan_geometry(int(M), int(L), {"same": IMP_MODE_SAME, "full": IMP_MODE_FULL}[mode],
+                                       C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
+def host_spectrum(filt, n1_rows):
+    """alpha/beta planes [n1_rows, 4096, 4] float32 exactly as a plan uploads them; needs no GPU."""
+    lib = load_library()
+    f = np.ascontiguousarray(filt, dtype=np.float64)
+    out = np.empty((int(n1_rows), 4096, 4), dtype=np.float32)
+    _check(lib.imp_debug_host_spectrum(f.ctypes.data_as(_pd), len(f), int(n1_rows), out.ctypes.data_as(_pf)))
+    return out
 
 
 _default_ctx = None

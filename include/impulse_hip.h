@@ -66,7 +66,9 @@ int imp_memset(imp_ctx* ctx, void* dptr, int value, size_t bytes);
  *   core/impulse_response.py:110-119, 126-135    ImpulseResponse.equalize / convolve (mode 'full')
  *   core/parallel_workers.py:9-21                process_plot_worker (mode 'full')
  *
- * A plan fixes (filter, M, L, mode).  nfft = 2^k >= max(L+M-1, 2^17), at most 2^21.
+ * A plan fixes (filter, M, L, mode).  The circular length is nfft = 131072*R2 with
+ * R2 in {1,2,3,4,5,6,8,10,12,16}: the smallest that covers L+M-1 ('full') or L + M/2 ('same':
+ * wrap-around may fall into the part of the linear convolution that the window discards).
  * ws_channels = channels processed per launch group (0 = choose so that the workspace stays
  * resident in the 256 MiB Infinity Cache).
  */
@@ -105,6 +107,13 @@ int imp_plan_set_timing(imp_plan* plan, int every_n);
 /* Synchronises, then returns accumulated milliseconds of pass A / B / C and the number of launch
  * groups measured since the last reset. */
 int imp_plan_get_timing(imp_plan* plan, double ms[3], int64_t* launches, int reset);
+
+/* Test hooks that need no GPU: the plan geometry chosen for (M, L, mode), and the fp64 host
+ * preparation of a filter spectrum (alpha/beta planes, fp32, in the row kernel's register order:
+ * ab[k1][kb2*256 + u][4], k2 = (u>>4) + 16*(u&15) + 256*kb2) for n1_rows = nfft / 8192. */
+int imp_debug_plan_geometry(int64_t M, int64_t L, int mode, int64_t* nfft, int64_t* out_start,
+                            int64_t* out_len);
+int imp_debug_host_spectrum(const double* filter, int64_t M, int n1_rows, float* ab_out);
 
 /* debug: copy the workspace of the last launch group to the host (complex64 [chunk][N1][4096]) */
 int imp_plan_debug_run_stage(imp_plan* plan, const float* x, int64_t B, int64_t ld_in, int stage,

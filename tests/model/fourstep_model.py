@@ -163,10 +163,35 @@ def pass_c(ws, nfft, start, length):
     return full[start:start + length]
 
 
-def convolve_same_model(x, h):
+SUPPORTED_R2 = (1, 2, 3, 4, 5, 6, 8, 10, 12, 16)     # N1 = 16*R2 rows of 4096 -> nfft = 131072*R2
+
+
+def pick_nfft(L, M, mode="same"):
+    """Same rule as plan_geometry() in csrc/impulse_hip.hip: 'same' only needs L + M/2 points
+    because wrap-around may fall into the part of the linear convolution the window discards."""
+    need = max(L + M // 2, M) if mode == "same" else L + M - 1
+    for r2 in SUPPORTED_R2:
+        if 131072 * r2 >= need:
+            return 131072 * r2
+    raise ValueError("too long")
+
+
+def alpha_beta_register_order(alpha, beta):
+    """[k1][k2] complex planes -> the float32 [k1][kb2*256 + u][4] layout of the row kernel."""
+    k2 = np.arange(N2)
+    pos = (k2 >> 8) * 256 + 16 * (k2 & 15) + ((k2 >> 4) & 15)
+    out = np.zeros(alpha.shape + (4,), dtype=np.float64)
+    out[:, pos, 0], out[:, pos, 1] = alpha.real, alpha.imag
+    out[:, pos, 2], out[:, pos, 3] = beta.real, beta.imag
+    out[0, 0, 1] = 0.0
+    out[0, 0, 3] = 0.0
+    return out
+
+
+def convolve_same_model(x, h, nfft=None):
     L, M = len(x), len(h)
-    need = L + M - 1
-    nfft = 1 << max(17, int(np.ceil(np.log2(need))))
+    if nfft is None:
+        nfft = pick_nfft(L, M, "same")
     alpha, beta = plan_alpha_beta(h, nfft)
     ws = pass_a(x, nfft)
     ws = pass_b(ws, alpha, beta)

@@ -44,8 +44,10 @@ def spec_rel_cropped(y, ref, fs=48000, n=65536):
 # ------------------------------------------------------------------------------------------------
 # K1/K5: convolution plans against the oracle
 # ------------------------------------------------------------------------------------------------
+# sizes chosen to hit every column radix R2 (nfft = 131072*R2) in at least one mode:
+# 'same': R2 = 1, 1, 1, 1, 2, 3, 5, 6, 10 ; 'full': 1, 1, 1, 1, 2, 3, 6, 8, 12
 @pytest.mark.parametrize("L,M", [(1, 1), (17, 5), (1000, 999), (70001, 61000), (150000, 100001),
-                                 (243635, 147635), (391270, 295270)])
+                                 (243635, 147635), (391270, 295270), (500000, 400000), (827965, 635965)])
 @pytest.mark.parametrize("mode", ["same", "full"])
 def test_conv_matches_oracle(gpu_ctx, L, M, mode):
     from impulse_hip import ConvPlan
@@ -55,6 +57,8 @@ def test_conv_matches_oracle(gpu_ctx, L, M, mode):
     x[2] = 0.0                                                   # an all-zero (silent) channel
     h = rng.standard_normal(M) * np.exp(-np.arange(M) / max(M / 5.0, 1.0))
     plan = ConvPlan(gpu_ctx, h, L, mode)
+    from impulse_hip._native import plan_geometry
+    assert plan.nfft == plan_geometry(M, L, mode)[0]
     y = plan.execute(x)
     plan.close()
     assert y.shape == (3, L if mode == "same" else L + M - 1)
@@ -67,7 +71,7 @@ def test_conv_matches_oracle(gpu_ctx, L, M, mode):
 
 
 def test_conv_full_size_c5_properties(gpu_ctx):
-    """C4/C5 shape (L = M = 2^20, nfft 2^21): identity filter, linearity, delay equivariance."""
+    """C4/C5 shape (L = M = 2^20, circular length 3*2^19): identity filter, linearity, delay equivariance."""
     from impulse_hip import ConvPlan
     L = M = 1 << 20
     rng = np.random.default_rng(0xC5)

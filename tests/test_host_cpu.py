@@ -172,6 +172,62 @@ def test_kernel_dataflow_model_is_a_linear_convolution():
         assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-12
 
 
+def test_plan_geometry_wraparound_rule(lib):
+    """'same' plans may use a circular length shorter than L+M-1; the NumPy model proves the window
+    is still exact at the chosen size, and the library picks the same size as the model."""
+    import fourstep_model as fm
+    from impulse_hip._native import plan_geometry
+    from oracle.scipy_restated import fft_convolve
+    cases = {(391270, 295270): 655360, (827965, 635965): 1310720, (1 << 20, 1 << 20): 1572864,
+             (243635, 147635): 393216, (100, 4): 131072, (4, 100): 131072, (1, 1): 131072}
+    for (L, M), want in cases.items():
+        nfft, start, n = plan_geometry(M, L, "same")
+        assert nfft == want == fm.pick_nfft(L, M, "same")
+        assert (start, n) == ((M - 1) // 2, L)
+        nfft_f, start_f, n_f = plan_geometry(M, L, "full")
+        assert nfft_f == fm.pick_nfft(L, M, "full") >= L + M - 1 and (start_f, n_f) == (0, L + M - 1)
+    from impulse_hip import NativeError
+    with pytest.raises(NativeError):
+        plan_geometry(4, 3_000_000, "same")
+    # aliasing lands only outside the window: model at the reduced size == linear convolution
+    rng = np.random.default_rng(8)
+    for L, M in ((250000, 190000), (60000, 130000)):          # nfft 393216 (R2=3) / 131072 with M > L
+        x, h = rng.standard_normal(L), rng.standard_normal(M)
+        nfft = fm.pick_nfft(L, M, "same")
+        assert nfft < L + M - 1
+        y = fm.convolve_same_model(x, h, nfft)
+        ref = fft_convolve(x, h, "same")
+        assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("n1", [16, 48, 80, 96, 128, 160, 192])
+def test_host_spectrum_matches_model(lib, n1):
+    """fp64 host FFT (radices 2/3/5) + alpha/beta packing of the library vs the NumPy model."""
+    import fourstep_model as fm
+    from impulse_hip._native import host_spectrum
+    rng = np.random.default_rng(n1)
+    M = 50000 + n1
+    h = rng.standard_normal(M) * np.exp(-np.arange(M) / 9000.0)
+    got = host_spectrum(h, n1).astype(np.float64)
+    alpha, beta = fm.plan_alpha_beta(h, 2 * n1 * 4096)
+    want = fm.alpha_beta_register_order(alpha, beta)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-7 * scale          # fp32 rounding of fp64 values
+
+
+def test_butterflies_native_unit_test(tmp_path):
+    """csrc/fft_regs.hip.h compiled for the host and checked against a naive DFT (radix 2..16)."""
+    exe = tmp_path / "tb"
+    src = os.path.join(ROOT, "tests", "native", "test_butterflies.cpp")
+    inc = os.path.join(ROOT, "impulcifer-pip313_amd", "csrc")
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+    r = subprocess.run([hipcc, "-O2", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", "-w", "-I", inc, src,
+                        "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "BUTTERFLIES OK" in r.stdout, r.stdout
+
+
 def test_two_rank_gloo_broadcast_and_sharding(tmp_path):
     """world_size 2 on CPU (gloo): rank 0's prepared spectrum bytes reach rank 1 through the same
     broadcast helper bench.py uses with RCCL, and the two shards tile the channel range."""

@@ -28,8 +28,9 @@ def main():
     rng = np.random.default_rng(1)
     ok = True
     # (L, M) chosen to hit every column radix: nfft 2^17 (R2=1) .. 2^21 (R2=16)
-    cases = [(70001, 61000), (150000, 100001), (300000, 147635), (391270, 295270), (1048576, 1048576)]
-    stage_checks = {(70001, 61000), (300000, 147635)}
+    cases = [(70001, 61000), (150000, 100001), (243635, 147635), (391270, 295270), (500000, 400000),
+             (827965, 635965), (1048576, 1048576)]
+    stage_checks = {(70001, 61000), (243635, 147635), (391270, 295270)}
     for (L, M) in cases:
         x = rng.standard_normal((3, L)).astype(np.float32)
         h = rng.standard_normal(M) * np.exp(-np.arange(M) / (M / 6.0))
@@ -54,7 +55,7 @@ def main():
             print(f"   ch{b} same rel err {e:.3e}", flush=True)
             ok &= e < 2e-6
         plan.close()
-        if L <= 300000:
+        if L <= 400000:
             planf = ConvPlan(ctx, h, L, "full")
             yf = planf.execute(x[:1])
             ref = fftconvolve(x[0].astype(np.float64), h, "full")
