@@ -317,6 +317,15 @@ __device__ __forceinline__ void bstore_cf(cf v, __amdgpu_buffer_rsrc_t r, unsign
   __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
 }
 
+// Orders this wave's LDS traffic (all earlier DS ops retired, nothing moved across by the
+// compiler) without stalling the other waves of the workgroup.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cf* lds = reinterpret_cast<cf*>(smem_raw);
@@ -363,10 +372,14 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   fft16<-1>(u);                                            // over j2 -> kb1
 #pragma unroll
   for (int q = 1; q < 16; ++q) u[q] = cmul(u[q], bload_cf(r_t2, vl8, q * 16 * 8));
-  __syncthreads();
+  // The X2 exchange stays inside one 16-lane group (same ka): both the plane-row it overwrites
+  // (read just above by the same 16 lanes) and the values it reads back are private to that group,
+  // which lives in one wave.  LDS executes a wave's DS ops in order, so a wave-level scheduling
+  // barrier replaces the workgroup barrier here (4 of the 9 barriers of this kernel).
+  wave_lds_fence();
 #pragma unroll
   for (int q = 0; q < 16; ++q) buf[hi4 * kRowPad + lo4 * 17 + q] = u[q];
-  __syncthreads();
+  wave_lds_fence();
   // thread (ka = hi4, kb1 = lo4) gathers t2 = 0..15
 #pragma unroll
   for (int t2 = 0; t2 < 16; ++t2) v[t2] = buf[hi4 * kRowPad + t2 * 17 + lo4];
@@ -417,14 +430,14 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], bload_cf(r_t2, vl8, q * 16 * 8));
 #pragma unroll
   for (int t2 = 0; t2 < 16; ++t2) buf[hi4 * kRowPad + t2 * 17 + lo4] = v[t2];
-  __syncthreads();
+  wave_lds_fence();                                        // intra-group exchange, see above
   // thread (ka = hi4, t2 = lo4) gathers kb1 = 0..15
 #pragma unroll
   for (int q = 0; q < 16; ++q) u[q] = buf[hi4 * kRowPad + lo4 * 17 + q];
   fft16<+1>(u);                                            // over kb1 -> j2
 #pragma unroll
   for (int j2 = 0; j2 < 16; ++j2) u[j2] = cmulc(u[j2], bload_cf(r_t4, vo8, j2 * 256 * 8));
-  __syncthreads();
+  wave_lds_fence();                                        // X1' rows are written by the group that read X2'
 #pragma unroll
   for (int j2 = 0; j2 < 16; ++j2) buf[hi4 * kRowPad + 16 * j2 + lo4] = u[j2];
   __syncthreads();
