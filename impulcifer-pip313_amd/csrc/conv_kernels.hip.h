@@ -216,7 +216,7 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
 // ---------------------------------------------------------------------------------------------
 template <int R2>
 struct MixCfg {
-  static constexpr int TC = (R2 <= 6) ? 64 : 32;
+  static constexpr int TC = 64;                 // 512-byte row segments; R2 = 10/12 -> 80/96 KiB of LDS
   static constexpr int T = TC * R2;
   static constexpr int G = (16 + R2 - 1) / R2;
   static constexpr size_t lds_bytes = sizeof(cf) * 16 * T;

@@ -10,8 +10,8 @@ from collections import defaultdict
 def short(name):
     if "rows_kernel" in name:
         return "rows_kernel"
-    if "cols_kernel" in name:
-        return "cols_fwd" if ", -1," in name or "<8, -1" in name or ", -1, " in name or "-1, imp::LoadRealPacked" in name else "cols_inv"
+    if "cols_kernel" in name or "cols_mixed_kernel" in name:
+        return "cols_fwd" if ", -1, " in name else "cols_inv"
     return name[:40]
 
 
