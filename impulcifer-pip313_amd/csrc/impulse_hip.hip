@@ -16,18 +16,16 @@
 #include <string>
 #include <vector>
 
-#include "../../include/impulse_hip.h"
+#include "internal.h"
 #include "conv_kernels.hip.h"
 #include "ir_kernels.hip.h"
-
-using imp::cf;
 
 // ------------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 
-static int fail(int code, const char* fmt, ...) {
+int imp_fail(int code, const char* fmt, ...) {
   char buf[1024];
   va_list ap;
   va_start(ap, fmt);
@@ -37,38 +35,7 @@ static int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-#define HIP_TRY(expr)                                                                         \
-  do {                                                                                        \
-    hipError_t e_ = (expr);                                                                   \
-    if (e_ != hipSuccess)                                                                     \
-      return fail(IMP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
-                  __LINE__);                                                                  \
-  } while (0)
-
-// ------------------------------------------------------------------------------------------------
-// context
-// ------------------------------------------------------------------------------------------------
-struct TwSet {
-  cf* full = nullptr;     // exp(-2 pi i (k1 n2 mod Nc) / Nc) at [k1*4096 + n2]
-  cf* hi = nullptr;       // exp(-2 pi i 1024 m / Nc), m < Nc/1024 = 4 N1   (w_N1^j = hi[4 j])
-};
-
-struct imp_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = true;
-  cf* tw_row = nullptr;                 // exp(-2 pi i m / 4096)
-  cf* tw_t1 = nullptr;                  // row-pass stage tables, see conv_kernels.hip.h
-  cf* tw_t2 = nullptr;
-  cf* tw_t4 = nullptr;
-  std::map<int, TwSet> tw_by_n1;        // keyed by N1
-  std::mutex mu;
-  // scratch for the small ragged kernels
-  void* scratch = nullptr;
-  size_t scratch_bytes = 0;
-};
-
-static int ctx_bind(imp_ctx* ctx) {
+int ctx_bind(imp_ctx* ctx) {
   HIP_TRY(hipSetDevice(ctx->device));
   return IMP_OK;
 }
@@ -235,6 +202,7 @@ extern "C" void imp_ctx_destroy(imp_ctx* ctx) {
   if (ctx->tw_t2) (void)hipFree(ctx->tw_t2);
   if (ctx->tw_t4) (void)hipFree(ctx->tw_t4);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  minphase_plans_destroy(ctx);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -1,0 +1,53 @@
+// Internal declarations shared by the translation units of libimpulse_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/impulse_hip.h"
+#include "fft_regs.hip.h"
+
+using imp::cf;
+
+int imp_fail(int code, const char* fmt, ...);
+#define fail imp_fail
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail(IMP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                  \
+  } while (0)
+
+struct TwSet {
+  cf* full = nullptr;     // exp(-2 pi i (k1 n2 mod Nc) / Nc) at [k1*4096 + n2]
+  cf* hi = nullptr;       // exp(-2 pi i 1024 m / Nc), m < Nc/1024 = 4 N1   (w_N1^j = hi[4 j])
+};
+
+struct MinPhasePlan;      // minphase.hip
+
+struct imp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  cf* tw_row = nullptr;                 // exp(-2 pi i m / 4096)
+  cf* tw_t1 = nullptr;                  // row-pass stage tables, see conv_kernels.hip.h
+  cf* tw_t2 = nullptr;
+  cf* tw_t4 = nullptr;
+  std::map<int, TwSet> tw_by_n1;        // keyed by N1
+  std::mutex mu;
+  // scratch for the small ragged kernels
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+  // K6 plans keyed by (taps n, fs)
+  std::map<std::pair<long long, long long>, MinPhasePlan*> minphase_plans;
+};
+
+int ctx_bind(imp_ctx* ctx);
+void minphase_plans_destroy(imp_ctx* ctx);

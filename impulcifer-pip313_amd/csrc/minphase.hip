@@ -1,0 +1,344 @@
+// K6 - batched minimum-phase FIR design on the GPU, in fp64.
+//
+// Replaces, for B channels at once, the tail of FrequencyResponse.minimum_phase_impulse_response
+// (reference autoeq/frequency_response.py:676-680):
+//     ir = scipy.signal.firwin2(2n, f, gain, fs=fs)          # f = linspace(0, fs//2, n)
+//     ir = scipy.signal.minimum_phase(ir, n_fft=len(ir))     # homomorphic, half=True  -> n taps
+// as called per channel by core/parallel_workers.py:129 (n = 9 600 @48 kHz, 19 200 @96 kHz).
+//
+// firwin2 : fx = interp(linspace(0, nyq, 1 + 2^ceil(log2 2n)), f, gain) ; irfft(fx * linear-phase
+//           shift)[:2n] * hamming(2n)
+// minimum_phase : |FFT_2n| -> + 1e-7 min>0 -> 0.5 log -> IFFT -> causal cepstral window -> FFT -> exp
+//           -> IFFT -> real[:n]
+//
+// Why fp64: the design forces a zero at Nyquist, so |H| there is rounding noise (1e-12) that the log
+// turns into a -27 spike; SciPy's own result moves by 5e-9 of the FIR peak for a 1-ulp change of the
+// input (tests/test_oracle_golden.py).  In fp32 that bin would be 1e-7 noise and the taps would move
+// by ~1e-4.  The work is tiny (4 transforms of 19 200/38 400 points + one of 2^16/2^17 per channel),
+// so it is laid out for simplicity: a batched Stockham autosort FFT, one launch per radix pass
+// (radix 4/2/3/5, generic O(R^2) butterflies with exact table twiddles), ping-ponging two global
+// buffers, and a few elementwise kernels.  HBM-bound streaming passes; no LDS, no MFMA.
+#include <cmath>
+#include <utility>
+
+#include "internal.h"
+
+typedef double2 cdbl;
+
+namespace {
+
+__device__ __forceinline__ cdbl zmul(cdbl a, cdbl b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// One Stockham pass of radix R over `batch` transforms of length N (blockIdx.y = transform).
+//   n = current sub-transform length, s = N / n interleaved sub-transforms, m = n / R
+//   a_k = x[q + s (p + k m)] ; b_j = sum_k a_k w_R^(j k) ; y[q + s (R p + j)] = b_j w_n^(p j)
+// roots[k] = exp(-2 pi i k / N); dir = +1 uses the conjugates.
+template <int R>
+__global__ __launch_bounds__(256) void stockham_pass(const cdbl* __restrict__ x, cdbl* __restrict__ y,
+                                                     const cdbl* __restrict__ roots, int N, int n, int s, int dir) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = n / R;
+  if (i >= s * m) return;
+  const int q = i % s, p = i / s;
+  const long long base = (long long)blockIdx.y * N;
+  cdbl a[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) a[k] = x[base + q + (long long)s * (p + k * m)];
+  const int step_r = N / R;        // w_R = roots[step_r]
+  const int step_n = N / n;        // w_n = roots[step_n]
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    cdbl acc = a[0];
+#pragma unroll
+    for (int k = 1; k < R; ++k) {
+      cdbl w = roots[((j * k) % R) * step_r];
+      if (dir > 0) w.y = -w.y;
+      const cdbl t = zmul(a[k], w);
+      acc.x += t.x;
+      acc.y += t.y;
+    }
+    cdbl tw = roots[(int)(((long long)p * j * step_n) % N)];
+    if (dir > 0) tw.y = -tw.y;
+    y[base + q + (long long)s * (R * p + j)] = zmul(acc, tw);
+  }
+}
+
+// firwin2 front: fx = np.interp(x_i, f, gain) on the two uniform grids, times the linear-phase
+// shift, extended to the Hermitian spectrum of length nirf = 2 (nfreqs - 1) for a complex IFFT.
+__global__ __launch_bounds__(256) void firwin2_spectrum(const double* __restrict__ gain, cdbl* __restrict__ spec,
+                                                        int n, int nfreqs, double nyq_f /* fs//2 grid end */,
+                                                        double nyq /* fs/2 */, int numtaps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nfreqs) return;
+  const double* g = gain + (long long)blockIdx.y * n;
+  cdbl* out = spec + (long long)blockIdx.y * (2 * (nfreqs - 1));
+  // np.linspace(0, stop, num): arange(num) * (stop / (num - 1)), last element forced to stop
+  const double step_x = nyq / (double)(nfreqs - 1);
+  const double step_f = nyq_f / (double)(n - 1);
+  const double xi = (i == nfreqs - 1) ? nyq : (double)i * step_x;
+  // np.interp: j = last index with f[j] <= x ; f[j] = j * step_f (f[n-1] = nyq_f)
+  double val;
+  if (xi >= nyq_f) {
+    val = g[n - 1];
+  } else {
+    int j = (int)(xi / step_f);
+    if (j > n - 2) j = n - 2;
+    auto fj = [&](int jj) { return (jj == n - 1) ? nyq_f : (double)jj * step_f; };
+    while (j > 0 && fj(j) > xi) --j;
+    while (j < n - 2 && fj(j + 1) <= xi) ++j;
+    const double slope = (g[j + 1] - g[j]) / (fj(j + 1) - fj(j));
+    val = slope * (xi - fj(j)) + g[j];
+  }
+  // shift = exp(-(numtaps - 1)/2 * 1j * pi * x / nyq)
+  const double ang = -((double)(numtaps - 1) / 2.0) * M_PI * xi / nyq;
+  double sn, cs;
+  sincos(ang, &sn, &cs);
+  const cdbl v = make_double2(val * cs, val * sn);
+  const int nirf = 2 * (nfreqs - 1);
+  // irfft ignores the imaginary parts of the DC and Nyquist bins
+  if (i == 0 || i == nfreqs - 1) {
+    out[i] = make_double2(v.x, 0.0);
+  } else {
+    out[i] = v;
+    out[nirf - i] = make_double2(v.x, -v.y);
+  }
+}
+
+// ir[k] = Re(ifft)[k] / nirf * hamming(numtaps)[k], as a complex sequence of length numtaps
+__global__ __launch_bounds__(256) void firwin2_window(const cdbl* __restrict__ time, cdbl* __restrict__ ir, int nirf,
+                                                      int numtaps) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= numtaps) return;
+  const double w = 0.54 - 0.46 * cos(2.0 * M_PI * (double)k / (double)(numtaps - 1));
+  const double v = time[(long long)blockIdx.y * nirf + k].x / (double)nirf;
+  ir[(long long)blockIdx.y * numtaps + k] = make_double2(v * w, 0.0);
+}
+
+// mag = |H| in place (.x), per-transform minimum of the strictly positive magnitudes
+__global__ __launch_bounds__(256) void magnitude_and_min(cdbl* __restrict__ h, unsigned long long* __restrict__ minbits,
+                                                         int N) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  double m = INFINITY;
+  if (k < N) {
+    cdbl* p = h + (long long)blockIdx.y * N + k;
+    const double mag = hypot(p->x, p->y);
+    *p = make_double2(mag, 0.0);
+    if (mag > 0.0) m = mag;
+  }
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) m = fmin(m, __shfl_xor(m, sft, 64));
+  // positive doubles order like their bit patterns
+  if ((threadIdx.x & 63) == 0 && m != INFINITY) atomicMin(&minbits[blockIdx.y], (unsigned long long)__double_as_longlong(m));
+}
+
+// x = 0.5 * log(mag + 1e-7 * min)
+__global__ __launch_bounds__(256) void half_log(cdbl* __restrict__ h, const unsigned long long* __restrict__ minbits, int N) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  const double mn = __longlong_as_double((long long)minbits[blockIdx.y]);
+  cdbl* p = h + (long long)blockIdx.y * N + k;
+  *p = make_double2(0.5 * log(p->x + 1e-7 * mn), 0.0);
+}
+
+// cepstrum (unnormalised IFFT output) -> real part / N * homomorphic window (1, 2.., 0..)
+__global__ __launch_bounds__(256) void cepstral_window(cdbl* __restrict__ c, int N) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  const int stop = N / 2;
+  double w = 0.0;
+  if (k == 0) w = 1.0;
+  else if (k < stop) w = 2.0;
+  else if (k == stop && (N & 1)) w = 1.0;
+  cdbl* p = c + (long long)blockIdx.y * N + k;
+  *p = make_double2(p->x / (double)N * w, 0.0);
+}
+
+__global__ __launch_bounds__(256) void complex_exp(cdbl* __restrict__ c, int N) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  cdbl* p = c + (long long)blockIdx.y * N + k;
+  const double e = exp(p->x);
+  double sn, cs;
+  sincos(p->y, &sn, &cs);
+  *p = make_double2(e * cs, e * sn);
+}
+
+__global__ __launch_bounds__(256) void take_real(const cdbl* __restrict__ c, double* __restrict__ out, int N, int ntaps) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= ntaps) return;
+  out[(long long)blockIdx.y * ntaps + k] = c[(long long)blockIdx.y * N + k].x / (double)N;
+}
+
+std::vector<int> factorise(int n) {
+  std::vector<int> f;
+  while (n % 4 == 0) { f.push_back(4); n /= 4; }
+  while (n % 2 == 0) { f.push_back(2); n /= 2; }
+  while (n % 3 == 0) { f.push_back(3); n /= 3; }
+  while (n % 5 == 0) { f.push_back(5); n /= 5; }
+  if (n != 1) f.clear();
+  return f;
+}
+
+}  // namespace
+
+struct MinPhasePlan {
+  int n = 0;            // taps out
+  int numtaps = 0;      // 2n
+  int nfreqs = 0;       // 1 + 2^ceil(log2 numtaps)
+  int nirf = 0;         // 2 (nfreqs - 1)
+  double nyq = 0, nyq_f = 0;
+  std::vector<int> fac_tap, fac_irf;
+  cdbl* roots_tap = nullptr;
+  cdbl* roots_irf = nullptr;
+  // work buffers for up to cap channels
+  int64_t cap = 0;
+  cdbl *a = nullptr, *b = nullptr;
+  double* gain = nullptr;
+  double* out = nullptr;
+  unsigned long long* minbits = nullptr;
+};
+
+static int upload_roots(cdbl** dptr, int N, hipStream_t s) {
+  std::vector<cdbl> h((size_t)N);
+  for (int k = 0; k < N; ++k) {
+    const double ang = -2.0 * M_PI * (double)k / (double)N;
+    h[(size_t)k] = make_double2(std::cos(ang), std::sin(ang));
+  }
+  HIP_TRY(hipMalloc((void**)dptr, (size_t)N * sizeof(cdbl)));
+  HIP_TRY(hipMemcpyAsync(*dptr, h.data(), (size_t)N * sizeof(cdbl), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return IMP_OK;
+}
+
+static void plan_free(MinPhasePlan* p) {
+  if (!p) return;
+  (void)hipFree(p->roots_tap);
+  (void)hipFree(p->roots_irf);
+  (void)hipFree(p->a);
+  (void)hipFree(p->b);
+  (void)hipFree(p->gain);
+  (void)hipFree(p->out);
+  (void)hipFree(p->minbits);
+  delete p;
+}
+
+void minphase_plans_destroy(imp_ctx* ctx) {
+  for (auto& kv : ctx->minphase_plans) plan_free(kv.second);
+  ctx->minphase_plans.clear();
+}
+
+// batched FFT: result ends in *cur (either buf0 or buf1)
+static int run_fft(imp_ctx* ctx, const std::vector<int>& fac, const cdbl* roots, int N, int64_t B, int dir, cdbl** cur,
+                   cdbl** other) {
+  int n = N, s = 1;
+  for (int r : fac) {
+    const int threads = N / r;
+    dim3 grid((unsigned)((threads + 255) / 256), (unsigned)B), block(256);
+    switch (r) {
+      case 4: hipLaunchKernelGGL(stockham_pass<4>, grid, block, 0, ctx->stream, *cur, *other, roots, N, n, s, dir); break;
+      case 2: hipLaunchKernelGGL(stockham_pass<2>, grid, block, 0, ctx->stream, *cur, *other, roots, N, n, s, dir); break;
+      case 3: hipLaunchKernelGGL(stockham_pass<3>, grid, block, 0, ctx->stream, *cur, *other, roots, N, n, s, dir); break;
+      case 5: hipLaunchKernelGGL(stockham_pass<5>, grid, block, 0, ctx->stream, *cur, *other, roots, N, n, s, dir); break;
+      default: return fail(IMP_ERR_UNSUPPORTED, "radix %d", r);
+    }
+    HIP_TRY(hipGetLastError());
+    std::swap(*cur, *other);
+    n /= r;
+    s *= r;
+  }
+  return IMP_OK;
+}
+
+extern "C" int imp_minphase_fir(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, double* fir_out) {
+  if (!ctx || (B && (!gain || !fir_out))) return fail(IMP_ERR_INVALID, "imp_minphase_fir: null argument");
+  if (B < 0 || n < 2 || n > (1 << 20)) return fail(IMP_ERR_INVALID, "imp_minphase_fir: bad B or n");
+  if (!(fs > 0)) return fail(IMP_ERR_INVALID, "imp_minphase_fir: fs must be positive");
+  if (B == 0) return IMP_OK;
+  for (int64_t b = 0; b < B; ++b)
+    if (gain[b * n + n - 1] != 0.0)
+      return fail(IMP_ERR_INVALID, "A Type II filter must have zero gain at the Nyquist frequency (channel %lld)", (long long)b);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+
+  MinPhasePlan* p = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const auto key = std::make_pair((long long)n, (long long)std::llround(fs * 1000.0));
+    auto it = ctx->minphase_plans.find(key);
+    if (it != ctx->minphase_plans.end()) {
+      p = it->second;
+    } else {
+      p = new (std::nothrow) MinPhasePlan();
+      if (!p) return fail(IMP_ERR_ALLOC, "out of host memory");
+      p->n = (int)n;
+      p->numtaps = 2 * (int)n;
+      int lg = 0;
+      while ((1 << lg) < p->numtaps) ++lg;
+      p->nfreqs = 1 + (1 << lg);
+      p->nirf = 2 * (p->nfreqs - 1);
+      p->nyq = 0.5 * fs;
+      p->nyq_f = std::floor(fs / 2.0);                 // the reference's grid ends at fs // 2
+      p->fac_tap = factorise(p->numtaps);
+      p->fac_irf = factorise(p->nirf);
+      if (p->fac_tap.empty() || p->fac_irf.empty()) {
+        delete p;
+        return fail(IMP_ERR_UNSUPPORTED, "2n = %d is not of the form 2^a 3^b 5^c", 2 * (int)n);
+      }
+      if ((rc = upload_roots(&p->roots_tap, p->numtaps, ctx->stream)) ||
+          (rc = upload_roots(&p->roots_irf, p->nirf, ctx->stream))) {
+        plan_free(p);
+        return rc;
+      }
+      ctx->minphase_plans[key] = p;
+    }
+  }
+  if (p->nyq_f != p->nyq)
+    return fail(IMP_ERR_INVALID, "freq must start with 0 and end with fs/2. (odd fs %g: grid ends at %g)", fs, p->nyq_f);
+  if (p->cap < B) {
+    (void)hipFree(p->a); (void)hipFree(p->b); (void)hipFree(p->gain); (void)hipFree(p->out); (void)hipFree(p->minbits);
+    p->a = p->b = nullptr; p->gain = p->out = nullptr; p->minbits = nullptr; p->cap = 0;
+    const size_t len = (size_t)std::max(p->nirf, p->numtaps);
+    if (hipMalloc((void**)&p->a, (size_t)B * len * sizeof(cdbl)) != hipSuccess ||
+        hipMalloc((void**)&p->b, (size_t)B * len * sizeof(cdbl)) != hipSuccess ||
+        hipMalloc((void**)&p->gain, (size_t)B * n * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->out, (size_t)B * n * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->minbits, (size_t)B * sizeof(unsigned long long)) != hipSuccess)
+      return fail(IMP_ERR_ALLOC, "imp_minphase_fir: device allocation for %lld channels failed", (long long)B);
+    p->cap = B;
+  }
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(p->gain, gain, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(p->minbits, 0xFF, (size_t)B * sizeof(unsigned long long), s));
+  auto grid_for = [&](int count) { return dim3((unsigned)((count + 255) / 256), (unsigned)B); };
+  cdbl *cur = p->a, *oth = p->b;
+
+  // firwin2
+  hipLaunchKernelGGL(firwin2_spectrum, grid_for(p->nfreqs), dim3(256), 0, s, p->gain, cur, p->n, p->nfreqs, p->nyq_f,
+                     p->nyq, p->numtaps);
+  HIP_TRY(hipGetLastError());
+  if ((rc = run_fft(ctx, p->fac_irf, p->roots_irf, p->nirf, B, +1, &cur, &oth))) return rc;
+  hipLaunchKernelGGL(firwin2_window, grid_for(p->numtaps), dim3(256), 0, s, cur, oth, p->nirf, p->numtaps);
+  HIP_TRY(hipGetLastError());
+  std::swap(cur, oth);
+  // minimum_phase (homomorphic, half = True)
+  const int N = p->numtaps;
+  if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, -1, &cur, &oth))) return rc;
+  hipLaunchKernelGGL(magnitude_and_min, grid_for(N), dim3(256), 0, s, cur, p->minbits, N);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(half_log, grid_for(N), dim3(256), 0, s, cur, p->minbits, N);
+  HIP_TRY(hipGetLastError());
+  if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, +1, &cur, &oth))) return rc;
+  hipLaunchKernelGGL(cepstral_window, grid_for(N), dim3(256), 0, s, cur, N);
+  HIP_TRY(hipGetLastError());
+  if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, -1, &cur, &oth))) return rc;
+  hipLaunchKernelGGL(complex_exp, grid_for(N), dim3(256), 0, s, cur, N);
+  HIP_TRY(hipGetLastError());
+  if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, +1, &cur, &oth))) return rc;
+  hipLaunchKernelGGL(take_real, grid_for(p->n), dim3(256), 0, s, cur, p->out, N, p->n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(fir_out, p->out, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return IMP_OK;
+}

@@ -74,6 +74,7 @@ SIGNATURES = {
     "imp_debug_plan_geometry": (C.c_int, [_i64, _i64, C.c_int, _pi64, _pi64, _pi64]),
     "imp_debug_host_spectrum": (C.c_int, [_pd, _i64, C.c_int, _pf]),
     "imp_plan_debug_run_stage": (C.c_int, [_vp, _pf, _i64, _i64, C.c_int, _pf]),
+    "imp_minphase_fir": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, _pd]),
     "imp_peak_index": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
     "imp_peak_index_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
     "imp_apply_window": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.POINTER(WindowParams)]),
@@ -212,6 +213,18 @@ class Context:
         _check(self._lib.imp_peak_index(self._h, _ptr_f(flat), _ptr_i64(offs), _ptr_i64(lens), B,
                                         float(peak_height), _ptr_i64(idx), _ptr_f(mx)))
         return idx, mx
+
+    def minphase_fir(self, gain, fs):
+        """Batched firwin2 + homomorphic minimum_phase (fp64 on the device): gain [B, n] linear gains on
+        linspace(0, fs//2, n) -> FIR taps [B, n]."""
+        g = np.ascontiguousarray(gain, dtype=np.float64)
+        one = g.ndim == 1
+        if one:
+            g = g[None, :]
+        out = np.empty_like(g)
+        _check(self._lib.imp_minphase_fir(self._h, g.ctypes.data_as(_pd), g.shape[0], g.shape[1], float(fs),
+                                          out.ctypes.data_as(_pd)))
+        return out[0] if one else out
 
     def apply_window(self, rows, params):
         """In-place-style windowing of a list of rows; returns new float32 arrays."""

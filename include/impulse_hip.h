@@ -131,6 +131,16 @@ int imp_peak_index(imp_ctx* ctx, const float* x, const int64_t* off, const int64
 int imp_peak_index_device(imp_ctx* ctx, const float* d_x, const int64_t* off, const int64_t* len,
                           int64_t B, double peak_height, int64_t* idx_out, float* maxabs_out);
 
+/* ---- K6: minimum-phase FIR design, batched, fp64 -----------------------------------------------
+ * Tail of FrequencyResponse.minimum_phase_impulse_response (autoeq/frequency_response.py:676-680),
+ * called per channel by core/parallel_workers.py:129:
+ *     ir = scipy.signal.firwin2(2n, linspace(0, fs//2, n), gain, fs=fs)      (Hamming window)
+ *     fir = scipy.signal.minimum_phase(ir, n_fft=2n)                         (homomorphic, n taps)
+ * gain: host [B][n] LINEAR gains on that grid (gain[n-1] must be 0: type II filter, as SciPy demands);
+ * fir_out: host [B][n].  2n must factor into 2, 3 and 5 (n comes from next_fast_len).  fs must be even
+ * (the grid ends at fs//2 and firwin2 requires it to end at fs/2). */
+int imp_minphase_fir(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, double* fir_out);
+
 /* ---- K4/K8: in-place gain, fades, decay window (elementwise) ---------------------------------
  * core/hrir.py:530-544 (gain), :591-612 (Hann fade-in), :642-651 (crop + Hann fade-out),
  * core/decay.py:383-403 apply_decay_window.

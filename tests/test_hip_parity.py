@@ -459,3 +459,59 @@ def test_equalize_and_plot_worker_full_convolution(gpu_ctx):
     sweep = np.sin(np.arange(147635) ** 1.3 / 500.0).astype(np.float32)
     _, _, rec = process_plot_worker(("FL", "left", ir.astype(np.float64), sweep, 48000))
     assert rel(rec, fft_convolve(sweep.astype(np.float64), ir.astype(np.float64), "full")) <= TIME_TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# K6: minimum-phase FIR design (fp64 on the device) against FIRs produced by the reference
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fs", [48000, 96000])
+def test_minimum_phase_fir_golden(gpu_ctx, golden, fs):
+    from impulse_hip import NativeError
+    from impulse_hip.frequency_response import (FrequencyResponse, fir_design_gain,
+                                                minimum_phase_impulse_responses)
+    g = golden("minphase")
+    freq = g[f"fs{fs}_freq"]
+    names = ("flat", "wavy", "tilt")
+    firs = minimum_phase_impulse_responses(freq, [g[f"fs{fs}_{nm}_eq"] for nm in names], fs, f_res=5, normalize=False)
+    for fir, nm in zip(firs, names):
+        want = g[f"fs{fs}_{nm}_fir"]
+        assert fir.shape == want.shape == ((9600,) if fs == 48000 else (19200,))
+        # 5e-8 of the FIR peak = the reference's own reproducibility floor for this ill-conditioned
+        # design (see tests/test_oracle_golden.py::test_minimum_phase_fir)
+        assert np.max(np.abs(fir - want)) <= 5e-8 * np.max(np.abs(want)), nm
+        assert np.all(np.isfinite(fir))
+        # minimum phase: energy is front-loaded (reference tests/test_frequency_response_core.py:101-112)
+        assert np.sum(fir[: len(fir) // 8] ** 2) > 0.9 * np.sum(fir ** 2)
+        # magnitude response of the taps follows the requested curve (dB, away from the band edges)
+        f = np.fft.rfftfreq(len(fir) * 4, 1 / fs)
+        H = 20 * np.log10(np.abs(np.fft.rfft(fir, len(fir) * 4)) + 1e-30)
+        from oracle.impulse_response import interpolate_log
+        sel = (f > 50) & (f < fs / 2 * 0.8)
+        assert np.max(np.abs(H[sel] - interpolate_log(freq, g[f"fs{fs}_{nm}_eq"], f[sel]))) < 0.5
+    fr = FrequencyResponse("x", frequency=freq, equalization=g[f"fs{fs}_wavy_eq"])
+    one = fr.minimum_phase_impulse_response(fs=fs, normalize=False, f_res=5)
+    assert np.array_equal(one, firs[1])                          # batched == single, bit for bit
+    bad = fir_design_gain(freq, g[f"fs{fs}_flat_eq"], fs, 5, False)
+    bad[-1] = 1.0
+    with pytest.raises(NativeError):
+        gpu_ctx.minphase_fir(bad, fs)                            # type II filter needs a Nyquist zero
+
+
+def test_minimum_phase_fir_then_equalize_chain(gpu_ctx, golden):
+    """EQ curve -> FIR (K6) -> ir.equalize(fir) (K5): the chain of core/pipeline.py:668-691."""
+    from impulse_hip.frequency_response import minimum_phase_impulse_response
+    from impulse_hip.impulse_response import ImpulseResponse
+    from oracle.minphase import minimum_phase_impulse_response as oracle_fir
+    from oracle.scipy_restated import fft_convolve
+    g = golden("minphase")
+    freq, eq = g["fs48000_freq"], g["fs48000_tilt_eq"]
+    fir = minimum_phase_impulse_response(freq, eq, 48000, f_res=5, normalize=False)
+    ofir = oracle_fir(freq, eq, 48000, f_res=5, normalize=False)
+    assert np.max(np.abs(fir - ofir)) <= 5e-8 * np.max(np.abs(ofir))
+    rng = np.random.default_rng(3)
+    data = (rng.standard_normal(33600) * np.exp(-np.arange(33600) / 3000.0)).astype(np.float32).astype(np.float64)
+    ir = ImpulseResponse(data.copy(), 48000)
+    ir.equalize(fir)
+    ref = fft_convolve(data, ofir, "full")
+    assert len(ir.data) == 33600 + 9600 - 1
+    assert rel(ir.data, ref) <= TIME_TOL and spec_rel(ir.data, ref) <= SPEC_TOL
