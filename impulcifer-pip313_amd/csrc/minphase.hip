@@ -91,8 +91,12 @@ __global__ __launch_bounds__(256) void firwin2_spectrum(const double* __restrict
     const double slope = (g[j + 1] - g[j]) / (fj(j + 1) - fj(j));
     val = slope * (xi - fj(j)) + g[j];
   }
-  // shift = exp(-(numtaps - 1)/2 * 1j * pi * x / nyq)
-  const double ang = -((double)(numtaps - 1) / 2.0) * M_PI * xi / nyq;
+  // shift = exp(-(numtaps - 1)/2 * 1j * pi * x / nyq).  NumPy divides a complex array by a real
+  // scalar as a multiplication by the reciprocal (scl = 1/nyq), so the phase is (c pi x) * (1/nyq);
+  // a true division differs by 1 ulp of a ~3e4 rad angle (3.6e-12) in ~20 % of the bins, which is
+  // enough to move the taps' alternating sum (= |H| at the forced Nyquist zero, 1e-11) by 25 %.
+  const double scl = 1.0 / nyq;
+  const double ang = (-((double)(numtaps - 1) / 2.0) * M_PI * xi) * scl;
   double sn, cs;
   sincos(ang, &sn, &cs);
   const cdbl v = make_double2(val * cs, val * sn);
@@ -251,7 +255,20 @@ static int run_fft(imp_ctx* ctx, const std::vector<int>& fac, const cdbl* roots,
   return IMP_OK;
 }
 
+static int minphase_run(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, double* fir_out, int stage);
+
 extern "C" int imp_minphase_fir(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, double* fir_out) {
+  return minphase_run(ctx, gain, B, n, fs, fir_out, 2);
+}
+
+extern "C" int imp_debug_minphase_stage(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, int stage,
+                                        double* out) {
+  if (stage < 0 || stage > 1) return fail(IMP_ERR_INVALID, "stage must be 0 (firwin2 taps) or 1 (|FFT| of the taps)");
+  return minphase_run(ctx, gain, B, n, fs, out, stage);
+}
+
+// stage 0: out[B][2n] = firwin2 taps; stage 1: out[B][2n] = |FFT_2n(taps)|; stage 2: out[B][n] = FIR
+static int minphase_run(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, double* fir_out, int stage) {
   if (!ctx || (B && (!gain || !fir_out))) return fail(IMP_ERR_INVALID, "imp_minphase_fir: null argument");
   if (B < 0 || n < 2 || n > (1 << 20)) return fail(IMP_ERR_INVALID, "imp_minphase_fir: bad B or n");
   if (!(fs > 0)) return fail(IMP_ERR_INVALID, "imp_minphase_fir: fs must be positive");
@@ -324,9 +341,18 @@ extern "C" int imp_minphase_fir(imp_ctx* ctx, const double* gain, int64_t B, int
   std::swap(cur, oth);
   // minimum_phase (homomorphic, half = True)
   const int N = p->numtaps;
+  auto dump_real = [&](const cdbl* src) -> int {       // debug stages: real parts of [B][N]
+    std::vector<cdbl> h((size_t)B * N);
+    HIP_TRY(hipMemcpyAsync(h.data(), src, h.size() * sizeof(cdbl), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; i < h.size(); ++i) fir_out[i] = h[i].x;
+    return IMP_OK;
+  };
+  if (stage == 0) return dump_real(cur);
   if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, -1, &cur, &oth))) return rc;
   hipLaunchKernelGGL(magnitude_and_min, grid_for(N), dim3(256), 0, s, cur, p->minbits, N);
   HIP_TRY(hipGetLastError());
+  if (stage == 1) return dump_real(cur);
   hipLaunchKernelGGL(half_log, grid_for(N), dim3(256), 0, s, cur, p->minbits, N);
   HIP_TRY(hipGetLastError());
   if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, +1, &cur, &oth))) return rc;

@@ -75,6 +75,7 @@ SIGNATURES = {
     "imp_debug_host_spectrum": (C.c_int, [_pd, _i64, C.c_int, _pf]),
     "imp_plan_debug_run_stage": (C.c_int, [_vp, _pf, _i64, _i64, C.c_int, _pf]),
     "imp_minphase_fir": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, _pd]),
+    "imp_debug_minphase_stage": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, C.c_int, _pd]),
     "imp_peak_index": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
     "imp_peak_index_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
     "imp_apply_window": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.POINTER(WindowParams)]),
@@ -225,6 +226,15 @@ class Context:
         _check(self._lib.imp_minphase_fir(self._h, g.ctypes.data_as(_pd), g.shape[0], g.shape[1], float(fs),
                                           out.ctypes.data_as(_pd)))
         return out[0] if one else out
+
+    def minphase_debug_stage(self, gain, fs, stage):
+        g = np.ascontiguousarray(gain, dtype=np.float64)
+        if g.ndim == 1:
+            g = g[None, :]
+        out = np.empty((g.shape[0], 2 * g.shape[1]), dtype=np.float64)
+        _check(self._lib.imp_debug_minphase_stage(self._h, g.ctypes.data_as(_pd), g.shape[0], g.shape[1], float(fs),
+                                                  int(stage), out.ctypes.data_as(_pd)))
+        return out
 
     def apply_window(self, rows, params):
         """In-place-style windowing of a list of rows; returns new float32 arrays."""

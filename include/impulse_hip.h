@@ -140,6 +140,9 @@ int imp_peak_index_device(imp_ctx* ctx, const float* d_x, const int64_t* off, co
  * fir_out: host [B][n].  2n must factor into 2, 3 and 5 (n comes from next_fast_len).  fs must be even
  * (the grid ends at fs//2 and firwin2 requires it to end at fs/2). */
 int imp_minphase_fir(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, double* fir_out);
+/* debug: intermediates of the design. stage 0: out[B][2n] = firwin2 taps; stage 1: |FFT_2n(taps)| */
+int imp_debug_minphase_stage(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, int stage,
+                             double* out);
 
 /* ---- K4/K8: in-place gain, fades, decay window (elementwise) ---------------------------------
  * core/hrir.py:530-544 (gain), :591-612 (Hann fade-in), :642-651 (crop + Hann fade-out),
