@@ -93,3 +93,29 @@ class ImpulseResponse(_PlotBase):
 
     def magnitude_response(self):
         return magnitude_response(self.data, self.fs)
+
+    def frequency_response(self):
+        """Magnitude response decimated to ~4 Hz steps and re-sampled on the 1 % log grid from 10 Hz
+        to fs/2 (reference :157-188)."""
+        from .frequency_response import FrequencyResponse, generate_frequencies
+
+        def flat(label):
+            f = generate_frequencies(f_step=1.01, f_min=10, f_max=self.fs / 2)
+            return FrequencyResponse(name=label, frequency=f, raw=np.zeros_like(f))
+
+        if len(self.data) < 2:
+            return flat("Frequency response (short IR)")
+        f, m = self.magnitude_response()
+        if len(f) == 0:
+            return flat("Frequency response (empty FFT)")
+        wanted = (self.fs / 2) / 4.0
+        step = 1 if (wanted < 2 or len(f) < 2) else (int(round(len(f) / wanted)) or 1)
+        if len(f[1::step]) == 0:
+            if len(f[1:]) == 0:
+                return flat("Frequency response (FFT too short)")
+            frequency, raw = f[1:], m[1:]
+        else:
+            frequency, raw = f[1::step], m[1::step]
+        fr = FrequencyResponse(name="Frequency response", frequency=frequency, raw=raw)
+        fr.interpolate(f_step=1.01, f_min=10, f_max=self.fs / 2)
+        return fr

@@ -16,3 +16,57 @@ def process_decay_worker(args):
     adjusted = ir_data.copy()
     apply_decay_window(adjusted, decay_adjustment_params(adjusted, fs, target))
     return (speaker, side, adjusted)
+
+
+_EQUALIZATION_CONTEXT = None
+
+
+def init_equalization_worker(room_frs, hp_left, hp_right, eq_left, eq_right, target, common_freq, estimator_fs):
+    """Install the shared equalisation inputs once per worker (reference :45-66)."""
+    global _EQUALIZATION_CONTEXT
+    _EQUALIZATION_CONTEXT = (room_frs, hp_left, hp_right, eq_left, eq_right, target, common_freq, estimator_fs)
+
+
+def equalization_curve(speaker, side, room_frs, hp_left, hp_right, eq_left, eq_right, target, common_freq,
+                       estimator_fs):
+    """FrequencyResponse whose ``equalization`` is the curve the FIR must realise for one speaker-ear
+    channel: error = room + headphone + user EQ - target, smoothed heavy/light, inverted with a
+    40 dB gain limit (6 dB above 10 kHz) - reference :98-126."""
+    from .frequency_response import FrequencyResponse
+    fr = FrequencyResponse(name=f'{speaker}-{side} eq', frequency=common_freq.copy(), raw=0, error=0)
+    if room_frs is not None and speaker in room_frs and side in room_frs[speaker]:
+        fr.error += room_frs[speaker][side].error
+    hp = hp_left if side == 'left' else hp_right
+    if hp is not None:
+        fr.error += hp.error
+    eq = eq_left if side == 'left' else eq_right
+    if eq is not None and isinstance(eq, FrequencyResponse):
+        fr.error += eq.error
+    fr.error -= target.raw
+    fr.smoothen_heavy_light()
+    fr.equalize(max_gain=40, treble_f_lower=10000, treble_f_upper=estimator_fs / 2)
+    return fr
+
+
+def process_equalization_worker(args):
+    """(speaker, side[, context...]) -> (speaker, side, minimum-phase FIR); the FIR is designed on the GPU."""
+    if len(args) == 2:
+        if _EQUALIZATION_CONTEXT is None:
+            raise RuntimeError("Equalization worker context was not initialized.")
+        speaker, side = args
+        ctx = _EQUALIZATION_CONTEXT
+    else:
+        speaker, side, ctx = args[0], args[1], tuple(args[2:])
+    fr = equalization_curve(speaker, side, *ctx)
+    return (speaker, side, fr.minimum_phase_impulse_response(fs=ctx[-1], normalize=False, f_res=5))
+
+
+def process_equalization_batch(tasks, room_frs, hp_left, hp_right, eq_left, eq_right, target, common_freq,
+                               estimator_fs):
+    """All (speaker, side) FIRs of a measurement in ONE device launch chain - what replaces the
+    reference's process pool over channels (core/pipeline.py:668-688)."""
+    from .frequency_response import minimum_phase_impulse_responses
+    curves = [equalization_curve(sp, sd, room_frs, hp_left, hp_right, eq_left, eq_right, target, common_freq,
+                                 estimator_fs).equalization for sp, sd in tasks]
+    firs = minimum_phase_impulse_responses(common_freq, curves, estimator_fs, f_res=5, normalize=False)
+    return [(sp, sd, fir) for (sp, sd), fir in zip(tasks, firs)]

@@ -1,0 +1,59 @@
+"""The hot-path slice of the reference's BRIR pipeline, as one function.
+
+Counterpart of the stages `_stage_open_measurements` (core/pipeline.py:565-573),
+`_stage_crop_and_align` (:585-601, cropping part), `_stage_equalize` (:647-692), `_stage_decay`
+(:694-716) and `_stage_normalize` (:725-735).  Orchestration, file discovery, plotting and report
+writing of the full pipeline are out of scope; this harness exists so the stage sequence can be
+parity-checked end to end and benchmarked.
+"""
+import numpy as np
+
+from .frequency_response import FrequencyResponse
+from .hrir import HRIR
+from .parallel_workers import process_decay_worker, process_equalization_batch
+
+
+def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, decay=None, peak_target=-0.1,
+              hp_left=None, hp_right=None, eq_left=None, eq_right=None, stages=None):
+    """recordings: list of (path_or_(fs, array), speakers[, side]) measurement files.
+    Returns the HRIR after: ingest (batched GPU deconvolution) -> crop_heads -> crop_tails ->
+    per-channel minimum-phase FIR (batched GPU design) + equalize -> optional decay adjustment ->
+    normalize.  ``stages`` (dict) receives copies of the intermediate channel data when given."""
+    hrir = HRIR(estimator)
+    for rec in recordings:
+        src, speakers = rec[0], rec[1]
+        side = rec[2] if len(rec) > 2 else None
+        if isinstance(src, str):
+            hrir.open_recording(src, speakers, side=side)
+        else:
+            hrir.open_recording_data(src[0], src[1], speakers, side=side)
+
+    def snap(name):
+        if stages is not None:
+            stages[name] = {(sp, sd): ir.data.copy() for sp, pair in hrir.irs.items() for sd, ir in pair.items()}
+
+    snap("ingest")
+    hrir.crop_heads(head_ms=head_ms)
+    snap("crop_heads")
+    hrir.crop_tails()
+    snap("crop_tails")
+
+    fs = estimator.fs
+    common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
+    if target is None:
+        target = FrequencyResponse(name="target", frequency=common.copy(), raw=0)
+    tasks = [(sp, sd) for sp, pair in hrir.irs.items() for sd in pair]
+    for sp, sd, fir in process_equalization_batch(tasks, room_frs, hp_left, hp_right, eq_left, eq_right, target,
+                                                  common, fs):
+        hrir.irs[sp][sd].equalize(fir)
+    snap("equalize")
+
+    if decay is not None:
+        for sp, pair in hrir.irs.items():
+            for sd, ir in pair.items():
+                _, _, ir.data = process_decay_worker((sp, sd, ir.data, fs, decay[sp] if isinstance(decay, dict) else decay))
+        snap("decay")
+
+    gain = hrir.normalize(peak_target=peak_target)
+    snap("normalize")
+    return hrir, gain

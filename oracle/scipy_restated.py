@@ -153,3 +153,48 @@ def spline1_eval(xk, yk, xq):
     x0, x1 = xk[idx], xk[idx + 1]
     t = (xq - x0) / (x1 - x0)
     return yk[idx] + t * (yk[idx + 1] - yk[idx])
+
+
+def _bspline_basis_all(t, k, x):
+    """All B-spline basis functions of degree k on knot vector t evaluated at x (Cox-de Boor).
+    Returns [len(x), len(t) - k - 1]."""
+    t = np.asarray(t, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    n = len(t) - k - 1
+    # degree 0: indicator of [t_i, t_{i+1}), with the last non-empty interval closed on the right
+    B = np.zeros((len(x), len(t) - 1))
+    last = np.max(np.nonzero(t[1:] > t[:-1])[0])
+    for i in range(len(t) - 1):
+        if t[i + 1] > t[i]:
+            if i == last:
+                B[:, i] = (x >= t[i]) & (x <= t[i + 1])
+            else:
+                B[:, i] = (x >= t[i]) & (x < t[i + 1])
+    for d in range(1, k + 1):
+        Bn = np.zeros((len(x), len(t) - 1 - d))
+        for i in range(len(t) - 1 - d):
+            left = t[i + d] - t[i]
+            right = t[i + d + 1] - t[i + 1]
+            term = 0.0
+            if left > 0:
+                term = term + (x - t[i]) / left * B[:, i]
+            if right > 0:
+                term = term + (t[i + d + 1] - x) / right * B[:, i + 1]
+            Bn[:, i] = term
+        B = Bn
+    return B[:, :n]
+
+
+def spline2_interp(xk, yk, xq):
+    """InterpolatedUnivariateSpline(xk, yk, k=2)(xq): FITPACK's interpolating quadratic spline
+    (fpcurf, s = 0): boundary knots of multiplicity 3 and interior knots at the midpoints
+    (x[i+1] + x[i+2]) / 2, i = 0..m-4; coefficients from the collocation system; points outside
+    [x0, x_{m-1}] are extrapolated with the end polynomial pieces."""
+    xk = np.asarray(xk, dtype=np.float64)
+    yk = np.asarray(yk, dtype=np.float64)
+    xq = np.asarray(xq, dtype=np.float64)
+    m = len(xk)
+    interior = (xk[1:m - 2] + xk[2:m - 1]) / 2.0
+    t = np.concatenate([[xk[0]] * 3, interior, [xk[-1]] * 3])
+    coef = np.linalg.solve(_bspline_basis_all(t, 2, xk), yk)
+    return _bspline_basis_all(t, 2, np.clip(xq, xk[0], xk[-1])) @ coef

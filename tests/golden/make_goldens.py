@@ -330,6 +330,83 @@ def main():
             mp[f"fs{fs}_{name}_fir"] = fir
     np.savez_compressed(os.path.join(OUT, "minphase.npz"), **mp)
 
+    # ------------------------------------------------------------------ 9. room correction + EQ worker on the real FC-left IR
+    from core.parallel_workers import init_equalization_worker, process_equalization_worker
+    from core.room_correction import (_open_mic_calibration, _open_room_target, calculate_specific_room_corrections,
+                                      discover_room_measurements)
+    from scipy.signal.windows import hann as _hann
+    fs = 48000                                   # (section 8 reused the name)
+    disc = discover_room_measurements(demo)
+    target = _open_room_target(e5, demo, None, disc)
+    mic = _open_mic_calibration(e5, demo, None, disc)
+    n_out = resp.shape[0]
+    fo = 2 * int(fs * (len(e5) / fs / e5.n_octaves) * (1 / 24))
+    d = r["cropped_head"].copy()
+    d[n_out - fo // 2:] *= _hann(fo)[fo // 2:]
+    rc = {"target_csv": np.frombuffer(open(os.path.join(demo, "room-target.csv"), "rb").read(), dtype=np.uint8),
+          "mic_txt": np.frombuffer(open(os.path.join(demo, "room-mic-calibration.txt"), "rb").read(), dtype=np.uint8),
+          "target_raw": target.raw.copy(), "mic_raw": mic.raw.copy(), "frequency": target.frequency.copy()}
+    rir = HRIR(e5)
+    rir.irs = {"FC": {"left": ImpulseResponse(d.copy(), fs)}}
+    rc["fr_raw_initial"] = rir.irs["FC"]["left"].frequency_response().raw.copy()
+    frs = calculate_specific_room_corrections(rir, target, mic_calibration=mic, limit=400)
+    fr = frs["FC"]["left"]
+    rc["fr_raw"], rc["fr_error"], rc["fr_target"] = fr.raw.copy(), fr.error.copy(), fr.target.copy()
+    common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
+    flat = FrequencyResponse(name="t", frequency=common.copy(), raw=0)
+    init_equalization_worker(frs, None, None, None, None, flat, common, fs)
+    _, _, fir = process_equalization_worker(("FC", "left"))
+    rc["worker_fir"] = fir
+    ir = ImpulseResponse(d.copy(), fs)
+    ir.equalize(fir)
+    rc["equalized_dec"] = decim(ir.data, 5)
+    rc["equalized_len"] = len(ir.data)
+    np.savez_compressed(os.path.join(OUT, "room_fc.npz"), **rc)
+
+    # ------------------------------------------------------------------ 10. pipeline slice (a18): synthetic FL,FR folder
+    import tempfile
+    e1 = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+    N1s, fs1 = len(e1), 48000
+    specs = ((0, 1.0), (12, 0.6), (12, 0.6), (0, 0.9))            # FL-L, FL-R, FR-L, FR-R (tests/test_pipeline_direct.py:190-195)
+    total = 2 * fs1 + N1s + 2 * fs1
+    tracks = np.zeros((4, total))
+    for t_i, (delay, gain) in enumerate(specs):
+        tracks[t_i, 2 * fs1 + delay: 2 * fs1 + delay + N1s] = gain * 0.5 * e1.test_signal
+    pcm = np.rint(tracks * 2 ** 31).astype(np.int32)
+    sl = {"pcm_specs": np.array(specs), "N": N1s}
+    with tempfile.TemporaryDirectory() as tmp:
+        wav = os.path.join(tmp, "FL,FR.wav")
+        wavfile.write(wav, fs1, pcm.T)
+        h = HRIR(e1)
+        h.open_recording(wav, ["FL", "FR"])
+    order = [("FL", "left"), ("FL", "right"), ("FR", "left"), ("FR", "right")]
+    sl["ingest_peaks"] = np.array([h.irs[sp][sd].peak_index() for sp, sd in order])
+    sl["ingest_len"] = len(h.irs["FL"]["left"].data)
+    h.crop_heads(head_ms=1)
+    sl["heads_len"] = np.array([len(h.irs[sp][sd].data) for sp, sd in order])
+    for (sp, sd) in order:
+        sl[f"heads_{sp}_{sd}"] = h.irs[sp][sd].data[:512].copy()
+    sl["tail_ind"] = int(h.crop_tails())
+    for (sp, sd) in order:
+        sl[f"tails_{sp}_{sd}"] = decim(h.irs[sp][sd].data, 3)
+    common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs1 / 2, f_step=1.01)
+    room = {sp: {sd: FrequencyResponse(name="r", frequency=common.copy(), raw=0,
+                                       error=2.0 * np.sin(2.5 * np.log10(common) + 0.7 * k))
+                 for k, sd in enumerate(("left", "right"), start=2 * j)}
+            for j, sp in enumerate(("FL", "FR"))}
+    flat = FrequencyResponse(name="t", frequency=common.copy(), raw=0)
+    init_equalization_worker(room, None, None, None, None, flat, common, fs1)
+    for (sp, sd) in order:
+        sl[f"room_error_{sp}_{sd}"] = room[sp][sd].error.copy()
+        _, _, fir = process_equalization_worker((sp, sd))
+        sl[f"fir_{sp}_{sd}"] = fir
+        h.irs[sp][sd].equalize(fir)
+    sl["eq_len"] = len(h.irs["FL"]["left"].data)
+    sl["norm_gain_db"] = float(h.normalize(peak_target=-0.1))
+    for (sp, sd) in order:
+        sl[f"final_{sp}_{sd}"] = h.irs[sp][sd].data.copy()
+    np.savez_compressed(os.path.join(OUT, "pipeline_slice.npz"), **sl)
+
     for fn in sorted(os.listdir(OUT)):
         if fn.endswith(".npz"):
             print(f"{fn:24s} {os.path.getsize(os.path.join(OUT, fn)) / 1024:9.1f} KiB")

@@ -518,3 +518,96 @@ def test_minimum_phase_fir_then_equalize_chain(gpu_ctx, golden):
     assert len(ir.data) == 33600 + 9600 - 1
     assert rel(ir.data, ref) <= TIME_TOL and spec_rel(ir.data, ref) <= SPEC_TOL
     assert rel(ir.data, fft_convolve(data, ofir, "full")) <= TIME_TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# a13/a14/a18: room correction, EQ worker and the pipeline slice through the product classes
+# ------------------------------------------------------------------------------------------------
+def test_room_correction_and_worker_real_column(gpu_ctx, golden):
+    """Real FC-left column: GPU estimate -> crop -> frequency_response -> mic calibration / target /
+    400 Hz limit -> EQ worker (curve on host, FIR on GPU) -> equalize (GPU), against the reference."""
+    from impulse_hip.frequency_response import FrequencyResponse
+    from impulse_hip.hrir import _hann
+    from impulse_hip.impulse_response import ImpulseResponse
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.parallel_workers import init_equalization_worker, process_equalization_worker
+    from impulse_hip.room_correction import calculate_specific_room_corrections
+    g, d = golden("room_fc"), golden("demo_fc")
+    N, P, n_out = int(d["N"]), float(d["P"]), int(d["responses_len"])
+    e = ImpulseResponseEstimator(min_duration=(N - 1) / 48000, fs=48000)
+    ir = ImpulseResponse(e.estimate((d["column_i32"].astype(np.float64) / 2 ** 31).astype(np.float32)), 48000)
+    ir.crop_head()
+    fo = 2 * int(48000 * (N / 48000 / P) * (1 / 24))
+    ir.data = ir.data[:n_out].copy()
+    ir.data[n_out - fo // 2:] *= _hann(fo)[fo // 2:]
+    freq = g["frequency"]
+    target = FrequencyResponse("room-target", frequency=freq.copy(), raw=g["target_raw"])
+    mic = FrequencyResponse("mic", frequency=freq.copy(), raw=g["mic_raw"])
+
+    class Rir:
+        irs = {"FC": {"left": ir}}
+
+    frs = calculate_specific_room_corrections(Rir, target, mic_calibration=mic, limit=400)
+    fr = frs["FC"]["left"]
+    # dB curves from an fp32 IR: 1e-6 of the spectrum peak is ~1e-3 dB on bins 40 dB below it
+    assert np.max(np.abs(fr.raw - g["fr_raw"])) < 5e-3
+    assert np.max(np.abs(fr.error - g["fr_error"])) < 5e-3
+    assert np.all(fr.error[freq > 400] == 0.0)                      # limit mask
+    common = FrequencyResponse.generate_frequencies(f_min=10, f_max=24000, f_step=1.01)
+    init_equalization_worker(frs, None, None, None, None, FrequencyResponse("t", frequency=common.copy(), raw=0),
+                             common, 48000)
+    sp, sd, fir = process_equalization_worker(("FC", "left"))
+    want = g["worker_fir"]
+    assert (sp, sd) == ("FC", "left") and fir.shape == want.shape
+    # taps are a very sensitive function of the curve (see tests/test_oracle_golden.py): compare responses
+    Hg, Hw = np.fft.rfft(fir, 4 * len(fir)), np.fft.rfft(want, 4 * len(want))
+    f = np.fft.rfftfreq(4 * len(fir), 1 / 48000)
+    sel = f < 20000
+    assert np.max(np.abs(20 * np.log10(np.abs(Hg[sel]) / np.abs(Hw[sel])))) < 0.02
+    assert np.max(np.abs(fir - want)) <= 1e-3 * np.max(np.abs(want))
+
+
+def test_pipeline_slice_product(gpu_ctx, golden, tmp_path):
+    """a18 end to end through the product: WAV -> HRIR.open_recording (batched GPU deconvolution) ->
+    crop_heads -> crop_tails -> batched FIR design + equalize -> normalize, stage by stage against the
+    reference's own run of the same synthetic FL,FR folder."""
+    from impulse_hip.audio_io import write_wav
+    from impulse_hip.frequency_response import FrequencyResponse
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.pipeline_slice import run_slice
+    g = golden("pipeline_slice")
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+    N, fs = len(e), 48000
+    tracks = np.zeros((4, 2 * fs + N + 2 * fs))
+    for t_i, (delay, gain) in enumerate(g["pcm_specs"]):
+        delay = int(delay)
+        tracks[t_i, 2 * fs + delay: 2 * fs + delay + N] = gain * 0.5 * e.test_signal
+    path = str(tmp_path / "FL,FR.wav")
+    write_wav(path, fs, tracks, bit_depth=32)
+    order = [("FL", "left"), ("FL", "right"), ("FR", "left"), ("FR", "right")]
+    common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
+    room = {sp: {} for sp in ("FL", "FR")}
+    for sp, sd in order:
+        room[sp][sd] = FrequencyResponse("r", frequency=common.copy(), raw=0, error=g[f"room_error_{sp}_{sd}"])
+    stages = {}
+    hrir, gain = run_slice(e, [(path, ["FL", "FR"])], room_frs=room, stages=stages)
+    assert list(hrir.irs) == ["FL", "FR"]
+    from impulse_hip.impulse_response import ImpulseResponse
+    assert [ImpulseResponse(stages["ingest"][k], fs).peak_index() for k in order] == list(g["ingest_peaks"])
+    assert len(stages["ingest"][order[0]]) == int(g["ingest_len"])
+    assert [len(stages["crop_heads"][k]) for k in order] == list(g["heads_len"])
+    for k in order:
+        want = g[f"heads_{k[0]}_{k[1]}"]
+        assert np.max(np.abs(stages["crop_heads"][k][:512] - want)) <= TIME_TOL * 0.5     # IR peak ~0.5
+    assert len(stages["crop_tails"][order[0]]) == int(g["tail_ind"])
+    for k in order:
+        want = g[f"tails_{k[0]}_{k[1]}"]
+        assert np.max(np.abs(stages["crop_tails"][k][::3] - want)) <= TIME_TOL * np.max(np.abs(want))
+    assert len(stages["equalize"][order[0]]) == int(g["eq_len"])
+    assert gain == pytest.approx(float(g["norm_gain_db"]), abs=1e-4)
+    for k in order:
+        want = g[f"final_{k[0]}_{k[1]}"]
+        got = hrir.irs[k[0]][k[1]].data
+        assert got.shape == want.shape
+        assert rel(got, want) <= 2e-6                     # fp32 IR through an fp32 FIR convolution and a gain
+        assert spec_rel(got, want) <= 2e-6

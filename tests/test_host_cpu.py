@@ -268,3 +268,60 @@ print("rank", rank, "ok")
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_product_curve_logic_matches_reference(golden, tmp_path):
+    """Host-side FrequencyResponse of the product (CSV parsing, interpolate, center, compensate,
+    smoothing, equalize incl. the clipped branch, limit mask) against the reference's outputs."""
+    from impulse_hip.frequency_response import FrequencyResponse
+    from impulse_hip.impulse_response import ImpulseResponse
+    from impulse_hip.parallel_workers import equalization_curve
+    from impulse_hip.room_correction import (calculate_specific_room_corrections, discover_room_measurements,
+                                             open_mic_calibration, open_room_target)
+    g, d, mp = golden("room_fc"), golden("demo_fc"), golden("minphase")
+
+    class Est:
+        fs = 48000
+
+    (tmp_path / "room-target.csv").write_bytes(g["target_csv"].tobytes())
+    (tmp_path / "room-mic-calibration.txt").write_bytes(g["mic_txt"].tobytes())
+    for nm in ("room-FL,FR-left.wav", "room-FC-right.wav", "room-XX.wav", "room.wav", "roomFL.wav", "room-fl-left.wav"):
+        (tmp_path / nm).write_bytes(b"")
+    disc = discover_room_measurements(str(tmp_path))
+    got = {(os.path.basename(m.file_path), m.speakers, m.side) for m in disc.measurements}
+    assert got == {("room-FL,FR-left.wav", ("FL", "FR"), "left"), ("room-FC-right.wav", ("FC",), "right"),
+                   ("room-XX.wav", ("XX",), None)}
+    assert disc.generic_path.endswith("room.wav") and disc.target_path.endswith("room-target.csv")
+    assert disc.mic_calibration_path.endswith("room-mic-calibration.txt")
+    target = open_room_target(Est(), str(tmp_path))
+    mic = open_mic_calibration(Est(), str(tmp_path))
+    np.testing.assert_array_equal(target.frequency, g["frequency"])
+    np.testing.assert_allclose(target.raw, g["target_raw"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(mic.raw, g["mic_raw"], rtol=0, atol=1e-12)
+    with pytest.raises(FileNotFoundError):
+        open_mic_calibration(Est(), str(tmp_path), str(tmp_path / "nope.txt"))
+
+    N, P, n_out = int(d["N"]), float(d["P"]), int(d["responses_len"])
+    fo = 2 * int(48000 * (N / 48000 / P) * (1 / 24))
+    data = d["cropped_head"].copy()
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(fo) / (fo - 1))
+    data[n_out - fo // 2:] *= w[fo // 2:]
+
+    class Rir:
+        irs = {"FC": {"left": ImpulseResponse(data, 48000)}}
+
+    np.testing.assert_allclose(Rir.irs["FC"]["left"].frequency_response().raw, g["fr_raw_initial"], rtol=0, atol=1e-10)
+    frs = calculate_specific_room_corrections(Rir, target, mic_calibration=mic, limit=400)
+    fr = frs["FC"]["left"]
+    np.testing.assert_allclose(fr.raw, g["fr_raw"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(fr.error, g["fr_error"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(fr.target, g["fr_target"], rtol=0, atol=1e-10)
+    for fs in (48000, 96000):
+        freq = mp[f"fs{fs}_freq"]
+        flat = FrequencyResponse("t", frequency=freq.copy(), raw=0)
+        for nm in ("flat", "wavy", "tilt"):
+            room = {"FL": {"left": FrequencyResponse("r", frequency=freq.copy(), raw=0, error=mp[f"fs{fs}_{nm}_error"])}}
+            cur = equalization_curve("FL", "left", room, None, None, None, None, flat, freq, fs)
+            np.testing.assert_allclose(cur.equalization, mp[f"fs{fs}_{nm}_eq"], rtol=0, atol=1e-12)
+    with pytest.raises(ValueError):
+        FrequencyResponse("dup", frequency=[10, 20, 20], raw=[0, 0, 0])
