@@ -6,6 +6,7 @@ loaded, or no gfx950 device is present, every compute entry point raises ``Nativ
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -147,6 +148,7 @@ class Context:
         self._lib = lib
         self._h = h
         self.device = int(device)
+        self._plans = weakref.WeakSet()       # plans hold a raw pointer to this context: they go first
 
     @property
     def handle(self):
@@ -179,6 +181,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
+            for plan in list(getattr(self, "_plans", ())):
+                plan.close()
             self._lib.imp_ctx_destroy(self._h)
             self._h = None
 
@@ -274,6 +278,7 @@ class ConvPlan:
             _check(self._lib.imp_conv_plan_create(ctx.handle, f.ctypes.data_as(_pd), self.M, self.n_filters,
                                                   self.M, self.L, self.mode, int(ws_channels), C.byref(h)))
         self._h = h
+        ctx._plans.add(self)
         nfft, out_len, wsc, n1 = _i64(), _i64(), _i64(), _i64()
         _check(self._lib.imp_plan_info(self._h, C.byref(nfft), C.byref(out_len), C.byref(wsc), C.byref(n1)))
         self.nfft, self.out_len, self.ws_channels, self.n1 = nfft.value, out_len.value, wsc.value, n1.value

@@ -4,7 +4,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "impulcifer-pip313_amd"), os.path.join(ROOT, "tests", "model")):
+for p in (ROOT, os.path.join(ROOT, "impulcifer-pip313_amd"), os.path.join(ROOT, "tests", "model"),
+          os.path.join(ROOT, "tests", "golden")):
     if p not in sys.path:
         sys.path.insert(0, p)
 

@@ -367,12 +367,10 @@ def main():
     import tempfile
     e1 = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
     N1s, fs1 = len(e1), 48000
-    specs = ((0, 1.0), (12, 0.6), (12, 0.6), (0, 0.9))            # FL-L, FL-R, FR-L, FR-R (tests/test_pipeline_direct.py:190-195)
-    total = 2 * fs1 + N1s + 2 * fs1
-    tracks = np.zeros((4, total))
-    for t_i, (delay, gain) in enumerate(specs):
-        tracks[t_i, 2 * fs1 + delay: 2 * fs1 + delay + N1s] = gain * 0.5 * e1.test_signal
-    pcm = np.rint(tracks * 2 ** 31).astype(np.int32)
+    sys.path.insert(0, OUT)
+    import slice_input
+    pcm = slice_input.to_pcm32(slice_input.make_tracks(e1.test_signal, fs1))
+    specs = slice_input.SPECS
     sl = {"pcm_specs": np.array(specs), "N": N1s}
     with tempfile.TemporaryDirectory() as tmp:
         wav = os.path.join(tmp, "FL,FR.wav")

@@ -578,10 +578,8 @@ def test_pipeline_slice_product(gpu_ctx, golden, tmp_path):
     g = golden("pipeline_slice")
     e = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
     N, fs = len(e), 48000
-    tracks = np.zeros((4, 2 * fs + N + 2 * fs))
-    for t_i, (delay, gain) in enumerate(g["pcm_specs"]):
-        delay = int(delay)
-        tracks[t_i, 2 * fs + delay: 2 * fs + delay + N] = gain * 0.5 * e.test_signal
+    import slice_input                                   # tests/golden/slice_input.py (inputs only)
+    tracks = slice_input.make_tracks(e.test_signal, fs)
     path = str(tmp_path / "FL,FR.wav")
     write_wav(path, fs, tracks, bit_depth=32)
     order = [("FL", "left"), ("FL", "right"), ("FR", "left"), ("FR", "right")]
