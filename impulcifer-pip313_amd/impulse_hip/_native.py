@@ -3,6 +3,7 @@
 The HIP library is the product path: there is NO CPU fallback.  If the shared object cannot be
 loaded, or no gfx950 device is present, every compute entry point raises ``NativeUnavailable``.
 """
+import atexit
 import ctypes as C
 import os
 import threading
@@ -84,6 +85,20 @@ SIGNATURES = {
 
 _lib = None
 _lib_lock = threading.Lock()
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _shutdown():
+    """Release every context (and the plans made on it) while the interpreter and the HIP runtime
+    are both still fully alive.  Objects kept alive past this point (e.g. by a traceback) would
+    otherwise reach the HIP runtime's own exit-time teardown with live streams/buffers, which aborts
+    the process (std::bad_variant_access inside libamdhip64 on ROCm 7.2)."""
+    for ctx in list(_live_contexts):
+        try:
+            ctx.close()
+        except Exception:
+            pass
 
 
 def library_path():
@@ -149,6 +164,7 @@ class Context:
         self._h = h
         self.device = int(device)
         self._plans = weakref.WeakSet()       # plans hold a raw pointer to this context: they go first
+        _live_contexts.add(self)
 
     @property
     def handle(self):
@@ -341,7 +357,8 @@ class ConvPlan:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.imp_plan_destroy(self._h)
+            if getattr(self.ctx, "_h", None):          # the context closes its plans before it goes
+                self._lib.imp_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):
