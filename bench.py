@@ -172,12 +172,20 @@ def main():
 
     import torch
     dist = None
+    # IMPULSE_BENCH_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks: ranks are
+    # folded onto the visible devices and the spectrum broadcast is staged through host memory.
+    backend = os.environ.get("IMPULSE_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    device = torch.device("cuda", dev_index)
+    comm_device = device if backend == "nccl" else torch.device("cpu")
 
     from impulse_hip import Context, ConvPlan
     from impulse_hip.sharding import broadcast_plan_spectrum, shard_channels
@@ -198,14 +206,15 @@ def main():
         total_channels = B * world
     M = len(est)
 
-    ctx = Context(local_rank)
+    ctx = Context(dev_index)
     if rank == 0:
         plan = ConvPlan(ctx, np.asarray(est.inverse_filter, dtype=np.float64), L, "same")
     else:
         plan = ConvPlan(ctx, None, L, "same", empty_M=M, n_filters=1)
     bcast_bytes = 0
     if world > 1:
-        bcast_bytes = broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0)   # RCCL over xGMI
+        bcast_bytes = broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0,
+                                              via_host=(backend != "nccl"))   # RCCL over xGMI
 
     # inputs/outputs resident in HBM before the clock starts (torch = device memory plumbing only)
     d_x = torch.from_numpy(rec).to(device)
@@ -233,7 +242,7 @@ def main():
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
@@ -243,6 +252,10 @@ def main():
     # parity gate on what the timed loop produced (outside the timed region)
     y = d_y.cpu().numpy()[:, :L]
     peaks_ok = all(int(np.argmax(np.abs(y[c]))) == M // 2 + delays[c] for c in range(B))
+    if dist is not None:                      # rank 0 reports the verdict of every rank
+        flag = torch.tensor([1 if peaks_ok else 0], dtype=torch.int32, device=comm_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        peaks_ok = bool(flag.item())
 
     result = None
     if rank == 0:
@@ -290,7 +303,8 @@ def main():
                        "(inverse-filter spectrum prepared once, outside the timed region)",
                        "channels_per_gpu_per_step": B, "sweep_samples": M, "column_samples": L,
                        "nfft": plan.nfft, "sharding": f"channels x{world}, no data-path collective; "
-                       f"one RCCL broadcast of {bcast_bytes} B spectrum at plan creation"},
+                       f"one {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} broadcast of "
+                       f"{bcast_bytes} B spectrum at plan creation"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(result))

@@ -28,9 +28,21 @@ def broadcast_bytes(buf, dist, src=0):
     return buf
 
 
-def broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0):
-    """Rank ``src`` sends its plan's prepared spectrum; the others load it into their (empty) plan."""
+def broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0, via_host=False):
+    """Rank ``src`` sends its plan's prepared spectrum; the others load it into their (empty) plan.
+    ``via_host`` stages the bytes through host memory (gloo rehearsal); the default keeps them on the
+    device end to end (RCCL)."""
     dptr, nbytes = plan.spectrum_buffer()
+    if via_host:
+        import numpy as np
+        host = np.empty(nbytes, dtype=np.uint8)
+        if dist.get_rank() == src:
+            ctx.d2h(host, dptr)
+        t = torch.from_numpy(host)
+        dist.broadcast(t, src=src)
+        if dist.get_rank() != src:
+            ctx.h2d(dptr, host)
+        return nbytes
     staging = torch.empty(nbytes, dtype=torch.uint8, device=device)
     if dist.get_rank() == src:
         ctx.d2d(staging.data_ptr(), dptr, nbytes)
