@@ -243,6 +243,25 @@ def test_estimate_batch_c2_full_size_analytic_peaks(gpu_ctx):
     assert np.array_equal(yf, y[:4])
 
 
+def test_estimate_batch_c3_full_size_analytic_peaks(gpu_ctx):
+    """BASELINE config 3: 13 speakers x 2 ears @96 kHz (N = 635 965, column 827 965, circular length
+    1 310 720 = radix-10 columns): analytic peaks, exact."""
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    e = ImpulseResponseEstimator(min_duration=5.0, fs=96000)
+    N, L = len(e), len(e) + 2 * 96000
+    assert (N, L) == (635965, 827965)
+    sweep = e.test_signal.astype(np.float32)
+    rec = np.zeros((26, L), dtype=np.float32)
+    delays = [90 + 53 * c for c in range(26)]
+    for c, d in enumerate(delays):
+        rec[c, d:d + N] += (0.4 + 0.02 * c) * sweep
+    y = e.estimate_batch(rec, dtype=np.float32)
+    assert y.shape == (26, L)
+    for c, d in enumerate(delays):
+        assert int(np.argmax(np.abs(y[c]))) == N // 2 + d
+    assert np.array_equal(y[17], e.estimate(rec[17]).astype(np.float32))
+
+
 # ------------------------------------------------------------------------------------------------
 # K3 peak index, K4/K8 windows, decay, container ops - against goldens from the reference
 # ------------------------------------------------------------------------------------------------
