@@ -9,6 +9,7 @@
 #include <complex>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -477,8 +478,11 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   const int64_t need = (mode == IMP_MODE_SAME) ? std::max(L + M / 2, M) : full;
   static const int kR2[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};      // N1 = 16*R2 rows of 4096
   int r2 = 0;
+  const bool pow2_only = std::getenv("IMPULSE_HIP_POW2_ONLY") != nullptr;     // debug/experiments
+  const bool no_wrap = std::getenv("IMPULSE_HIP_NO_WRAP") != nullptr;
+  const int64_t need_eff = no_wrap ? full : need;
   for (int cand : kR2)
-    if ((int64_t)cand * 2 * 16 * imp::kN2 >= need) {
+    if ((!pow2_only || (cand & (cand - 1)) == 0) && (int64_t)cand * 2 * 16 * imp::kN2 >= need_eff) {
       r2 = cand;
       break;
     }
