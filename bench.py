@@ -158,6 +158,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ws-channels", type=int, default=0, help="channels per launch group (0 = library default)")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--event-stride", type=int, default=8,
                     help="bracket the three passes of every n-th step with HIP events (sampling keeps the "
@@ -208,9 +209,9 @@ def main():
 
     ctx = Context(dev_index)
     if rank == 0:
-        plan = ConvPlan(ctx, np.asarray(est.inverse_filter, dtype=np.float64), L, "same")
+        plan = ConvPlan(ctx, np.asarray(est.inverse_filter, dtype=np.float64), L, "same", ws_channels=args.ws_channels)
     else:
-        plan = ConvPlan(ctx, None, L, "same", empty_M=M, n_filters=1)
+        plan = ConvPlan(ctx, None, L, "same", ws_channels=args.ws_channels, empty_M=M, n_filters=1)
     bcast_bytes = 0
     if world > 1:
         bcast_bytes = broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0,

@@ -47,7 +47,10 @@ struct imp_ctx {
   size_t scratch_bytes = 0;
   // K6 plans keyed by (taps n, fs)
   std::map<std::pair<long long, long long>, MinPhasePlan*> minphase_plans;
+  // K2 plans keyed by row length n
+  std::map<long long, struct MagPlan*> magnitude_plans;
 };
 
 int ctx_bind(imp_ctx* ctx);
 void minphase_plans_destroy(imp_ctx* ctx);
+void magnitude_plans_destroy(imp_ctx* ctx);

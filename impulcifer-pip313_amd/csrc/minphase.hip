@@ -19,6 +19,7 @@
 // (radix 4/2/3/5, generic O(R^2) butterflies with exact table twiddles), ping-ponging two global
 // buffers, and a few elementwise kernels.  HBM-bound streaming passes; no LDS, no MFMA.
 #include <cmath>
+#include <new>
 #include <utility>
 
 #include "internal.h"
@@ -173,6 +174,37 @@ __global__ __launch_bounds__(256) void take_real(const cdbl* __restrict__ c, dou
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= ntaps) return;
   out[(long long)blockIdx.y * ntaps + k] = c[(long long)blockIdx.y * N + k].x / (double)N;
+}
+
+// ---- K2: arbitrary-length DFT by Bluestein's chirp-z identity --------------------------------
+// a[m] = x[m] c[m] (zero padded to Mfft), c[m] = exp(-i pi m^2 / n)
+__global__ __launch_bounds__(256) void bluestein_pre(const double* __restrict__ x, const cdbl* __restrict__ chirp,
+                                                     cdbl* __restrict__ a, int n, int mfft) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= mfft) return;
+  cdbl v = make_double2(0.0, 0.0);
+  if (m < n) {
+    const double xv = x[(long long)blockIdx.y * n + m];
+    const cdbl c = chirp[m];
+    v = make_double2(xv * c.x, xv * c.y);
+  }
+  a[(long long)blockIdx.y * mfft + m] = v;
+}
+
+__global__ __launch_bounds__(256) void pointwise_mul(cdbl* __restrict__ a, const cdbl* __restrict__ b, int mfft) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= mfft) return;
+  cdbl* p = a + (long long)blockIdx.y * mfft + m;
+  *p = zmul(*p, b[m]);
+}
+
+// X[k] = c[k] * conv[k] / Mfft ; out = 20 log10 |X[k]| for k < half (no epsilon: -inf for exact zeros)
+__global__ __launch_bounds__(256) void bluestein_post_db(const cdbl* __restrict__ conv, const cdbl* __restrict__ chirp,
+                                                         double* __restrict__ out, int mfft, int half) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= half) return;
+  const cdbl v = zmul(conv[(long long)blockIdx.y * mfft + k], chirp[k]);
+  out[(long long)blockIdx.y * half + k] = 20.0 * log10(hypot(v.x, v.y) / (double)mfft);
 }
 
 std::vector<int> factorise(int n) {
@@ -365,6 +397,117 @@ static int minphase_run(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, 
   hipLaunchKernelGGL(take_real, grid_for(p->n), dim3(256), 0, s, cur, p->out, N, p->n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(fir_out, p->out, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return IMP_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K2: magnitude response of arbitrary-length rows (core/audio_io.py:100-113), fp64 Bluestein
+// ------------------------------------------------------------------------------------------------
+struct MagPlan {
+  int n = 0, mfft = 0;
+  std::vector<int> fac;
+  cdbl *roots = nullptr, *chirp = nullptr, *bhat = nullptr;
+  int64_t cap = 0;
+  cdbl *a = nullptr, *b = nullptr;
+  double *x = nullptr, *out = nullptr;
+};
+
+static std::map<long long, MagPlan*>& mag_plans(imp_ctx* ctx) { return ctx->magnitude_plans; }
+
+static void mag_plan_free(MagPlan* p) {
+  if (!p) return;
+  (void)hipFree(p->roots); (void)hipFree(p->chirp); (void)hipFree(p->bhat);
+  (void)hipFree(p->a); (void)hipFree(p->b); (void)hipFree(p->x); (void)hipFree(p->out);
+  delete p;
+}
+
+void magnitude_plans_destroy(imp_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  auto& m = mag_plans(ctx);
+  for (auto& kv : m) mag_plan_free(kv.second);
+  m.clear();
+}
+
+extern "C" int imp_magnitude_db(imp_ctx* ctx, const double* x, int64_t B, int64_t n, double* db_out) {
+  if (!ctx || (B && n && (!x || !db_out))) return fail(IMP_ERR_INVALID, "imp_magnitude_db: null argument");
+  if (B < 0 || n < 0 || n > (1 << 22)) return fail(IMP_ERR_INVALID, "imp_magnitude_db: bad B or n");
+  if (B == 0 || n == 0) return IMP_OK;
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  const int half = (int)((n + 1) / 2);
+  MagPlan* p = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto& plans = mag_plans(ctx);
+    auto it = plans.find((long long)n);
+    if (it != plans.end()) {
+      p = it->second;
+    } else {
+      p = new (std::nothrow) MagPlan();
+      if (!p) return fail(IMP_ERR_ALLOC, "out of host memory");
+      p->n = (int)n;
+      int mf = 1;
+      while (mf < 2 * (int)n - 1) mf <<= 1;
+      if (mf < 4) mf = 4;
+      p->mfft = mf;
+      p->fac = factorise(mf);
+      // chirp c[m] = exp(-i pi m^2 / n), phase reduced exactly: m^2 mod 2n
+      std::vector<cdbl> c((size_t)n), bb((size_t)mf, make_double2(0.0, 0.0));
+      for (int64_t m = 0; m < n; ++m) {
+        const double ang = -M_PI * (double)((m * m) % (2 * n)) / (double)n;
+        c[(size_t)m] = make_double2(std::cos(ang), std::sin(ang));
+      }
+      // b[j] = conj(c[|j|]) placed circularly at j mod mfft, j in (-n, n)
+      for (int64_t j = 0; j < n; ++j) {
+        const cdbl v = make_double2(c[(size_t)j].x, -c[(size_t)j].y);
+        bb[(size_t)j] = v;
+        if (j) bb[(size_t)(mf - j)] = v;
+      }
+      hipStream_t s = ctx->stream;
+      bool ok = upload_roots(&p->roots, mf, s) == IMP_OK &&
+                hipMalloc((void**)&p->chirp, (size_t)n * sizeof(cdbl)) == hipSuccess &&
+                hipMalloc((void**)&p->bhat, (size_t)mf * sizeof(cdbl)) == hipSuccess &&
+                hipMalloc((void**)&p->b, (size_t)mf * sizeof(cdbl)) == hipSuccess &&
+                hipMemcpyAsync(p->chirp, c.data(), (size_t)n * sizeof(cdbl), hipMemcpyHostToDevice, s) == hipSuccess &&
+                hipMemcpyAsync(p->bhat, bb.data(), (size_t)mf * sizeof(cdbl), hipMemcpyHostToDevice, s) == hipSuccess;
+      if (ok) {
+        cdbl *cur = p->bhat, *oth = p->b;
+        ok = run_fft(ctx, p->fac, p->roots, mf, 1, -1, &cur, &oth) == IMP_OK && hipStreamSynchronize(s) == hipSuccess;
+        if (ok && cur != p->bhat) std::swap(p->bhat, p->b);       // result may sit in the other buffer
+      }
+      if (p->b) { (void)hipFree(p->b); p->b = nullptr; }
+      if (!ok) {
+        mag_plan_free(p);
+        return fail(IMP_ERR_HIP, "imp_magnitude_db: plan set-up for n = %lld failed", (long long)n);
+      }
+      plans[(long long)n] = p;
+    }
+  }
+  if (p->cap < B) {
+    (void)hipFree(p->a); (void)hipFree(p->b); (void)hipFree(p->x); (void)hipFree(p->out);
+    p->a = p->b = nullptr; p->x = p->out = nullptr; p->cap = 0;
+    if (hipMalloc((void**)&p->a, (size_t)B * p->mfft * sizeof(cdbl)) != hipSuccess ||
+        hipMalloc((void**)&p->b, (size_t)B * p->mfft * sizeof(cdbl)) != hipSuccess ||
+        hipMalloc((void**)&p->x, (size_t)B * n * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->out, (size_t)B * half * sizeof(double)) != hipSuccess)
+      return fail(IMP_ERR_ALLOC, "imp_magnitude_db: device allocation failed");
+    p->cap = B;
+  }
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(p->x, x, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, s));
+  auto grid_for = [&](int count) { return dim3((unsigned)((count + 255) / 256), (unsigned)B); };
+  cdbl *cur = p->a, *oth = p->b;
+  hipLaunchKernelGGL(bluestein_pre, grid_for(p->mfft), dim3(256), 0, s, p->x, p->chirp, cur, p->n, p->mfft);
+  HIP_TRY(hipGetLastError());
+  if ((rc = run_fft(ctx, p->fac, p->roots, p->mfft, B, -1, &cur, &oth))) return rc;
+  hipLaunchKernelGGL(pointwise_mul, grid_for(p->mfft), dim3(256), 0, s, cur, p->bhat, p->mfft);
+  HIP_TRY(hipGetLastError());
+  if ((rc = run_fft(ctx, p->fac, p->roots, p->mfft, B, +1, &cur, &oth))) return rc;
+  hipLaunchKernelGGL(bluestein_post_db, grid_for(half), dim3(256), 0, s, cur, p->chirp, p->out, p->mfft, half);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(db_out, p->out, (size_t)B * half * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return IMP_OK;
 }

@@ -77,6 +77,7 @@ SIGNATURES = {
     "imp_debug_host_spectrum": (C.c_int, [_pd, _i64, C.c_int, _pf]),
     "imp_plan_debug_run_stage": (C.c_int, [_vp, _pf, _i64, _i64, C.c_int, _pf]),
     "imp_minphase_fir": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, _pd]),
+    "imp_magnitude_db": (C.c_int, [_vp, _pd, _i64, _i64, _pd]),
     "imp_debug_minphase_stage": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, C.c_int, _pd]),
     "imp_peak_index": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
     "imp_peak_index_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
@@ -245,6 +246,18 @@ class Context:
         out = np.empty_like(g)
         _check(self._lib.imp_minphase_fir(self._h, g.ctypes.data_as(_pd), g.shape[0], g.shape[1], float(fs),
                                           out.ctypes.data_as(_pd)))
+        return out[0] if one else out
+
+    def magnitude_db(self, x):
+        """20 log10 |rfft(x)| on the first ceil(n/2) bins, batched over rows: [B, n] -> [B, ceil(n/2)] float64."""
+        a = np.ascontiguousarray(x, dtype=np.float64)
+        one = a.ndim == 1
+        if one:
+            a = a[None, :]
+        out = np.empty((a.shape[0], (a.shape[1] + 1) // 2), dtype=np.float64)
+        if out.size:
+            _check(self._lib.imp_magnitude_db(self._h, a.ctypes.data_as(_pd), a.shape[0], a.shape[1],
+                                              out.ctypes.data_as(_pd)))
         return out[0] if one else out
 
     def minphase_debug_stage(self, gain, fs, stage):

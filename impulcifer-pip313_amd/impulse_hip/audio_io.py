@@ -90,17 +90,25 @@ def write_wav(file_path, fs, data, bit_depth=32):
 
 
 def magnitude_response(x, fs):
-    """20 log10 |rfft(x)| on the first ceil(n/2) bins (reference core/audio_io.py:100-113).
-
-    HOST analysis in float64 for now: arbitrary-length DFTs (K2) are not on the device yet; this
-    is part of the container-level bookkeeping (normalisation gain, FR curves), not of the batched
-    deconvolution path."""
+    """20 log10 |rfft(x)| on the first ceil(n/2) bins (reference core/audio_io.py:100-113), computed
+    on the GPU in fp64 for any length (kernel K2: Bluestein on a Stockham FFT).  Exact zeros give -inf,
+    as in the reference (no epsilon)."""
+    from . import _native
     n = len(x)
     half = int(np.ceil(n / 2))
-    X = np.fft.rfft(x)
-    with np.errstate(divide="ignore"):
-        mag = 20 * np.log10(np.abs(X[:half]))
-    return np.arange(half) * (fs / n), mag
+    f = np.arange(half) * (fs / n) if n else np.zeros(0)
+    if n == 0:
+        return f, np.zeros(0)
+    return f, _native.default_context().magnitude_db(np.asarray(x, dtype=np.float64))
+
+
+def magnitude_responses(rows, fs):
+    """Batched form for equally long rows: [B, n] -> (f, dB[B, ceil(n/2)]) in one launch chain."""
+    from . import _native
+    rows = np.asarray(rows, dtype=np.float64)
+    n = rows.shape[1]
+    half = int(np.ceil(n / 2))
+    return np.arange(half) * (fs / n), _native.default_context().magnitude_db(rows)
 
 
 def running_mean(x, N):

@@ -119,6 +119,12 @@ int imp_debug_host_spectrum(const double* filter, int64_t M, int n1_rows, float*
 int imp_plan_debug_run_stage(imp_plan* plan, const float* x, int64_t B, int64_t ld_in, int stage,
                              float* ws_out_host);
 
+/* ---- K2: magnitude response of arbitrary-length rows, fp64 --------------------------------------
+ * core/audio_io.py:100-113 magnitude_response: 20*log10(abs(np.fft.rfft(x)[:ceil(n/2)])), no epsilon
+ * (exact zeros give -inf).  x: host [B][n] float64 (IR data is float64 in the reference's classes);
+ * db_out: host [B][ceil(n/2)].  Any n up to 2^22 (Bluestein on a power-of-two Stockham FFT). */
+int imp_magnitude_db(imp_ctx* ctx, const double* x, int64_t B, int64_t n, double* db_out);
+
 /* ---- K3: first significant peak ---------------------------------------------------------------
  * core/impulse_response.py:32-70 ImpulseResponse.peak_index (twin core/decay.py:12-41):
  * normalise by max|x| of the searched range, scipy.signal.find_peaks(+x and -x, height), minimum

@@ -568,6 +568,19 @@ def test_room_correction_and_worker_real_column(gpu_ctx, golden):
     class Rir:
         irs = {"FC": {"left": ir}}
 
+    # the same chain on the reference's own float64 IR isolates the curve logic + K2 from the fp32 IR
+    ref_data = d["cropped_head"].copy()
+    ref_data[n_out - fo // 2:] *= _hann(fo)[fo // 2:]
+
+    class RirRef:
+        irs = {"FC": {"left": ImpulseResponse(ref_data, 48000)}}
+
+    np.testing.assert_allclose(RirRef.irs["FC"]["left"].frequency_response().raw, g["fr_raw_initial"], rtol=0, atol=1e-9)
+    fr64 = calculate_specific_room_corrections(RirRef, target, mic_calibration=mic, limit=400)["FC"]["left"]
+    np.testing.assert_allclose(fr64.raw, g["fr_raw"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(fr64.error, g["fr_error"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(fr64.target, g["fr_target"], rtol=0, atol=1e-9)
+
     frs = calculate_specific_room_corrections(Rir, target, mic_calibration=mic, limit=400)
     fr = frs["FC"]["left"]
     # dB curves from an fp32 IR: 1e-6 of the spectrum peak is ~1e-3 dB on bins 40 dB below it
@@ -638,3 +651,33 @@ def test_pipeline_slice_product(gpu_ctx, golden, tmp_path):
         band = np.fft.rfftfreq(len(want), 1 / fs) < 0.9 * fs / 2
         assert np.max(np.abs(A - R)[band]) / np.max(R) <= 2e-6
         assert np.max(np.abs(A - R)) / np.max(R) <= 5e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# K2: magnitude response of arbitrary-length rows (fp64 Bluestein on the device)
+# ------------------------------------------------------------------------------------------------
+def test_magnitude_response_golden(gpu_ctx, golden):
+    """The reference pins this function bit-exactly to np.fft.rfft (tests/test_magnitude_response_parity.py);
+    a different transform algorithm cannot be bit-identical, so the device result is held to 1e-9 dB
+    (fp64 Bluestein: ~1e-13 relative on |X|), including odd and non-smooth lengths."""
+    from impulse_hip.audio_io import magnitude_response, magnitude_responses
+    g = golden("magnitude")
+    for seed, sizes in ((0xA110, (8, 1024, 48000)), (0xA111, (9, 1025, 48001))):
+        rr = np.random.default_rng(seed)
+        for n in sizes:
+            x = rr.standard_normal(n).astype(np.float32).astype(np.float64)
+            f, m = magnitude_response(x, 48000)
+            assert np.array_equal(f, g[f"n{n}_f"])
+            assert m.shape == g[f"n{n}_db"].shape
+            assert np.max(np.abs(m - g[f"n{n}_db"])) <= 1e-9
+    # impulse, all-zero (-inf like the reference: no epsilon), batched prime length
+    x = np.zeros(2048)
+    x[0] = 1.0
+    assert np.max(np.abs(magnitude_response(x, 48000)[1])) <= 1e-9
+    assert np.all(np.isneginf(magnitude_response(np.zeros(100), 48000)[1]))
+    rows = np.random.default_rng(1).standard_normal((5, 43199))            # 43199 = 13 * 3323
+    f, m = magnitude_responses(rows, 48000)
+    with np.errstate(divide="ignore"):
+        ref = 20 * np.log10(np.abs(np.fft.rfft(rows, axis=1)[:, : (43199 + 1) // 2]))
+    assert m.shape == ref.shape and np.max(np.abs(m - ref)) <= 1e-9
+    assert np.array_equal(magnitude_response(np.zeros(0), 48000)[1], np.zeros(0))
