@@ -30,7 +30,6 @@ constexpr int kRowPad = 272;     // LDS row pitch (float2) of the 16x256 exchang
 //   t1[a*256 + t]      = w4096^(t a)                            row pass, stage after the 1st FFT16
 //   t2[q*16 + l]       = w4096^(16 l q)   (= w256^(l q))        row pass, stage after the 2nd FFT16
 //   t4[j*256 + t]      = w4096^((16 j + (t&15)) (t>>4))         row pass, inverse 2nd twiddle
-//   row[m]             = w4096^m                                 (spectrum kernel only)
 // ---------------------------------------------------------------------------------------------
 struct Twiddles {
   const cf* __restrict__ full;
@@ -38,7 +37,6 @@ struct Twiddles {
   const cf* __restrict__ t1;
   const cf* __restrict__ t2;
   const cf* __restrict__ t4;
-  const cf* __restrict__ row;
 };
 
 // Blocks b and b+8 share an XCD (round-robin dispatch; a speed assumption only).  Work items are

@@ -41,20 +41,6 @@ int ctx_bind(imp_ctx* ctx) {
   return IMP_OK;
 }
 
-static int upload_twiddle(cf** dptr, size_t n, double step_num, double denom, hipStream_t s) {
-  std::vector<cf> h(n);
-  for (size_t m = 0; m < n; ++m) {
-    // angle = -2 pi * (step_num * m) / denom, reduced exactly in integers first
-    double frac = std::fmod(step_num * (double)m, denom) / denom;
-    double ang = -2.0 * M_PI * frac;
-    h[m] = make_float2((float)std::cos(ang), (float)std::sin(ang));
-  }
-  HIP_TRY(hipMalloc((void**)dptr, n * sizeof(cf)));
-  HIP_TRY(hipMemcpyAsync(*dptr, h.data(), n * sizeof(cf), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  return IMP_OK;
-}
-
 static int upload_table(cf** dptr, const std::vector<cf>& h, hipStream_t s) {
   HIP_TRY(hipMalloc((void**)dptr, h.size() * sizeof(cf)));
   HIP_TRY(hipMemcpyAsync(*dptr, h.data(), h.size() * sizeof(cf), hipMemcpyHostToDevice, s));
@@ -160,8 +146,7 @@ extern "C" int imp_ctx_create(int device_id, imp_ctx** out) {
     delete ctx;
     return fail(IMP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
   }
-  int rc = upload_twiddle(&ctx->tw_row, 4096, 1.0, 4096.0, ctx->stream);
-  if (!rc) rc = ctx_row_tables(ctx);
+  int rc = ctx_row_tables(ctx);
   if (rc) {
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -198,7 +183,6 @@ extern "C" void imp_ctx_destroy(imp_ctx* ctx) {
     (void)hipFree(kv.second.full);
     (void)hipFree(kv.second.hi);
   }
-  if (ctx->tw_row) (void)hipFree(ctx->tw_row);
   if (ctx->tw_t1) (void)hipFree(ctx->tw_t1);
   if (ctx->tw_t2) (void)hipFree(ctx->tw_t2);
   if (ctx->tw_t4) (void)hipFree(ctx->tw_t4);
@@ -402,7 +386,7 @@ static int launch_cols(imp_plan* p, int64_t nchan, Load ld, Store st) {
     attr_set = true;
   }
   const int tiles = imp::kN2 / Cfg::TC;
-  imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4, p->ctx->tw_row};
+  imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
   dim3 grid((unsigned)(nchan * tiles)), block(Cfg::T);
   hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->ctx->stream, ld, st, tw, (int)nchan);
   HIP_TRY(hipGetLastError());
@@ -420,7 +404,7 @@ static int launch_cols_mixed(imp_plan* p, int64_t nchan, Load ld, Store st) {
     attr_set = true;
   }
   const int tiles = imp::kN2 / Cfg::TC;
-  imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4, p->ctx->tw_row};
+  imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
   dim3 grid((unsigned)(nchan * tiles)), block(Cfg::T);
   hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->ctx->stream, ld, st, tw, (int)nchan);
   HIP_TRY(hipGetLastError());
@@ -461,7 +445,7 @@ static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan) {
   a.n1_total = p->N1;
   a.npairs = p->N1 / 2;
   a.nchan = (int)nchan;
-  imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4, p->ctx->tw_row};
+  imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
   dim3 grid((unsigned)(nchan * a.npairs)), block(512);
   hipLaunchKernelGGL(imp::rows_kernel, grid, block, kRowsLds, p->ctx->stream, a, tw);
   HIP_TRY(hipGetLastError());

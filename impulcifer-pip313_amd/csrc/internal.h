@@ -36,7 +36,6 @@ struct imp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = true;
-  cf* tw_row = nullptr;                 // exp(-2 pi i m / 4096)
   cf* tw_t1 = nullptr;                  // row-pass stage tables, see conv_kernels.hip.h
   cf* tw_t2 = nullptr;
   cf* tw_t4 = nullptr;

@@ -681,3 +681,57 @@ def test_magnitude_response_golden(gpu_ctx, golden):
         ref = 20 * np.log10(np.abs(np.fft.rfft(rows, axis=1)[:, : (43199 + 1) // 2]))
     assert m.shape == ref.shape and np.max(np.abs(m - ref)) <= 1e-9
     assert np.array_equal(magnitude_response(np.zeros(0), 48000)[1], np.zeros(0))
+
+
+# ------------------------------------------------------------------------------------------------
+# alignment / shift (next-tier row f1; host-side correlations): the reference's own assertions
+# (tests/test_dsp_stages.py:105-166)
+# ------------------------------------------------------------------------------------------------
+def test_alignment_and_shift_behaviour(gpu_ctx):
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.impulse_response import ImpulseResponse
+
+    class Est:
+        fs = 48000
+
+    def ir(d):
+        return ImpulseResponse(np.asarray(d, dtype=np.float64), 48000)
+
+    def impulse_at(i, n=2048):
+        d = np.zeros(n)
+        d[i] = 1.0
+        return ir(d)
+
+    def lag(a, b, seg=1440):
+        corr = np.correlate(a[:seg], b[:seg], mode="full")
+        return int(np.arange(-len(a[:seg]) + 1, len(a[:seg]))[np.argmax(corr)])
+
+    h = HRIR(Est())
+    h.irs = {"FL": {"left": impulse_at(60), "right": impulse_at(60)},
+             "FR": {"left": impulse_at(60), "right": impulse_at(67)}}
+    assert abs(lag(h.irs["FL"]["left"].data, h.irs["FR"]["right"].data)) == 7
+    h.align_ipsilateral_all(speaker_pairs=[("FL", "FR")], segment_ms=30)
+    assert abs(lag(h.irs["FL"]["left"].data, h.irs["FR"]["right"].data)) <= 1
+    assert all(len(x.data) == 2048 for p in h.irs.values() for x in p.values())
+    # onset groups: every group's left-ear peak is moved onto FL's (device peak search)
+    h = HRIR(Est())
+    h.irs = {"FL": {"left": impulse_at(100), "right": impulse_at(110)},
+             "SL": {"left": impulse_at(130), "right": impulse_at(150)},
+             "FC": {"left": impulse_at(90), "right": impulse_at(90)}}
+    h.align_onset_groups_peak_leftref()
+    assert [h.irs[s]["left"].peak_index() for s in ("FL", "SL", "FC")] == [100, 100, 100]
+    assert h.irs["SL"]["right"].peak_index() == 120 and h.irs["FC"]["right"].peak_index() == 100
+    del h.irs["FL"]
+    with pytest.raises(RuntimeError):
+        h.align_onset_groups_peak_leftref()
+    x = ir([1.0, 2.0, 3.0, 4.0])
+    x.shift(2)
+    np.testing.assert_array_equal(x.data, [0.0, 0.0, 1.0, 2.0])
+    x = ir([1.0, 2.0, 3.0, 4.0])
+    x.shift(-1)
+    np.testing.assert_array_equal(x.data, [2.0, 3.0, 4.0, 0.0])
+    x.shift(0)
+    np.testing.assert_array_equal(x.data, [2.0, 3.0, 4.0, 0.0])
+    x.shift(3)
+    x.shift(-3)
+    assert len(x.data) == 4
