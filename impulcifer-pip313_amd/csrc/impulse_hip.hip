@@ -172,6 +172,7 @@ extern "C" int imp_ctx_synchronize(imp_ctx* ctx) {
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (auto st : ctx->side_streams) HIP_TRY(hipStreamSynchronize(st));
   return IMP_OK;
 }
 
@@ -189,6 +190,10 @@ extern "C" void imp_ctx_destroy(imp_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   minphase_plans_destroy(ctx);
   magnitude_plans_destroy(ctx);
+  for (auto st : ctx->side_streams) {
+    (void)hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+  }
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -357,7 +362,11 @@ struct imp_plan {
   int64_t out_start = 0, out_len = 0;
   int64_t nfft = 0, Nc = 0;
   int N1 = 0, R2 = 0;
-  int64_t ws_channels = 0;
+  int64_t ws_channels = 0;           // channels the workspace holds in total
+  int lanes = 1;                     // launch groups in flight (imp_plan_set_overlap)
+  int64_t group_counter_lane = 0;    // round-robin lane assignment of launch groups
+  hipStream_t cur_stream = nullptr;  // lane the kernels of the current launch group go to
+  cf* cur_ws = nullptr;
   TwSet tw;
   float4* ab = nullptr;    // [n_filters][N1][4096]
   cf* ws = nullptr;        // [ws_channels][N1][4096]
@@ -388,7 +397,7 @@ static int launch_cols(imp_plan* p, int64_t nchan, Load ld, Store st) {
   const int tiles = imp::kN2 / Cfg::TC;
   imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
   dim3 grid((unsigned)(nchan * tiles)), block(Cfg::T);
-  hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->ctx->stream, ld, st, tw, (int)nchan);
+  hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->cur_stream, ld, st, tw, (int)nchan);
   HIP_TRY(hipGetLastError());
   return IMP_OK;
 }
@@ -406,7 +415,7 @@ static int launch_cols_mixed(imp_plan* p, int64_t nchan, Load ld, Store st) {
   const int tiles = imp::kN2 / Cfg::TC;
   imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
   dim3 grid((unsigned)(nchan * tiles)), block(Cfg::T);
-  hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->ctx->stream, ld, st, tw, (int)nchan);
+  hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->cur_stream, ld, st, tw, (int)nchan);
   HIP_TRY(hipGetLastError());
   return IMP_OK;
 }
@@ -438,7 +447,7 @@ static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan) {
     attr_set = true;
   }
   imp::RowsArgs a;
-  a.ws = p->ws;
+  a.ws = p->cur_ws;
   const int64_t plane = (int64_t)p->N1 * imp::kN2;
   a.ab = p->ab + (p->n_filters > 1 ? first_chan * plane : 0);
   a.ab_chan_stride = p->n_filters > 1 ? plane : 0;
@@ -447,7 +456,7 @@ static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan) {
   a.nchan = (int)nchan;
   imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
   dim3 grid((unsigned)(nchan * a.npairs)), block(512);
-  hipLaunchKernelGGL(imp::rows_kernel, grid, block, kRowsLds, p->ctx->stream, a, tw);
+  hipLaunchKernelGGL(imp::rows_kernel, grid, block, kRowsLds, p->cur_stream, a, tw);
   HIP_TRY(hipGetLastError());
   return IMP_OK;
 }
@@ -510,10 +519,12 @@ static int plan_alloc(imp_plan* p) {
   return IMP_OK;
 }
 
+static int plan_sync_lanes(imp_plan* p);
+
 extern "C" void imp_plan_destroy(imp_plan* p) {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
-  (void)hipStreamSynchronize(p->ctx->stream);
+  (void)plan_sync_lanes(p);
   if (p->ab) (void)hipFree(p->ab);
   if (p->ws) (void)hipFree(p->ws);
   if (p->d_in) (void)hipFree(p->d_in);
@@ -612,9 +623,17 @@ extern "C" int imp_plan_set_timing(imp_plan* p, int enable) {
   return IMP_OK;
 }
 
+static int plan_sync_lanes(imp_plan* p) {
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  for (int l = 1; l < p->lanes && l - 1 < (int)p->ctx->side_streams.size(); ++l)
+    HIP_TRY(hipStreamSynchronize(p->ctx->side_streams[(size_t)(l - 1)]));
+  return IMP_OK;
+}
+
 static int plan_collect_timing(imp_plan* p) {
   if (p->timed == 0) return IMP_OK;
-  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  int rcs = plan_sync_lanes(p);
+  if (rcs) return rcs;
   for (int64_t i = 0; i < p->timed; ++i) {
     for (int k = 0; k < 3; ++k) {
       float ms = 0.f;
@@ -655,7 +674,7 @@ static int timing_event(imp_plan* p, int slot) {
     HIP_TRY(hipEventCreate(&ev));
     p->events.push_back(ev);
   }
-  HIP_TRY(hipEventRecord(p->events[(size_t)(4 * p->timed + slot)], p->ctx->stream));
+  HIP_TRY(hipEventRecord(p->events[(size_t)(4 * p->timed + slot)], p->cur_stream));
   if (slot == 3) ++p->timed;
   return IMP_OK;
 }
@@ -665,15 +684,20 @@ static int run_group(imp_plan* p, const float* d_x, int64_t nchan, int64_t chan_
                      int64_t elem_stride_in, float* d_y, int64_t chan_stride_out, int64_t first_chan,
                      int last_stage) {
   int rc;
+  // lane = stream + private slice of the workspace; successive launch groups go round robin
+  const int64_t lane_channels = p->ws_channels / p->lanes;
+  const int lane = (p->lanes > 1) ? (int)(p->group_counter_lane++ % p->lanes) : 0;
+  p->cur_stream = lane ? p->ctx->side_streams[(size_t)(lane - 1)] : p->ctx->stream;
+  p->cur_ws = p->ws + (int64_t)lane * lane_channels * p->N1 * imp::kN2;
   // every kernel indexes ws[] by the group-local channel and ab[] by the global one: check both
-  if (nchan < 1 || nchan > p->ws_channels)
-    return fail(IMP_ERR_INVALID, "launch group of %lld channels exceeds the workspace (%lld)", (long long)nchan,
-                (long long)p->ws_channels);
+  if (nchan < 1 || nchan > lane_channels)
+    return fail(IMP_ERR_INVALID, "launch group of %lld channels exceeds the workspace lane (%lld)", (long long)nchan,
+                (long long)lane_channels);
   if (p->n_filters > 1 && first_chan + nchan > p->n_filters)
     return fail(IMP_ERR_INVALID, "channel %lld has no filter: the plan holds %lld per-channel filters",
                 (long long)(first_chan + nchan - 1), (long long)p->n_filters);
   imp::LoadRealPacked ld{d_x, chan_stride_in, elem_stride_in, p->L};
-  imp::StoreWorkspace stw{p->ws, p->N1};
+  imp::StoreWorkspace stw{p->cur_ws, p->N1};
   if ((rc = timing_event(p, 0))) return rc;
   if ((rc = launch_cols_any<-1>(p, nchan, ld, stw))) return rc;
   if ((rc = timing_event(p, 1))) return rc;
@@ -681,7 +705,7 @@ static int run_group(imp_plan* p, const float* d_x, int64_t nchan, int64_t chan_
   if ((rc = launch_rows(p, nchan, first_chan))) return rc;
   if ((rc = timing_event(p, 2))) return rc;
   if (last_stage < 2) return IMP_OK;
-  imp::LoadWorkspace ldw{p->ws, p->N1};
+  imp::LoadWorkspace ldw{p->cur_ws, p->N1};
   imp::StoreRealCrop stc{d_y, chan_stride_out, 1, p->out_start, p->out_len};
   if ((rc = launch_cols_any<+1>(p, nchan, ldw, stc))) return rc;
   if ((rc = timing_event(p, 3))) return rc;
@@ -700,12 +724,31 @@ extern "C" int imp_conv_execute_device(imp_plan* p, const float* d_x, int64_t B,
                 (long long)p->n_filters);
   int rc = ctx_bind(p->ctx);
   if (rc) return rc;
-  for (int64_t c0 = 0; c0 < B; c0 += p->ws_channels) {
-    const int64_t n = std::min(p->ws_channels, B - c0);
+  const int64_t grp = p->ws_channels / p->lanes;
+  for (int64_t c0 = 0; c0 < B; c0 += grp) {
+    const int64_t n = std::min(grp, B - c0);
     rc = run_group(p, d_x + c0 * chan_stride_in, n, chan_stride_in, elem_stride_in,
                    d_y + c0 * chan_stride_out, chan_stride_out, c0, 2);
     if (rc) return rc;
   }
+  return IMP_OK;
+}
+
+extern "C" int imp_plan_set_overlap(imp_plan* p, int lanes) {
+  if (!p) return fail(IMP_ERR_INVALID, "null plan");
+  if (lanes < 1 || lanes > 4) return fail(IMP_ERR_INVALID, "lanes must be in [1, 4]");
+  if (p->ws_channels / lanes < 1) return fail(IMP_ERR_INVALID, "workspace of %lld channels cannot be split %d ways",
+                                              (long long)p->ws_channels, lanes);
+  int rc = ctx_bind(p->ctx);
+  if (rc) return rc;
+  if ((rc = plan_sync_lanes(p))) return rc;
+  while ((int)p->ctx->side_streams.size() < lanes - 1) {
+    hipStream_t st;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    p->ctx->side_streams.push_back(st);
+  }
+  p->lanes = lanes;
+  p->group_counter_lane = 0;
   return IMP_OK;
 }
 
@@ -739,6 +782,7 @@ extern "C" int imp_conv_execute(imp_plan* p, const float* x, int64_t B, int64_t 
   if (rc) return rc;
   // even row pitches keep the float2 fast paths aligned
   const int64_t pin = (p->L + 1) & ~(int64_t)1, pout = (p->out_len + 1) & ~(int64_t)1;
+  if (p->lanes > 1) return fail(IMP_ERR_INVALID, "host-buffer execution needs imp_plan_set_overlap(plan, 1)");
   const int64_t grp = std::min(B, p->ws_channels);
   if ((rc = plan_staging(p, (size_t)(grp * pin) * sizeof(float), (size_t)(grp * pout) * sizeof(float)))) return rc;
   hipStream_t s = p->ctx->stream;
@@ -760,6 +804,7 @@ extern "C" int imp_conv_execute_interleaved(imp_plan* p, const float* frames, in
   if (ld_out < p->out_len) return fail(IMP_ERR_INVALID, "ld_out < out_len");
   int rc = ctx_bind(p->ctx);
   if (rc) return rc;
+  if (p->lanes > 1) return fail(IMP_ERR_INVALID, "host-buffer execution needs imp_plan_set_overlap(plan, 1)");
   const int64_t pout = (p->out_len + 1) & ~(int64_t)1;
   const int64_t grp = std::min(C, p->ws_channels);
   if ((rc = plan_staging(p, (size_t)(p->L * C) * sizeof(float), (size_t)(grp * pout) * sizeof(float)))) return rc;

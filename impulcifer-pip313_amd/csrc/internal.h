@@ -44,6 +44,8 @@ struct imp_ctx {
   // scratch for the small ragged kernels
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // extra streams for overlapped launch groups (imp_plan_set_overlap); lane 0 is `stream`
+  std::vector<hipStream_t> side_streams;
   // K6 plans keyed by (taps n, fs)
   std::map<std::pair<long long, long long>, MinPhasePlan*> minphase_plans;
   // K2 plans keyed by row length n

@@ -71,6 +71,7 @@ SIGNATURES = {
     "imp_conv_execute": (C.c_int, [_vp, _pf, _i64, _i64, _pf, _i64]),
     "imp_conv_execute_interleaved": (C.c_int, [_vp, _pf, _i64, _pf, _i64]),
     "imp_conv_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64]),
+    "imp_plan_set_overlap": (C.c_int, [_vp, C.c_int]),
     "imp_plan_set_timing": (C.c_int, [_vp, C.c_int]),
     "imp_plan_get_timing": (C.c_int, [_vp, _pd, _pi64, C.c_int]),
     "imp_debug_plan_geometry": (C.c_int, [_i64, _i64, C.c_int, _pi64, _pi64, _pi64]),
@@ -347,6 +348,11 @@ class ConvPlan:
     def execute_device(self, d_x, B, chan_stride_in, d_y, chan_stride_out, elem_stride_in=1):
         _check(self._lib.imp_conv_execute_device(self._h, _vp(int(d_x)), int(B), int(chan_stride_in),
                                                  int(elem_stride_in), _vp(int(d_y)), int(chan_stride_out)))
+
+    def set_overlap(self, lanes):
+        """lanes > 1: successive launch groups of execute_device overlap on that many streams (inputs must
+        be ready before each call; outputs are complete after ctx.synchronize())."""
+        _check(self._lib.imp_plan_set_overlap(self._h, int(lanes)))
 
     def set_timing(self, every_n):
         """0/False = off; n = bracket the three passes of every n-th launch group with HIP events."""

@@ -101,6 +101,15 @@ int imp_conv_execute_interleaved(imp_plan* plan, const float* frames, int64_t C,
 int imp_conv_execute_device(imp_plan* plan, const float* d_x, int64_t B, int64_t chan_stride_in,
                             int64_t elem_stride_in, float* d_y, int64_t chan_stride_out);
 
+/* Overlapped execution of independent launch groups.  With lanes = n > 1 the workspace is split into n
+ * private slices and successive launch groups of imp_conv_execute_device - within one call and across
+ * calls - go round robin to n streams (lane 0 = the context stream), so that one group's column pass
+ * runs beside another group's row pass instead of the whole chip moving through the same phase.
+ * Contract while lanes > 1: inputs must be complete before the call (they are not ordered against
+ * earlier work on the context stream), outputs are complete after imp_ctx_synchronize, and two calls
+ * in flight must not write the same output memory.  lanes = 1 restores strict stream order. */
+int imp_plan_set_overlap(imp_plan* plan, int lanes);
+
 /* per-kernel timing with HIP events on the plan's stream (for bench.py's roofline block):
  * every_n = 0 switches it off, n >= 1 brackets the three passes of every n-th launch group. */
 int imp_plan_set_timing(imp_plan* plan, int every_n);

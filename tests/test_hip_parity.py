@@ -735,3 +735,35 @@ def test_alignment_and_shift_behaviour(gpu_ctx):
     x.shift(3)
     x.shift(-3)
     assert len(x.data) == 4
+
+
+def test_overlapped_launch_groups_are_bit_identical(gpu_ctx):
+    """imp_plan_set_overlap: launch groups on 3 lanes (private workspace slices, 3 streams) must give
+    exactly the bytes of the strictly serial order, within one call and across calls."""
+    from impulse_hip import ConvPlan, NativeError
+    rng = np.random.default_rng(12)
+    L, M, B = 60000, 40000, 13
+    x = rng.standard_normal((B, L)).astype(np.float32)
+    h = rng.standard_normal(M)
+    plan = ConvPlan(gpu_ctx, h, L, "same", ws_channels=9)          # 3 lanes x 3 channels -> 5 groups
+    serial = plan.execute(x)
+    pitch = L
+    d_x, d_y1, d_y2 = gpu_ctx.malloc(B * pitch * 4), gpu_ctx.malloc(B * pitch * 4), gpu_ctx.malloc(B * pitch * 4)
+    gpu_ctx.h2d(d_x, x)
+    plan.set_overlap(3)
+    plan.execute_device(d_x, B, pitch, d_y1, pitch)
+    plan.execute_device(d_x, B, pitch, d_y2, pitch)                 # a second call in flight, other output
+    gpu_ctx.synchronize()
+    for d in (d_y1, d_y2):
+        got = np.empty((B, pitch), dtype=np.float32)
+        gpu_ctx.d2h(got, d)
+        assert np.array_equal(got, serial)
+    with pytest.raises(NativeError):
+        plan.execute(x)                                             # host-buffer path needs strict order
+    with pytest.raises(NativeError):
+        plan.set_overlap(5)
+    plan.set_overlap(1)
+    assert np.array_equal(plan.execute(x), serial)
+    for d in (d_x, d_y1, d_y2):
+        gpu_ctx.free(d)
+    plan.close()
