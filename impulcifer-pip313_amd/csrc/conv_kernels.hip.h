@@ -86,6 +86,31 @@ struct LoadRealPacked {
   }
 };
 
+// Raw PCM frames as they sit in a WAV file: sample i of channel c at base[(i*elem_stride) + c*chan_stride]
+// (interleaved: elem_stride = tracks, chan_stride = 1), int32 or int16, scaled to [-1, 1) by 2^-(bits-1)
+// exactly like soundfile/libsndfile and the reference's reader do (core/audio_truehd.py:153-185).
+template <class Sample>
+struct LoadPcmPacked {
+  const Sample* __restrict__ base;
+  long long chan_stride;
+  long long elem_stride;
+  long long len;
+  float scale;
+  __device__ __forceinline__ cf operator()(int b, int n1, int n2) const {
+    const long long i0 = 2 * (((long long)n1 << kLogN2) + n2);
+    const Sample* p = base + (long long)b * chan_stride;
+    cf z = make_float2(0.f, 0.f);
+    // int -> float conversion is exact for 16-bit and rounds 32-bit PCM to fp32 (the device dtype)
+    if (i0 < len) z.x = (float)p[i0 * elem_stride] * scale;
+    if (i0 + 1 < len) z.y = (float)p[(i0 + 1) * elem_stride] * scale;
+    return z;
+  }
+  __device__ __forceinline__ int live_rows() const {
+    const long long nz = (len + 1) / 2;
+    return (int)((nz + kN2 - 1) >> kLogN2);
+  }
+};
+
 struct LoadWorkspace {
   const cf* __restrict__ ws;   // [B][N1][4096]
   int n1_total;

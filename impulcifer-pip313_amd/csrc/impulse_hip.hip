@@ -680,9 +680,20 @@ static int timing_event(imp_plan* p, int slot) {
 }
 
 // one launch group: nchan <= ws_channels channels, device pointers
+template <class Load>
+static int run_group_with(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64_t chan_stride_out,
+                          int64_t first_chan, int last_stage);
+
 static int run_group(imp_plan* p, const float* d_x, int64_t nchan, int64_t chan_stride_in,
                      int64_t elem_stride_in, float* d_y, int64_t chan_stride_out, int64_t first_chan,
                      int last_stage) {
+  imp::LoadRealPacked ld{d_x, chan_stride_in, elem_stride_in, p->L};
+  return run_group_with(p, ld, nchan, d_y, chan_stride_out, first_chan, last_stage);
+}
+
+template <class Load>
+static int run_group_with(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64_t chan_stride_out,
+                          int64_t first_chan, int last_stage) {
   int rc;
   // lane = stream + private slice of the workspace; successive launch groups go round robin
   const int64_t lane_channels = p->ws_channels / p->lanes;
@@ -696,7 +707,6 @@ static int run_group(imp_plan* p, const float* d_x, int64_t nchan, int64_t chan_
   if (p->n_filters > 1 && first_chan + nchan > p->n_filters)
     return fail(IMP_ERR_INVALID, "channel %lld has no filter: the plan holds %lld per-channel filters",
                 (long long)(first_chan + nchan - 1), (long long)p->n_filters);
-  imp::LoadRealPacked ld{d_x, chan_stride_in, elem_stride_in, p->L};
   imp::StoreWorkspace stw{p->cur_ws, p->N1};
   if ((rc = timing_event(p, 0))) return rc;
   if ((rc = launch_cols_any<-1>(p, nchan, ld, stw))) return rc;
@@ -729,6 +739,31 @@ extern "C" int imp_conv_execute_device(imp_plan* p, const float* d_x, int64_t B,
     const int64_t n = std::min(grp, B - c0);
     rc = run_group(p, d_x + c0 * chan_stride_in, n, chan_stride_in, elem_stride_in,
                    d_y + c0 * chan_stride_out, chan_stride_out, c0, 2);
+    if (rc) return rc;
+  }
+  return IMP_OK;
+}
+
+extern "C" int imp_conv_execute_device_pcm(imp_plan* p, const void* d_pcm, int bits, int64_t B, int64_t chan_stride_in,
+                                           int64_t elem_stride_in, float* d_y, int64_t chan_stride_out) {
+  if (!p || !d_pcm || !d_y) return fail(IMP_ERR_INVALID, "imp_conv_execute_device_pcm: null argument");
+  if (bits != 16 && bits != 32) return fail(IMP_ERR_INVALID, "PCM width must be 16 or 32 bits");
+  if (B < 0 || elem_stride_in < 1) return fail(IMP_ERR_INVALID, "bad B or elem_stride_in");
+  if (chan_stride_out < p->out_len) return fail(IMP_ERR_INVALID, "chan_stride_out < out_len");
+  int rc = ctx_bind(p->ctx);
+  if (rc) return rc;
+  const int64_t grp = p->ws_channels / p->lanes;
+  for (int64_t c0 = 0; c0 < B; c0 += grp) {
+    const int64_t n = std::min(grp, B - c0);
+    if (bits == 32) {
+      imp::LoadPcmPacked<int32_t> ld{(const int32_t*)d_pcm + c0 * chan_stride_in, chan_stride_in, elem_stride_in, p->L,
+                                     1.0f / 2147483648.0f};
+      rc = run_group_with(p, ld, n, d_y + c0 * chan_stride_out, chan_stride_out, c0, 2);
+    } else {
+      imp::LoadPcmPacked<int16_t> ld{(const int16_t*)d_pcm + c0 * chan_stride_in, chan_stride_in, elem_stride_in, p->L,
+                                     1.0f / 32768.0f};
+      rc = run_group_with(p, ld, n, d_y + c0 * chan_stride_out, chan_stride_out, c0, 2);
+    }
     if (rc) return rc;
   }
   return IMP_OK;

@@ -71,6 +71,7 @@ SIGNATURES = {
     "imp_conv_execute": (C.c_int, [_vp, _pf, _i64, _i64, _pf, _i64]),
     "imp_conv_execute_interleaved": (C.c_int, [_vp, _pf, _i64, _pf, _i64]),
     "imp_conv_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64]),
+    "imp_conv_execute_device_pcm": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _i64]),
     "imp_plan_set_overlap": (C.c_int, [_vp, C.c_int]),
     "imp_plan_set_timing": (C.c_int, [_vp, C.c_int]),
     "imp_plan_get_timing": (C.c_int, [_vp, _pd, _pi64, C.c_int]),
@@ -348,6 +349,38 @@ class ConvPlan:
     def execute_device(self, d_x, B, chan_stride_in, d_y, chan_stride_out, elem_stride_in=1):
         _check(self._lib.imp_conv_execute_device(self._h, _vp(int(d_x)), int(B), int(chan_stride_in),
                                                  int(elem_stride_in), _vp(int(d_y)), int(chan_stride_out)))
+
+    def execute_device_pcm(self, d_pcm, bits, B, chan_stride_in, elem_stride_in, d_y, chan_stride_out):
+        _check(self._lib.imp_conv_execute_device_pcm(self._h, _vp(int(d_pcm)), int(bits), int(B), int(chan_stride_in),
+                                                     int(elem_stride_in), _vp(int(d_y)), int(chan_stride_out)))
+
+    def execute_pcm_columns(self, frames, column_starts):
+        """frames: interleaved PCM [n_frames, tracks] int16/int32 (WAV wire order).  Deconvolves, for every
+        column start s, the L frames frames[s:s+L] of every track: returns float32 [len(column_starts), tracks,
+        out_len].  The block is uploaded once, untouched; scaling and de-interleaving happen in the loader."""
+        frames = np.ascontiguousarray(frames)
+        if frames.dtype not in (np.int16, np.int32) or frames.ndim != 2:
+            raise ValueError("frames must be int16/int32 [n_frames, tracks]")
+        bits = 16 if frames.dtype == np.int16 else 32
+        n_frames, tracks = frames.shape
+        ctx = self.ctx
+        pitch = (self.out_len + 1) & ~1
+        d_in = ctx.malloc(frames.nbytes)
+        d_out = ctx.malloc(max(1, len(column_starts) * tracks) * pitch * 4)
+        try:
+            ctx.h2d(d_in, frames)
+            for j, s0 in enumerate(column_starts):
+                if s0 < 0 or s0 + self.L > n_frames:
+                    raise ValueError("column outside the recording")
+                self.execute_device_pcm(d_in + s0 * tracks * frames.itemsize, bits, tracks, 1, tracks,
+                                        d_out + j * tracks * pitch * 4, pitch)
+            ctx.synchronize()
+            out = np.empty((len(column_starts), tracks, pitch), dtype=np.float32)
+            ctx.d2h(out, d_out)
+        finally:
+            ctx.free(d_in)
+            ctx.free(d_out)
+        return out[:, :, :self.out_len]
 
     def set_overlap(self, lanes):
         """lanes > 1: successive launch groups of execute_device overlap on that many streams (inputs must

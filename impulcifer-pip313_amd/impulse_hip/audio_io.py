@@ -11,6 +11,41 @@ import struct
 import numpy as np
 
 
+def _parse_riff(blob, file_path):
+    if blob[:4] != b"RIFF" or blob[8:12] != b"WAVE":
+        raise ValueError(f"{file_path}: not a RIFF/WAVE file")
+    pos = 12
+    fmt = None
+    data = None
+    while pos + 8 <= len(blob):
+        cid, size = blob[pos:pos + 4], struct.unpack("<I", blob[pos + 4:pos + 8])[0]
+        body = memoryview(blob)[pos + 8: pos + 8 + size]
+        if cid == b"fmt ":
+            tag, nch, fs, _, align, bits = struct.unpack("<HHIIHH", body[:16])
+            if tag == 0xFFFE and len(body) >= 26:            # extensible: real tag in the GUID
+                tag = struct.unpack("<H", body[24:26])[0]
+            fmt = (tag, nch, fs, bits, align)
+        elif cid == b"data":
+            data = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or data is None:
+        raise ValueError(f"{file_path}: missing fmt/data chunk")
+    return fmt, data
+
+
+def read_wav_pcm(file_path):
+    """(fs, frames[n_frames, tracks]) with the file's own int16/int32 samples in wire order, or None when
+    the file is not 16/32-bit PCM.  This is what the device loader consumes directly."""
+    with open(file_path, "rb") as fh:
+        blob = fh.read()
+    (tag, nch, fs, bits, _), data = _parse_riff(blob, file_path)
+    if tag != 1 or bits not in (16, 32):
+        return None
+    nframes = len(data) // ((bits // 8) * nch)
+    frames = np.frombuffer(data, dtype="<i2" if bits == 16 else "<i4", count=nframes * nch).reshape(nframes, nch)
+    return int(fs), frames
+
+
 def read_wav(file_path, expand=False):
     """Returns (fs, data[tracks, samples] float64); 1-D for mono unless ``expand``."""
     with open(file_path, "rb") as fh:

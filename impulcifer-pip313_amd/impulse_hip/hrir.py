@@ -10,7 +10,7 @@ import warnings
 import numpy as np
 
 from . import _native
-from .audio_io import magnitude_response, read_wav, write_wav
+from .audio_io import magnitude_response, read_wav, read_wav_pcm, write_wav
 from .constants import (HEXADECAGONAL_TRACK_ORDER, IPSILATERAL_PAIRS, SPEAKER_DELAYS, SPEAKER_NAMES,
                         speaker_side, track_name)
 from .impulse_response import ImpulseResponse
@@ -146,6 +146,34 @@ def ingest_recording(estimator, expected_fs, fs, recording, speakers, side=None,
     return ordered
 
 
+def ingest_pcm_frames(estimator, expected_fs, fs, frames, speakers, side=None, silence_length=2.0):
+    """Same result as ingest_recording, from the WAV's own interleaved PCM frames [n_frames, tracks]
+    (int16/int32): the block goes to the GPU untouched; scaling to [-1, 1) and de-interleaving happen in
+    the column-pass loader (imp_conv_execute_device_pcm)."""
+    if fs != expected_fs:
+        raise ValueError("Sampling rate of recording must match sampling rate of test signal.")
+    n_frames, tracks = frames.shape
+    shape_only = np.broadcast_to(np.zeros(1), (tracks, n_frames))        # geometry needs shapes only
+    rec, jobs = split_recording(shape_only, speakers, len(estimator), fs, side, silence_length)
+    origin = n_frames - rec.shape[1]                                     # every trim is from the front
+    scale = 1.0 / float(2 ** (8 * frames.dtype.itemsize - 1))
+    by_len = {}
+    for job in jobs:
+        by_len.setdefault(job[4] - job[3], []).append(job)
+    irs = {}
+    for length, group in by_len.items():
+        starts = sorted({origin + a for (_, _, _, a, _) in group})
+        out = estimator._plan(length).execute_pcm_columns(frames, starts)
+        for sp, sd, tr, a, b in group:
+            y = out[starts.index(origin + a), tr].astype(np.float64)
+            column = frames[origin + a: origin + b, tr].astype(np.float64) * scale
+            irs.setdefault(sp, {})[sd] = ImpulseResponse(y, fs, column)
+    ordered = {}
+    for sp, sd, *_ in jobs:
+        ordered.setdefault(sp, {})[sd] = irs[sp][sd]
+    return ordered
+
+
 class HRIR(_PlotBase):
     def __init__(self, estimator):
         self.estimator = estimator
@@ -173,7 +201,13 @@ class HRIR(_PlotBase):
     def open_recording(self, file_path, speakers, side=None, silence_length=2.0, debug=False):
         """Split a combined sweep recording into speaker-ear impulse responses (batched on GPU)."""
         self._require_matching_fs("open recording")
-        fs, recording = read_wav(file_path, expand=True)
+        pcm = read_wav_pcm(file_path) if hasattr(self.estimator, "_plan") else None
+        if pcm is not None:
+            got = ingest_pcm_frames(self.estimator, self.fs, pcm[0], pcm[1], speakers, side, silence_length)
+            for sp, sides in got.items():
+                self.irs.setdefault(sp, {}).update(sides)
+            return
+        fs, recording = read_wav(file_path, expand=True)                   # 24-bit / float files, duck-typed estimators
         self.open_recording_data(fs, recording, speakers, side=side, silence_length=silence_length)
 
     def open_recording_data(self, fs, recording, speakers, side=None, silence_length=2.0):

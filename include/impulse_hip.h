@@ -101,6 +101,13 @@ int imp_conv_execute_interleaved(imp_plan* plan, const float* frames, int64_t C,
 int imp_conv_execute_device(imp_plan* plan, const float* d_x, int64_t B, int64_t chan_stride_in,
                             int64_t elem_stride_in, float* d_y, int64_t chan_stride_out);
 
+/* device in = raw PCM as it sits in a WAV data chunk (bits = 16 or 32, little endian): sample i of channel
+ * b at d_pcm[b*chan_stride_in + i*elem_stride_in] (interleaved frames: chan_stride_in = 1, elem_stride_in =
+ * tracks).  The loader scales by 2^-(bits-1) and de-interleaves while packing, replacing the reference's
+ * host-side int->float64 conversion and transpose (core/audio_truehd.py:153-185, core/hrir.py:202-219). */
+int imp_conv_execute_device_pcm(imp_plan* plan, const void* d_pcm, int bits, int64_t B, int64_t chan_stride_in,
+                                int64_t elem_stride_in, float* d_y, int64_t chan_stride_out);
+
 /* Overlapped execution of independent launch groups.  With lanes = n > 1 the workspace is split into n
  * private slices and successive launch groups of imp_conv_execute_device - within one call and across
  * calls - go round robin to n streams (lane 0 = the context stream), so that one group's column pass

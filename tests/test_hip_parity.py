@@ -767,3 +767,37 @@ def test_overlapped_launch_groups_are_bit_identical(gpu_ctx):
     for d in (d_x, d_y1, d_y2):
         gpu_ctx.free(d)
     plan.close()
+
+
+def test_pcm_wire_format_ingest(gpu_ctx, tmp_path):
+    """HRIR.open_recording on 32- and 16-bit PCM files goes through the PCM loader (raw interleaved
+    frames on the device); it must give the same IRs as the float path and as the oracle."""
+    from impulse_hip.audio_io import read_wav, read_wav_pcm, write_wav
+    from impulse_hip.hrir import HRIR, ingest_recording
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from oracle.estimator import estimate
+    import slice_input
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+    tracks = slice_input.make_tracks(e.test_signal, 48000)
+    for bits, tol in ((32, TIME_TOL), (16, TIME_TOL)):
+        path = str(tmp_path / f"FL,FR-{bits}.wav")
+        write_wav(path, 48000, tracks, bit_depth=bits)
+        fs, frames = read_wav_pcm(path)
+        assert frames.shape == (tracks.shape[1], 4) and frames.dtype == (np.int32 if bits == 32 else np.int16)
+        h = HRIR(e)
+        h.open_recording(path, ["FL", "FR"])
+        fs2, rec = read_wav(path, expand=True)
+        ref = ingest_recording(e, 48000, fs2, rec, ["FL", "FR"])           # float path of the product
+        for sp in ("FL", "FR"):
+            for sd in ("left", "right"):
+                a, b = h.irs[sp][sd], ref[sp][sd]
+                assert np.array_equal(a.recording, b.recording)            # identical float64 columns
+                o = estimate(b.recording, e.inverse_filter)
+                assert rel(a.data, o) <= tol and rel(b.data, o) <= tol
+                assert a.peak_index() == b.peak_index()
+    (tmp_path / "f24.wav").write_bytes(b"")                                # 24-bit falls back to the float reader
+    write_wav(str(tmp_path / "f24.wav"), 48000, tracks[:, : 2 * 48000 + len(e) + 96000], bit_depth=24)
+    assert read_wav_pcm(str(tmp_path / "f24.wav")) is None
+    h = HRIR(e)
+    h.open_recording(str(tmp_path / "f24.wav"), ["FL", "FR"])
+    assert set(h.irs) == {"FL", "FR"}
