@@ -33,6 +33,18 @@ def needs_build():
     return False
 
 
+def build_variant(name, defines):
+    """Diagnostic builds (tools/): csrc/libimpulse_hip_<name>.so with extra -D flags."""
+    out = os.path.join(CSRC, f"libimpulse_hip_{name}.so")
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
+    cmd += [f"-D{d}" for d in defines] + SOURCES + ["-o", out]
+    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError(f"hipcc failed building {out}")
+    return out
+
+
 def build_library(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
@@ -51,4 +63,8 @@ def build_library(force=False, verbose=False):
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+        sys.exit(0)
     print(build_library(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

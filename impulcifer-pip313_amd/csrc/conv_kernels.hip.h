@@ -340,6 +340,16 @@ __device__ __forceinline__ void bstore_cf(cf v, __amdgpu_buffer_rsrc_t r, unsign
   __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
 }
 
+// W = alpha z + beta conj(zp) in four packed instructions (alpha = ab.xy, beta = ab.zw)
+__device__ __forceinline__ cf filter_bin(float4 ab, cf z, cf zp) {
+  const v2f al = {ab.x, ab.y}, be = {ab.z, ab.w};
+  v2f t = to_v(cmul(z, to_c(al))), w;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(to_v(zp)), "v"(be), "v"(t));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]"
+      : "=v"(w) : "v"(to_v(zp)), "v"(be), "v"(t));
+  return to_c(w);
+}
+
 // Orders this wave's LDS traffic (all earlier DS ops retired, nothing moved across by the
 // compiler) without stalling the other waves of the workgroup.
 __device__ __forceinline__ void wave_lds_fence() {
@@ -349,9 +359,33 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifdef IMP_PHASE_TRACE
+// Diagnostic build only (tools/phase_trace.py): per-workgroup phase timestamps of wave 0.
+__device__ unsigned long long g_phase_trace[8192 * 16];
+#define IMP_MARK(i)                                                                       \
+  do {                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_phase_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define IMP_MARK_MEM(i)                                   \
+  do {                                                    \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
+    IMP_MARK(i);                                          \
+  } while (0)
+#define IMP_MARK_WALL(i)                                                                  \
+  do {                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_phase_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define IMP_MARK(i)
+#define IMP_MARK_MEM(i)
+#define IMP_MARK_WALL(i)
+#endif
+
 __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cf* lds = reinterpret_cast<cf*>(smem_raw);
+  IMP_MARK_WALL(12);
+  IMP_MARK(0);
 
   const int tid = threadIdx.x;
   // a wave never straddles the two rows: everything derived from `half` is wave-uniform (SGPRs)
@@ -381,6 +415,7 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   cf v[16], u[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) v[j] = bload_cf(r_row, vo8, j * 256 * 8);
+  IMP_MARK_MEM(1);
 
   // ---- forward FFT4096 ----
   fft16<-1>(v);                                            // over j -> a
@@ -389,6 +424,7 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
 #pragma unroll
   for (int a = 0; a < 16; ++a) buf[a * kRowPad + t] = v[a];
   __syncthreads();
+  IMP_MARK(2);
   // thread (ka = hi4, t2 = lo4) gathers j2 = 0..15 (t = 16 j2 + t2)
 #pragma unroll
   for (int j2 = 0; j2 < 16; ++j2) u[j2] = buf[hi4 * kRowPad + 16 * j2 + lo4];
@@ -408,6 +444,7 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   for (int t2 = 0; t2 < 16; ++t2) v[t2] = buf[hi4 * kRowPad + t2 * 17 + lo4];
   fft16<-1>(v);                                            // over t2 -> kb2
   __syncthreads();
+  IMP_MARK(3);
 
   // ---- partner exchange: plane [kb2][u] ----
 #pragma unroll
@@ -426,6 +463,7 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
     const unsigned pk2 = (k1 != 0) ? (4095u - k2) : ((4096u - k2) & 4095u);
     u[q] = pbuf[(pk2 >> 8) * kRowPad + 16 * (pk2 & 15u) + ((pk2 >> 4) & 15u)];
   }
+  IMP_MARK(4);
   // bin 0 of the packed transform carries DC and Nyquist: ab.x = H[0]/Nc, ab.z = H[Nc]/Nc
   const bool dc_lane = (k1 == 0) && (t == 0);
   cf w_dc = make_float2(0.f, 0.f);
@@ -437,15 +475,12 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   // W = alpha Z + beta conj(Z[Nc-k]), in place
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    const float4 ab = bload_f4(r_ab, vo16, q * 256 * 16);
-    const cf z = v[q], zp = u[q];
-    cf w;
-    w.x = ab.x * z.x - ab.y * z.y + ab.z * zp.x + ab.w * zp.y;
-    w.y = ab.x * z.y + ab.y * z.x + ab.w * zp.x - ab.z * zp.y;
-    v[q] = w;
+    v[q] = filter_bin(bload_f4(r_ab, vo16, q * 256 * 16), v[q], u[q]);
   }
   if (dc_lane) v[0] = w_dc;
+  IMP_MARK_MEM(5);
   __syncthreads();
+  IMP_MARK(6);
 
   // ---- inverse FFT4096 (mirror) ----
   fft16<+1>(v);                                            // over kb2 -> t2
@@ -464,11 +499,18 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
 #pragma unroll
   for (int j2 = 0; j2 < 16; ++j2) buf[hi4 * kRowPad + 16 * j2 + lo4] = u[j2];
   __syncthreads();
+  IMP_MARK(7);
 #pragma unroll
   for (int a = 0; a < 16; ++a) v[a] = buf[a * kRowPad + t];
   fft16<+1>(v);                                            // over ka -> j
+  IMP_MARK(8);
 #pragma unroll
   for (int j = 0; j < 16; ++j) bstore_cf(v[j], r_row, vo8, j * 256 * 8);
+  IMP_MARK_MEM(9);
+  IMP_MARK_WALL(13);
+#ifdef IMP_PHASE_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_phase_trace[blockIdx.x * 16 + 14] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+#endif
 }
 
 }  // namespace imp

@@ -1,6 +1,13 @@
-// In-register radix-2/4/8/16 butterflies for gfx950 (wave64, fp32).
+// In-register radix-2/3/4/5/8/16 butterflies for gfx950 (wave64, fp32).
 // Every array index below is a compile-time constant after unrolling, so the
 // 16 complex values of a thread stay in VGPRs (32 regs) - no scratch.
+//
+// The row and column passes are VALU-issue bound (tools/phase_trace.py: ~75 % of a row workgroup's
+// life is butterflies), so on the device every complex primitive is ONE or TWO packed-fp32 VOP3P
+// instructions (v_pk_add/mul/fma_f32) whose op_sel / neg modifiers do the re<->im swaps and sign
+// flips that a multiply by +-i or by a twiddle needs: complex add = 1, a +- i b = 1, complex
+// multiply = 2.  Left to itself the compiler spends 4 instructions per complex multiply plus
+// v_mov/v_xor shuffles.  The host versions (same rounding sequence) serve the CPU unit test.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -8,16 +15,67 @@ namespace imp {
 
 typedef float2 cf;  // complex fp32: .x = re, .y = im
 
-__host__ __device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
-__host__ __device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
-__host__ __device__ __forceinline__ cf cmul(cf a, cf b) {
-  return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+// Target overloads: the __device__ versions are packed VOP3P, the __host__ ones plain C++.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f to_v(cf a) { return __builtin_bit_cast(v2f, a); }
+__device__ __forceinline__ cf to_c(v2f a) { return __builtin_bit_cast(cf, a); }
+// op_sel[i] / op_sel_hi[i]: which half of source i feeds the low / high result lane (0 = .x, 1 = .y)
+#define IMP_PK2(op, mods)                                                     \
+  v2f r;                                                                      \
+  asm(op " %0, %1, %2 " mods : "=v"(r) : "v"(to_v(a)), "v"(to_v(b)));         \
+  return to_c(r)
+__device__ __forceinline__ cf cadd(cf a, cf b) { IMP_PK2("v_pk_add_f32", ""); }
+__device__ __forceinline__ cf csub(cf a, cf b) { IMP_PK2("v_pk_add_f32", "neg_lo:[0,1] neg_hi:[0,1]"); }
+// a - i b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ cf cadd_mi(cf a, cf b) { IMP_PK2("v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"); }
+// a + i b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ cf cadd_pi(cf a, cf b) { IMP_PK2("v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"); }
+#undef IMP_PK2
+// a * b: t = (a.y b.y, a.y b.x); r = (a.x b.x - t.x, a.x b.y + t.y)
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(to_v(a)), "v"(to_v(b)));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+      : "=v"(r) : "v"(to_v(a)), "v"(to_v(b)), "v"(t));
+  return to_c(r);
 }
-// a * conj(b)
-__host__ __device__ __forceinline__ cf cmulc(cf a, cf b) {
-  return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -a.x * b.y));
+// a * conj(b): t = (a.y b.y, a.x b.y); r = (a.x b.x + t.x, a.y b.x - t.y)
+__device__ __forceinline__ cf cmulc(cf a, cf b) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(t) : "v"(to_v(a)), "v"(to_v(b)));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]"
+      : "=v"(r) : "v"(to_v(a)), "v"(to_v(b)), "v"(t));
+  return to_c(r);
 }
+// a + s * b with a real pair s = (s0, s1) applied component-wise
+__device__ __forceinline__ cf cfma_real(cf b, cf s, cf a) {
+  v2f r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(to_v(b)), "v"(to_v(s)), "v"(to_v(a)));
+  return to_c(r);
+}
+__device__ __forceinline__ cf cmul_real(cf b, cf s) {
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(to_v(b)), "v"(to_v(s)));
+  return to_c(r);
+}
+__host__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__host__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+__host__ __forceinline__ cf cadd_mi(cf a, cf b) { return make_float2(a.x + b.y, a.y - b.x); }
+__host__ __forceinline__ cf cadd_pi(cf a, cf b) { return make_float2(a.x - b.y, a.y + b.x); }
+__host__ __forceinline__ cf cmul(cf a, cf b) {
+  return make_float2(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x));
+}
+__host__ __forceinline__ cf cmulc(cf a, cf b) {
+  return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.y, b.x, -(a.x * b.y)));
+}
+__host__ __forceinline__ cf cfma_real(cf b, cf s, cf a) { return make_float2(fmaf(b.x, s.x, a.x), fmaf(b.y, s.y, a.y)); }
+__host__ __forceinline__ cf cmul_real(cf b, cf s) { return make_float2(b.x * s.x, b.y * s.y); }
 __host__ __device__ __forceinline__ cf cconj(cf a) { return make_float2(a.x, -a.y); }
+// a -+ i b: forward (DIR < 0) rotates by -i, inverse by +i
+template <int DIR>
+__host__ __device__ __forceinline__ cf cadd_rot(cf a, cf b) { return DIR < 0 ? cadd_mi(a, b) : cadd_pi(a, b); }
+template <int DIR>
+__host__ __device__ __forceinline__ cf csub_rot(cf a, cf b) { return DIR < 0 ? cadd_pi(a, b) : cadd_mi(a, b); }
 // multiply by twiddle w (forward table value); DIR<0 -> a*w, DIR>0 -> a*conj(w)
 template <int DIR>
 __host__ __device__ __forceinline__ cf ctw(cf a, cf w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
@@ -29,41 +87,51 @@ __host__ __device__ __forceinline__ void bfly2(cf& a, cf& b) {
   a = cadd(t, b);
   b = csub(t, b);
 }
+// bfly2 on (a, w b) with w = -i (forward) / +i (inverse) folded into the adds
+template <int DIR>
+__host__ __device__ __forceinline__ void bfly2_rot(cf& a, cf& b) {
+  cf t = a;
+  a = cadd_rot<DIR>(t, b);
+  b = csub_rot<DIR>(t, b);
+}
 
 template <int DIR>
 __host__ __device__ __forceinline__ void bfly4(cf& a, cf& b, cf& c, cf& d) {
-  cf t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
-  // forward: (-i)*t3 ; inverse: (+i)*t3
-  cf r3 = DIR < 0 ? make_float2(t3.y, -t3.x) : make_float2(-t3.y, t3.x);
+  const cf t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
   a = cadd(t0, t2);
-  b = cadd(t1, r3);
+  b = cadd_rot<DIR>(t1, t3);   // t1 -+ i t3
   c = csub(t0, t2);
-  d = csub(t1, r3);
+  d = csub_rot<DIR>(t1, t3);
+}
+// bfly4 on (a, b, w c, d) with w = -i (forward) / +i (inverse) folded into the first adds
+template <int DIR>
+__host__ __device__ __forceinline__ void bfly4_crot(cf& a, cf& b, cf& c, cf& d) {
+  const cf t0 = cadd_rot<DIR>(a, c), t1 = csub_rot<DIR>(a, c), t2 = cadd(b, d), t3 = csub(b, d);
+  a = cadd(t0, t2);
+  b = cadd_rot<DIR>(t1, t3);
+  c = csub(t0, t2);
+  d = csub_rot<DIR>(t1, t3);
 }
 
-// multiply by exp(DIR * 2 pi i * m / 16) with compile-time m
+// multiply by exp(DIR * 2 pi i * m / 16) with compile-time m (m = 4, 12 are folded into butterflies
+// by the callers; the values below are the forward twiddle cr - i sf, conjugated for the inverse)
 template <int DIR, int M>
 __host__ __device__ __forceinline__ cf mul_w16(cf a) {
   constexpr float C1 = 0.92387953251128675613f;  // cos(pi/8)
   constexpr float S1 = 0.38268343236508977173f;  // sin(pi/8)
   constexpr float R = 0.70710678118654752440f;   // sqrt(1/2)
   constexpr int m = M & 15;
-  // forward value w = (cr, -si); inverse = conj
-  constexpr float cr = (m == 0) ? 1.f : (m == 1) ? C1 : (m == 2) ? R : (m == 3) ? S1 : (m == 4) ? 0.f
-                     : (m == 5) ? -S1 : (m == 6) ? -R : (m == 7) ? -C1 : (m == 8) ? -1.f
-                     : (m == 9) ? -C1 : (m == 10) ? -R : (m == 11) ? -S1 : (m == 12) ? 0.f
+  static_assert(m != 4 && m != 8 && m != 12, "rotations by +-i and -1 belong in the butterfly");
+  constexpr float cr = (m == 0) ? 1.f : (m == 1) ? C1 : (m == 2) ? R : (m == 3) ? S1
+                     : (m == 5) ? -S1 : (m == 6) ? -R : (m == 7) ? -C1
+                     : (m == 9) ? -C1 : (m == 10) ? -R : (m == 11) ? -S1
                      : (m == 13) ? S1 : (m == 14) ? R : C1;
-  constexpr float sf = (m == 0) ? 0.f : (m == 1) ? S1 : (m == 2) ? R : (m == 3) ? C1 : (m == 4) ? 1.f
-                     : (m == 5) ? C1 : (m == 6) ? R : (m == 7) ? S1 : (m == 8) ? 0.f
-                     : (m == 9) ? -S1 : (m == 10) ? -R : (m == 11) ? -C1 : (m == 12) ? -1.f
+  constexpr float sf = (m == 0) ? 0.f : (m == 1) ? S1 : (m == 2) ? R : (m == 3) ? C1
+                     : (m == 5) ? C1 : (m == 6) ? R : (m == 7) ? S1
+                     : (m == 9) ? -S1 : (m == 10) ? -R : (m == 11) ? -C1
                      : (m == 13) ? -C1 : (m == 14) ? -R : -S1;
-  // forward twiddle = cr - i*sf ; inverse = cr + i*sf
-  constexpr float wi = DIR < 0 ? -sf : sf;
   if constexpr (m == 0) return a;
-  else if constexpr (m == 4) return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
-  else if constexpr (m == 8) return make_float2(-a.x, -a.y);
-  else if constexpr (m == 12) return DIR < 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
-  else return make_float2(fmaf(a.x, cr, -a.y * wi), fmaf(a.x, wi, a.y * cr));
+  else return ctw<DIR>(a, make_float2(cr, -sf));
 }
 
 // 16-point DFT, natural order in / natural order out.
@@ -72,18 +140,19 @@ __host__ __device__ __forceinline__ void fft16(cf (&v)[16]) {
   // n = 4*n1 + n2 ; k = k1 + 4*k2
 #pragma unroll
   for (int n2 = 0; n2 < 4; ++n2) bfly4<DIR>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
-  // now v[4*k1 + n2] = A[n2][k1]; twiddle w16^(n2*k1)
+  // now v[4*k1 + n2] = A[n2][k1]; twiddle w16^(n2*k1); w16^4 = -+i goes into the butterfly of k1 = 2
   v[4 * 1 + 1] = mul_w16<DIR, 1>(v[4 * 1 + 1]);
   v[4 * 1 + 2] = mul_w16<DIR, 2>(v[4 * 1 + 2]);
   v[4 * 1 + 3] = mul_w16<DIR, 3>(v[4 * 1 + 3]);
   v[4 * 2 + 1] = mul_w16<DIR, 2>(v[4 * 2 + 1]);
-  v[4 * 2 + 2] = mul_w16<DIR, 4>(v[4 * 2 + 2]);
   v[4 * 2 + 3] = mul_w16<DIR, 6>(v[4 * 2 + 3]);
   v[4 * 3 + 1] = mul_w16<DIR, 3>(v[4 * 3 + 1]);
   v[4 * 3 + 2] = mul_w16<DIR, 6>(v[4 * 3 + 2]);
   v[4 * 3 + 3] = mul_w16<DIR, 9>(v[4 * 3 + 3]);
-#pragma unroll
-  for (int k1 = 0; k1 < 4; ++k1) bfly4<DIR>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+  bfly4<DIR>(v[0], v[1], v[2], v[3]);
+  bfly4<DIR>(v[4], v[5], v[6], v[7]);
+  bfly4_crot<DIR>(v[8], v[9], v[10], v[11]);
+  bfly4<DIR>(v[12], v[13], v[14], v[15]);
   // v[4*k1 + k2] = X[k1 + 4*k2] -> transpose the 4x4 index grid
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -102,11 +171,10 @@ __host__ __device__ __forceinline__ void fft8(cf& x0, cf& x1, cf& x2, cf& x3, cf
   bfly4<DIR>(x0, x2, x4, x6);   // n2 = 0 -> A[0][k1] in x0,x2,x4,x6
   bfly4<DIR>(x1, x3, x5, x7);   // n2 = 1 -> A[1][k1] in x1,x3,x5,x7
   x3 = mul_w16<DIR, 2>(x3);     // w8^1
-  x5 = mul_w16<DIR, 4>(x5);     // w8^2
   x7 = mul_w16<DIR, 6>(x7);     // w8^3
   bfly2<DIR>(x0, x1);           // k1=0: X[0], X[4]
   bfly2<DIR>(x2, x3);           // k1=1: X[1], X[5]
-  bfly2<DIR>(x4, x5);           // k1=2: X[2], X[6]
+  bfly2_rot<DIR>(x4, x5);       // k1=2: X[2], X[6] with w8^2 = -+i folded in
   bfly2<DIR>(x6, x7);           // k1=3: X[3], X[7]
   // currently: x0=X0 x1=X4 x2=X1 x3=X5 x4=X2 x5=X6 x6=X3 x7=X7
   cf t1 = x1, t2 = x2, t3 = x3, t4 = x4, t5 = x5, t6 = x6;
@@ -139,13 +207,11 @@ template <int DIR>
 __host__ __device__ __forceinline__ void bfly3(cf& a, cf& b, cf& c) {
   constexpr float S = 0.86602540378443864676f;      // sin(2 pi / 3)
   const cf t1 = cadd(b, c);
-  const cf m1 = make_float2(a.x - 0.5f * t1.x, a.y - 0.5f * t1.y);
-  const cf d = csub(b, c);
-  // forward: -i*S*d ; inverse: +i*S*d
-  const cf t2 = DIR < 0 ? make_float2(S * d.y, -S * d.x) : make_float2(-S * d.y, S * d.x);
+  const cf m1 = cfma_real(t1, make_float2(-0.5f, -0.5f), a);
+  const cf d = cmul_real(csub(b, c), make_float2(S, S));
   a = cadd(a, t1);
-  b = cadd(m1, t2);
-  c = csub(m1, t2);
+  b = cadd_rot<DIR>(m1, d);    // m1 -+ i S d
+  c = csub_rot<DIR>(m1, d);
 }
 
 template <int DIR>
@@ -154,19 +220,18 @@ __host__ __device__ __forceinline__ void bfly5(cf& a, cf& b, cf& c, cf& d, cf& e
   constexpr float C2 = -0.80901699437494742410f;    // cos(4 pi / 5)
   constexpr float S1 = 0.95105651629515357212f;     // sin(2 pi / 5)
   constexpr float S2 = 0.58778525229247312917f;     // sin(4 pi / 5)
+  const cf c1 = make_float2(C1, C1), c2 = make_float2(C2, C2), s1 = make_float2(S1, S1), s2 = make_float2(S2, S2);
   const cf t1 = cadd(b, e), t2 = cadd(c, d), t3 = csub(b, e), t4 = csub(c, d);
-  const cf m1 = make_float2(a.x + C1 * t1.x + C2 * t2.x, a.y + C1 * t1.y + C2 * t2.y);
-  const cf m2 = make_float2(a.x + C2 * t1.x + C1 * t2.x, a.y + C2 * t1.y + C1 * t2.y);
-  const cf n1 = make_float2(S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y);
-  const cf n2 = make_float2(S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y);
+  const cf m1 = cfma_real(t2, c2, cfma_real(t1, c1, a));
+  const cf m2 = cfma_real(t2, c1, cfma_real(t1, c2, a));
+  const cf n1 = cfma_real(t4, s2, cmul_real(t3, s1));
+  const cf n2 = cfma_real(t4, make_float2(-S1, -S1), cmul_real(t3, s2));
   // forward: X1 = m1 - i n1, X4 = m1 + i n1, X2 = m2 - i n2, X3 = m2 + i n2 ; inverse: signs swapped
-  const cf r1 = DIR < 0 ? make_float2(n1.y, -n1.x) : make_float2(-n1.y, n1.x);   // (-/+ i) n1
-  const cf r2 = DIR < 0 ? make_float2(n2.y, -n2.x) : make_float2(-n2.y, n2.x);
   a = cadd(a, cadd(t1, t2));
-  b = cadd(m1, r1);
-  e = csub(m1, r1);
-  c = cadd(m2, r2);
-  d = csub(m2, r2);
+  b = cadd_rot<DIR>(m1, n1);
+  e = csub_rot<DIR>(m1, n1);
+  c = cadd_rot<DIR>(m2, n2);
+  d = csub_rot<DIR>(m2, n2);
 }
 
 // R-point DFT of x[0..R-1] in place, natural order in and out, R in {3, 5, 6, 10, 12}.

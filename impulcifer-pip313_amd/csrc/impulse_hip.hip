@@ -1013,3 +1013,13 @@ extern "C" int imp_apply_window(imp_ctx* ctx, float* x, const int64_t* off, cons
     return cleanup(fail(IMP_ERR_HIP, "imp_apply_window: d2h copy failed"));
   return cleanup(IMP_OK);
 }
+
+#ifdef IMP_PHASE_TRACE
+// Diagnostic build only (not in include/impulse_hip.h): copies the rows-kernel phase marks to the host.
+extern "C" int imp_debug_phase_trace(unsigned long long* out, int64_t n_words) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(imp::g_phase_trace), (size_t)n_words * sizeof(unsigned long long), 0,
+                          hipMemcpyDeviceToHost) != hipSuccess)
+    return IMP_ERR_HIP;
+  return IMP_OK;
+}
+#endif
