@@ -21,6 +21,10 @@ namespace imp {
 constexpr int kN2 = 4096;        // row length (complex points)
 constexpr int kLogN2 = 12;
 constexpr int kRowPad = 272;     // LDS row pitch (float2) of the 16x256 exchange planes
+#ifndef IMP_AB_PREFETCH
+#define IMP_AB_PREFETCH 8
+#endif
+constexpr int kAbPrefetch = IMP_AB_PREFETCH;   // alpha/beta bins fetched before the partner exchange (register budget)
 
 // ---------------------------------------------------------------------------------------------
 // Twiddle tables (device, fp32 rounded from fp64 on the host).  Every table is laid out in the
@@ -51,44 +55,77 @@ __device__ __forceinline__ void xcd_work_item(int nchan, int& tile, int& chan) {
   tile = tl * 8 + xcd;
 }
 
+// Raw buffer (SRSRC) addressing.  Every global access of the three passes is a buffer instruction:
+// one 32-bit VGPR offset per thread + a scalar offset per element instead of 64-bit VGPR address
+// pairs (rows: 138 VGPRs -> spills; columns: two thirds of the VALU work was address arithmetic
+// and bounds branches), and the hardware range check does the zero fill and the crop:
+//   * a load whose offset is >= num_records returns 0 without touching memory,
+//   * an out-of-range store is dropped,
+//   * both per dword, so a dwordx2 straddling the end keeps its valid half,
+//   * voffset and soffset both take part; a voffset that is itself out of range (e.g. negative) is
+//     out of range whatever soffset adds (tools/probes/buffer_oob_probe.hip, measured on gfx950).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ cf bload_cf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
+}
+__device__ __forceinline__ float bload_f(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float4 bload_f4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+}
+__device__ __forceinline__ void bstore_cf(cf v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  u32x2 x;
+  x.x = __float_as_uint(v.x);
+  x.y = __float_as_uint(v.y);
+  __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
+}
+
 // ---------------------------------------------------------------------------------------------
-// Loaders / storers for the column passes.  n1 = row (0..N1), n2 = column (0..4096).
+// Loaders / storers for the column passes.  A column thread owns 16 complex points
+//   e_j = e0 + j * step      (complex index n1*4096 + n2; e0 per thread, step wave-uniform)
+// `column<STEP>(b, e0, v)` fetches them for channel b (b is wave-uniform).
 // ---------------------------------------------------------------------------------------------
 
-// Real channel, planar [B][ld] or interleaved frames [L][C] (elem_stride = C, chan offset folded
-// into the base): z = (x[2n], x[2n+1]) with zero fill beyond `len`.
+// Real fp32 channel, planar [B][ld] (elem_stride 1) or interleaved frames [L][C] (elem_stride = C,
+// the channel offset folded into the base): z = (x[2n], x[2n+1]), zero beyond `len`.
 struct LoadRealPacked {
   const float* __restrict__ base;   // channel 0, sample 0
   long long chan_stride;            // elements between channels
   long long elem_stride;            // elements between consecutive samples of a channel
   long long len;                    // valid samples per channel
-  __device__ __forceinline__ cf operator()(int b, int n1, int n2) const {
-    long long n = ((long long)n1 << kLogN2) + n2;
-    long long i0 = 2 * n;
+  template <int STEP>
+  __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[16]) const {
     const float* p = base + (long long)b * chan_stride;
-    cf z = make_float2(0.f, 0.f);
-    if (i0 + 1 < len) {
-      if (elem_stride == 1 && ((reinterpret_cast<uintptr_t>(p + i0) & 7u) == 0)) {
-        z = *reinterpret_cast<const float2*>(p + i0);
-      } else {
-        z.x = p[i0 * elem_stride];
-        z.y = p[(i0 + 1) * elem_stride];
+    if (elem_stride == 1) {
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(p, (unsigned)len * 4u);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = bload_cf(r, e0 * 8u, (unsigned)(j * STEP) * 8u);
+    } else {
+      const unsigned es = (unsigned)elem_stride * 4u;                          // bytes between samples
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(p, ((unsigned)(len - 1) * (unsigned)elem_stride + 1u) * 4u);
+      const unsigned vo = 2u * e0 * es;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const unsigned so = 2u * (unsigned)(j * STEP) * es;
+        v[j].x = bload_f(r, vo, so);
+        v[j].y = bload_f(r, vo, so + es);
       }
-    } else if (i0 < len) {
-      z.x = p[i0 * elem_stride];
     }
-    return z;
-  }
-  // rows n1 >= this are entirely zero: skip their loads
-  __device__ __forceinline__ int live_rows() const {
-    long long nz = (len + 1) / 2;                       // complex points with data
-    return (int)((nz + kN2 - 1) >> kLogN2);
   }
 };
 
-// Raw PCM frames as they sit in a WAV file: sample i of channel c at base[(i*elem_stride) + c*chan_stride]
+// Raw PCM frames as they sit in a WAV file: sample i of channel c at base[i*elem_stride + c*chan_stride]
 // (interleaved: elem_stride = tracks, chan_stride = 1), int32 or int16, scaled to [-1, 1) by 2^-(bits-1)
 // exactly like soundfile/libsndfile and the reference's reader do (core/audio_truehd.py:153-185).
+// int -> float is exact for 16-bit and rounds 32-bit PCM to fp32 (the device dtype).
 template <class Sample>
 struct LoadPcmPacked {
   const Sample* __restrict__ base;
@@ -96,58 +133,93 @@ struct LoadPcmPacked {
   long long elem_stride;
   long long len;
   float scale;
-  __device__ __forceinline__ cf operator()(int b, int n1, int n2) const {
-    const long long i0 = 2 * (((long long)n1 << kLogN2) + n2);
-    const Sample* p = base + (long long)b * chan_stride;
-    cf z = make_float2(0.f, 0.f);
-    // int -> float conversion is exact for 16-bit and rounds 32-bit PCM to fp32 (the device dtype)
-    if (i0 < len) z.x = (float)p[i0 * elem_stride] * scale;
-    if (i0 + 1 < len) z.y = (float)p[(i0 + 1) * elem_stride] * scale;
-    return z;
+  __device__ __forceinline__ float sample(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) const {
+    if constexpr (sizeof(Sample) == 2) return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(r, vo, so, 0) * scale;
+    else return (float)(int)__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0) * scale;
   }
-  __device__ __forceinline__ int live_rows() const {
-    const long long nz = (len + 1) / 2;
-    return (int)((nz + kN2 - 1) >> kLogN2);
+  template <int STEP>
+  __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[16]) const {
+    const Sample* p = base + (long long)b * chan_stride;
+    const unsigned es = (unsigned)elem_stride * (unsigned)sizeof(Sample);
+    const __amdgpu_buffer_rsrc_t r =
+        make_rsrc(p, ((unsigned)(len - 1) * (unsigned)elem_stride + 1u) * (unsigned)sizeof(Sample));
+    const unsigned vo = 2u * e0 * es;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const unsigned so = 2u * (unsigned)(j * STEP) * es;
+      v[j].x = sample(r, vo, so);
+      v[j].y = sample(r, vo, so + es);
+    }
   }
 };
 
 struct LoadWorkspace {
   const cf* __restrict__ ws;   // [B][N1][4096]
   int n1_total;
-  __device__ __forceinline__ cf operator()(int b, int n1, int n2) const {
-    return ws[((long long)b * n1_total + n1) * kN2 + n2];
+  template <int STEP>
+  __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[16]) const {
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(ws + (long long)b * n1_total * kN2, (unsigned)n1_total * kN2 * 8u);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = bload_cf(r, e0 * 8u, (unsigned)(j * STEP) * 8u);
   }
-  __device__ __forceinline__ int live_rows() const { return n1_total; }
 };
 
+// Storers: bind(b) gives the channel's buffer; put(r, e, step_elems, v) writes complex point e + step_elems
+// (e per thread, step_elems a compile-time multiple of 4096).
 struct StoreWorkspace {
   cf* __restrict__ ws;
   int n1_total;
-  __device__ __forceinline__ void operator()(int b, int k1, int n2, cf v) const {
-    ws[((long long)b * n1_total + k1) * kN2 + n2] = v;
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind(int b) const {
+    return make_rsrc(ws + (long long)b * n1_total * kN2, (unsigned)n1_total * kN2 * 8u);
+  }
+  __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, unsigned e, unsigned step_elems, cf v) const {
+    bstore_cf(v, r, e * 8u, step_elems * 8u);
   }
 };
 
 // Unpack y[2n] = re, y[2n+1] = im and keep the window [start, start+len) of the linear
-// convolution ('same': start = (M-1)/2, len = L; 'full': start = 0, len = L+M-1).
+// convolution ('same': start = (M-1)/2, len = L; 'full': start = 0, len = L+M-1).  The crop is the
+// buffer's range check: sample 2n - start as an unsigned byte offset is out of range on both sides.
 struct StoreRealCrop {
   float* __restrict__ base;
   long long chan_stride;
-  long long elem_stride;
   long long start;
   long long len;
-  __device__ __forceinline__ void operator()(int b, int n1, int n2, cf v) const {
-    long long n = ((long long)n1 << kLogN2) + n2;
-    long long i0 = 2 * n - start;
-    float* p = base + (long long)b * chan_stride;
-    if (i0 >= 0 && i0 + 1 < len && elem_stride == 1 && ((reinterpret_cast<uintptr_t>(p + i0) & 7u) == 0)) {
-      *reinterpret_cast<float2*>(p + i0) = v;
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind(int b) const {
+    return make_rsrc(base + (long long)b * chan_stride, (unsigned)len * 4u);
+  }
+  __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, unsigned e, unsigned step_elems, cf v) const {
+    // the whole offset goes through the VGPR: a negative voffset stays out of range whatever soffset adds
+    const unsigned off = (2u * (e + step_elems) - (unsigned)start) * 4u;
+    if (start & 1) {
+      // odd start: one point straddles y[-1] | y[0]; two dword stores let the range check split it.
+      // The second offset is made opaque so that the two are not merged back into one dwordx2,
+      // which is dropped whole when its voffset is negative (measured).
+      unsigned off_im = off + 4u;
+      asm volatile("" : "+v"(off_im));
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), r, off, 0u, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), r, off_im, 0u, 0);
     } else {
-      if (i0 >= 0 && i0 < len) p[i0 * elem_stride] = v.x;
-      if (i0 + 1 >= 0 && i0 + 1 < len) p[(i0 + 1) * elem_stride] = v.y;
+      bstore_cf(v, r, off, 0u);
     }
   }
 };
+
+// wave-uniform twiddle (SGPR pair): one VOP3P may read one scalar pair, so the multiply needs no copy
+template <int DIR>
+__device__ __forceinline__ cf ctw_uniform(cf a, cf w) {
+  v2f t, r;
+  if constexpr (DIR < 0) {
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(to_v(a)), "s"(to_v(w)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+        : "=v"(r) : "v"(to_v(a)), "s"(to_v(w)), "v"(t));
+  } else {
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(t) : "v"(to_v(a)), "s"(to_v(w)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_hi:[0,0,1]"
+        : "=v"(r) : "v"(to_v(a)), "s"(to_v(w)), "v"(t));
+  }
+  return to_c(r);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Column pass.  Tile = TC columns x N1 rows, one thread = 16 rows of one column.
@@ -165,12 +237,33 @@ struct ColsCfg {
   static constexpr size_t lds_bytes = (R2 > 1) ? sizeof(cf) * 16 * T : 0;
 };
 
+// first stage shared by both column kernels: fetch, (inverse: conj four-step twiddle,) FFT16, w_N1^(g a)
+template <int R2, int TC, int DIR, class Load>
+__device__ __forceinline__ void cols_first_stage(const Load& ld, const Twiddles& tw, __amdgpu_buffer_rsrc_t r_full,
+                                                 int b, int g, unsigned e0, cf (&v)[16]) {
+  ld.template column<R2 * kN2>(b, e0, v);
+  if constexpr (DIR > 0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = cmulc(v[j], bload_cf(r_full, e0 * 8u, (unsigned)(j * R2 * kN2) * 8u));
+  }
+  fft16<DIR>(v);   // index a
+  if constexpr (R2 > 1) {
+    // w_N1^(g a) = hi[4 g a]  (Nc/1024 = 4 N1 entries); g is wave-uniform for 64-column tiles
+    if constexpr (TC == 64) {
+      const int gu = __builtin_amdgcn_readfirstlane(g);
+#pragma unroll
+      for (int a = 1; a < 16; ++a) v[a] = ctw_uniform<DIR>(v[a], tw.hi[4 * gu * a]);
+    } else {
+#pragma unroll
+      for (int a = 1; a < 16; ++a) v[a] = ctw<DIR>(v[a], tw.hi[4 * g * a]);
+    }
+  }
+}
+
 template <int R2, int DIR, class Load, class Store>
-__global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st, Twiddles tw,
-                                                                int nchan) {
+__global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st, Twiddles tw, int nchan, int n1_total) {
   using Cfg = ColsCfg<R2>;
   constexpr int TC = Cfg::TC, T = Cfg::T, G = Cfg::G;
-  constexpr int N1 = 16 * R2;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cf* buf = reinterpret_cast<cf*>(smem_raw);
 
@@ -179,28 +272,14 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
   const int g = tid / TC;
   int b, tile;
   xcd_work_item(nchan, tile, b);
-  const int n2 = tile * TC + c;
+  const unsigned n2 = (unsigned)(tile * TC + c);
+  const __amdgpu_buffer_rsrc_t r_full = make_rsrc(tw.full, (unsigned)n1_total * kN2 * 8u);
+  const __amdgpu_buffer_rsrc_t r_out = st.bind(b);
 
   cf v[16];
-  const int live = ld.live_rows();
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int row = g + R2 * j;
-    cf z = make_float2(0.f, 0.f);
-    if (row < live) {
-      z = ld(b, row, n2);
-      if constexpr (DIR > 0) z = cmulc(z, tw.full[row * kN2 + n2]);
-    }
-    v[j] = z;
-  }
-
-  fft16<DIR>(v);   // index a
+  cols_first_stage<R2, TC, DIR>(ld, tw, r_full, b, g, (unsigned)g * kN2 + n2, v);
 
   if constexpr (R2 > 1) {
-    // w_N1^(g a) = hi[4 g a]  (Nc/1024 = 4 N1 entries); g is wave-uniform for 64-column tiles
-    const int gu = (TC == 64) ? __builtin_amdgcn_readfirstlane(g) : g;
-#pragma unroll
-    for (int a = 1; a < 16; ++a) v[a] = ctw<DIR>(v[a], tw.hi[4 * gu * a]);
 #pragma unroll
     for (int a = 0; a < 16; ++a) buf[a * T + tid] = v[a];
     __syncthreads();
@@ -210,24 +289,18 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
 #pragma unroll
       for (int gp = 0; gp < R2; ++gp) v[i * R2 + gp] = buf[(g * G + i) * T + gp * TC + c];
     fft_groups<DIR, R2>(v);
+  }
+  constexpr int GG = (R2 > 1) ? G : 16, KB = (R2 > 1) ? R2 : 1;
 #pragma unroll
-    for (int i = 0; i < G; ++i)
+  for (int i = 0; i < GG; ++i) {
+    const unsigned e = (unsigned)((R2 > 1 ? g * G : 0) + i) * kN2 + n2;      // row a = g*G + i (R2 = 1: a = i)
 #pragma unroll
-      for (int kb = 0; kb < R2; ++kb) {
-        const int row = (g * G + i) + 16 * kb;
-        cf z = v[i * R2 + kb];
-        if constexpr (DIR < 0) z = cmul(z, tw.full[row * kN2 + n2]);
-        st(b, row, n2, z);
-      }
-  } else {
-#pragma unroll
-    for (int a = 0; a < 16; ++a) {
-      cf z = v[a];
-      if constexpr (DIR < 0) z = cmul(z, tw.full[a * kN2 + n2]);
-      st(b, a, n2, z);
+    for (int kb = 0; kb < KB; ++kb) {
+      cf z = v[i * KB + kb];
+      if constexpr (DIR < 0) z = cmul(z, bload_cf(r_full, e * 8u, (unsigned)(kb * 16 * kN2) * 8u));
+      st.put(r_out, e, (unsigned)(kb * 16 * kN2), z);
     }
   }
-  (void)N1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -246,7 +319,8 @@ struct MixCfg {
 };
 
 template <int R2, int DIR, class Load, class Store>
-__global__ __launch_bounds__(MixCfg<R2>::T) void cols_mixed_kernel(Load ld, Store st, Twiddles tw, int nchan) {
+__global__ __launch_bounds__(MixCfg<R2>::T) void cols_mixed_kernel(Load ld, Store st, Twiddles tw, int nchan,
+                                                                    int n1_total) {
   using Cfg = MixCfg<R2>;
   constexpr int TC = Cfg::TC, T = Cfg::T, G = Cfg::G;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -257,24 +331,12 @@ __global__ __launch_bounds__(MixCfg<R2>::T) void cols_mixed_kernel(Load ld, Stor
   const int g = tid / TC;
   int b, tile;
   xcd_work_item(nchan, tile, b);
-  const int n2 = tile * TC + c;
+  const unsigned n2 = (unsigned)(tile * TC + c);
+  const __amdgpu_buffer_rsrc_t r_full = make_rsrc(tw.full, (unsigned)n1_total * kN2 * 8u);
+  const __amdgpu_buffer_rsrc_t r_out = st.bind(b);
 
   cf v[16];
-  const int live = ld.live_rows();
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int row = g + R2 * j;
-    cf z = make_float2(0.f, 0.f);
-    if (row < live) {
-      z = ld(b, row, n2);
-      if constexpr (DIR > 0) z = cmulc(z, tw.full[row * kN2 + n2]);
-    }
-    v[j] = z;
-  }
-  fft16<DIR>(v);   // index a
-  const int gu = (TC == 64) ? __builtin_amdgcn_readfirstlane(g) : g;
-#pragma unroll
-  for (int a = 1; a < 16; ++a) v[a] = ctw<DIR>(v[a], tw.hi[4 * gu * a]);   // w_N1^(g a)
+  cols_first_stage<R2, TC, DIR>(ld, tw, r_full, b, g, (unsigned)g * kN2 + n2, v);
 #pragma unroll
   for (int a = 0; a < 16; ++a) buf[a * T + tid] = v[a];
   __syncthreads();
@@ -286,12 +348,12 @@ __global__ __launch_bounds__(MixCfg<R2>::T) void cols_mixed_kernel(Load ld, Stor
 #pragma unroll
       for (int gp = 0; gp < R2; ++gp) y[gp] = buf[ka * T + gp * TC + c];
       fft_small<DIR, R2>(y);
+      const unsigned e = (unsigned)ka * kN2 + n2;
 #pragma unroll
       for (int kb = 0; kb < R2; ++kb) {
-        const int row = ka + 16 * kb;
         cf z = y[kb];
-        if constexpr (DIR < 0) z = cmul(z, tw.full[row * kN2 + n2]);
-        st(b, row, n2, z);
+        if constexpr (DIR < 0) z = cmul(z, bload_cf(r_full, e * 8u, (unsigned)(kb * 16 * kN2) * 8u));
+        st.put(r_out, e, (unsigned)(kb * 16 * kN2), z);
       }
     }
   }
@@ -315,30 +377,6 @@ struct RowsArgs {
   int npairs;                      // N1/2: pair 0 = rows (0, N1/2), pair p = rows (p, N1-p)
   int nchan;                       // channels in this launch group
 };
-
-// Raw buffer (SRSRC) addressing: one 32-bit VGPR offset per thread + scalar offsets per element,
-// instead of sixteen 64-bit VGPR address pairs that would otherwise stay live from the first load
-// to the last store of the row (measured: 138 VGPRs -> spills under the 2-workgroups/CU bound).
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ cf bload_cf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-  return make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
-}
-__device__ __forceinline__ float4 bload_f4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-  return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
-}
-__device__ __forceinline__ void bstore_cf(cf v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  u32x2 x;
-  x.x = __float_as_uint(v.x);
-  x.y = __float_as_uint(v.y);
-  __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
-}
 
 // W = alpha z + beta conj(zp) in four packed instructions (alpha = ab.xy, beta = ab.zw)
 __device__ __forceinline__ cf filter_bin(float4 ab, cf z, cf zp) {
@@ -412,17 +450,24 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   const unsigned vo16 = (unsigned)t * 16u;     // same for float4
   const unsigned vl8 = (unsigned)lo4 * 8u;
 
+  // Every table read below is issued one phase ahead of its use, into whichever of the two register
+  // arrays is idle at that point, so its latency hides behind the butterflies / the LDS exchange
+  // (phase trace: the four twiddle fetches were ~1 us of exposed latency each).
   cf v[16], u[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) v[j] = bload_cf(r_row, vo8, j * 256 * 8);
+#pragma unroll
+  for (int a = 1; a < 16; ++a) u[a] = bload_cf(r_t1, vo8, a * 256 * 8);      // stage-1 twiddles
   IMP_MARK_MEM(1);
 
   // ---- forward FFT4096 ----
   fft16<-1>(v);                                            // over j -> a
 #pragma unroll
-  for (int a = 1; a < 16; ++a) v[a] = cmul(v[a], bload_cf(r_t1, vo8, a * 256 * 8));
+  for (int a = 1; a < 16; ++a) v[a] = cmul(v[a], u[a]);
 #pragma unroll
   for (int a = 0; a < 16; ++a) buf[a * kRowPad + t] = v[a];
+#pragma unroll
+  for (int q = 1; q < 16; ++q) v[q] = bload_cf(r_t2, vl8, q * 16 * 8);       // stage-2 twiddles
   __syncthreads();
   IMP_MARK(2);
   // thread (ka = hi4, t2 = lo4) gathers j2 = 0..15 (t = 16 j2 + t2)
@@ -430,7 +475,7 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   for (int j2 = 0; j2 < 16; ++j2) u[j2] = buf[hi4 * kRowPad + 16 * j2 + lo4];
   fft16<-1>(u);                                            // over j2 -> kb1
 #pragma unroll
-  for (int q = 1; q < 16; ++q) u[q] = cmul(u[q], bload_cf(r_t2, vl8, q * 16 * 8));
+  for (int q = 1; q < 16; ++q) u[q] = cmul(u[q], v[q]);
   // The X2 exchange stays inside one 16-lane group (same ka): both the plane-row it overwrites
   // (read just above by the same 16 lanes) and the values it reads back are private to that group,
   // which lives in one wave.  LDS executes a wave's DS ops in order, so a wave-level scheduling
@@ -442,6 +487,9 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   // thread (ka = hi4, kb1 = lo4) gathers t2 = 0..15
 #pragma unroll
   for (int t2 = 0; t2 < 16; ++t2) v[t2] = buf[hi4 * kRowPad + t2 * 17 + lo4];
+  float4 ab_pre[kAbPrefetch];                              // first half of this thread's alpha/beta, a phase early
+#pragma unroll
+  for (int q = 0; q < kAbPrefetch; ++q) ab_pre[q] = bload_f4(r_ab, vo16, q * 256 * 16);
   fft16<-1>(v);                                            // over t2 -> kb2
   __syncthreads();
   IMP_MARK(3);
@@ -475,7 +523,7 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   // W = alpha Z + beta conj(Z[Nc-k]), in place
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    v[q] = filter_bin(bload_f4(r_ab, vo16, q * 256 * 16), v[q], u[q]);
+    v[q] = filter_bin(q < kAbPrefetch ? ab_pre[q] : bload_f4(r_ab, vo16, q * 256 * 16), v[q], u[q]);
   }
   if (dc_lane) v[0] = w_dc;
   IMP_MARK_MEM(5);
@@ -483,18 +531,22 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   IMP_MARK(6);
 
   // ---- inverse FFT4096 (mirror) ----
+#pragma unroll
+  for (int q = 1; q < 16; ++q) u[q] = bload_cf(r_t2, vl8, q * 16 * 8);       // u[] is free after the multiply
   fft16<+1>(v);                                            // over kb2 -> t2
 #pragma unroll
-  for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], bload_cf(r_t2, vl8, q * 16 * 8));
+  for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], u[q]);
 #pragma unroll
   for (int t2 = 0; t2 < 16; ++t2) buf[hi4 * kRowPad + t2 * 17 + lo4] = v[t2];
   wave_lds_fence();                                        // intra-group exchange, see above
   // thread (ka = hi4, t2 = lo4) gathers kb1 = 0..15
 #pragma unroll
   for (int q = 0; q < 16; ++q) u[q] = buf[hi4 * kRowPad + lo4 * 17 + q];
+#pragma unroll
+  for (int j2 = 0; j2 < 16; ++j2) v[j2] = bload_cf(r_t4, vo8, j2 * 256 * 8);  // v[] is free: inverse 2nd twiddle
   fft16<+1>(u);                                            // over kb1 -> j2
 #pragma unroll
-  for (int j2 = 0; j2 < 16; ++j2) u[j2] = cmulc(u[j2], bload_cf(r_t4, vo8, j2 * 256 * 8));
+  for (int j2 = 0; j2 < 16; ++j2) u[j2] = cmulc(u[j2], v[j2]);
   wave_lds_fence();                                        // X1' rows are written by the group that read X2'
 #pragma unroll
   for (int j2 = 0; j2 < 16; ++j2) buf[hi4 * kRowPad + 16 * j2 + lo4] = u[j2];

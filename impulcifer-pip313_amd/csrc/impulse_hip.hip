@@ -397,7 +397,7 @@ static int launch_cols(imp_plan* p, int64_t nchan, Load ld, Store st) {
   const int tiles = imp::kN2 / Cfg::TC;
   imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
   dim3 grid((unsigned)(nchan * tiles)), block(Cfg::T);
-  hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->cur_stream, ld, st, tw, (int)nchan);
+  hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->cur_stream, ld, st, tw, (int)nchan, (int)p->N1);
   HIP_TRY(hipGetLastError());
   return IMP_OK;
 }
@@ -415,7 +415,7 @@ static int launch_cols_mixed(imp_plan* p, int64_t nchan, Load ld, Store st) {
   const int tiles = imp::kN2 / Cfg::TC;
   imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
   dim3 grid((unsigned)(nchan * tiles)), block(Cfg::T);
-  hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->cur_stream, ld, st, tw, (int)nchan);
+  hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->cur_stream, ld, st, tw, (int)nchan, (int)p->N1);
   HIP_TRY(hipGetLastError());
   return IMP_OK;
 }
@@ -716,7 +716,7 @@ static int run_group_with(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64
   if ((rc = timing_event(p, 2))) return rc;
   if (last_stage < 2) return IMP_OK;
   imp::LoadWorkspace ldw{p->cur_ws, p->N1};
-  imp::StoreRealCrop stc{d_y, chan_stride_out, 1, p->out_start, p->out_len};
+  imp::StoreRealCrop stc{d_y, chan_stride_out, p->out_start, p->out_len};
   if ((rc = launch_cols_any<+1>(p, nchan, ldw, stc))) return rc;
   if ((rc = timing_event(p, 3))) return rc;
   return IMP_OK;
@@ -727,6 +727,9 @@ extern "C" int imp_conv_execute_device(imp_plan* p, const float* d_x, int64_t B,
   if (!p || !d_x || !d_y) return fail(IMP_ERR_INVALID, "imp_conv_execute_device: null argument");
   if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
   if (elem_stride_in < 1) return fail(IMP_ERR_INVALID, "elem_stride_in must be >= 1");
+  // one channel is addressed through a 32-bit buffer range
+  if ((double)p->L * (double)elem_stride_in * 4.0 >= 4294967296.0)
+    return fail(IMP_ERR_INVALID, "L * elem_stride_in exceeds the 4 GiB buffer range of one channel");
   if (chan_stride_out < p->out_len) return fail(IMP_ERR_INVALID, "chan_stride_out %lld < out_len %lld",
                                                 (long long)chan_stride_out, (long long)p->out_len);
   if (p->n_filters > 1 && B > p->n_filters)
@@ -749,6 +752,8 @@ extern "C" int imp_conv_execute_device_pcm(imp_plan* p, const void* d_pcm, int b
   if (!p || !d_pcm || !d_y) return fail(IMP_ERR_INVALID, "imp_conv_execute_device_pcm: null argument");
   if (bits != 16 && bits != 32) return fail(IMP_ERR_INVALID, "PCM width must be 16 or 32 bits");
   if (B < 0 || elem_stride_in < 1) return fail(IMP_ERR_INVALID, "bad B or elem_stride_in");
+  if ((double)p->L * (double)elem_stride_in * 4.0 >= 4294967296.0)
+    return fail(IMP_ERR_INVALID, "L * elem_stride_in exceeds the 4 GiB buffer range of one channel");
   if (chan_stride_out < p->out_len) return fail(IMP_ERR_INVALID, "chan_stride_out < out_len");
   int rc = ctx_bind(p->ctx);
   if (rc) return rc;

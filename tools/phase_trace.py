@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["IMPULSE_HIP_LIB"] = os.path.join(ROOT, "impulcifer-pip313_amd", "csrc", "libimpulse_hip_trace.so")
+os.environ.setdefault("IMPULSE_HIP_LIB", os.path.join(ROOT, "impulcifer-pip313_amd", "csrc", "libimpulse_hip_trace.so"))
 sys.path.insert(0, os.path.join(ROOT, "impulcifer-pip313_amd"))
 sys.path.insert(0, ROOT)
 
@@ -39,10 +39,13 @@ def main():
     d_x = ctx.malloc(x.nbytes)
     d_y = ctx.malloc(x.nbytes)
     ctx.h2d(d_x, x)
-    for _ in range(5):
+    for _ in range(int(os.environ.get("TRACE_REPEATS", "5"))):
         plan.execute_device(d_x, nch, pitch, d_y, pitch)
     ctx.synchronize()
     lib = _native.load_library()
+    if not hasattr(lib, "imp_debug_phase_trace"):
+        print("library without phase marks: ran the launches only (use under rocprofv3 --kernel-trace)")
+        return
     n_wg = nch * plan.n1 // 2 + (nch if False else 0)
     n_wg = nch * ((plan.n1 // 2 + 8) // 8 * 8)          # grid is padded to a multiple of 8 tiles
     words = np.zeros(8192 * 16, dtype=np.uint64)
