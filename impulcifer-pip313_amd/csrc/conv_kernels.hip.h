@@ -66,6 +66,10 @@ __device__ __forceinline__ void xcd_work_item(int nchan, int& tile, int& chan) {
 //     out of range whatever soffset adds (tools/probes/buffer_oob_probe.hip, measured on gfx950).
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef IMP_STREAM_AUX
+#define IMP_STREAM_AUX 0     // cache policy of the once-touched input / output streams (2 = nt)
+#endif
+constexpr int kStreamAux = IMP_STREAM_AUX;
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -107,7 +111,10 @@ struct LoadRealPacked {
     if (elem_stride == 1) {
       const __amdgpu_buffer_rsrc_t r = make_rsrc(p, (unsigned)len * 4u);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = bload_cf(r, e0 * 8u, (unsigned)(j * STEP) * 8u);
+      for (int j = 0; j < 16; ++j) {
+        const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, e0 * 8u, (unsigned)(j * STEP) * 8u, kStreamAux);
+        v[j] = make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
+      }
     } else {
       const unsigned es = (unsigned)elem_stride * 4u;                          // bytes between samples
       const __amdgpu_buffer_rsrc_t r = make_rsrc(p, ((unsigned)(len - 1) * (unsigned)elem_stride + 1u) * 4u);
@@ -200,7 +207,10 @@ struct StoreRealCrop {
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), r, off, 0u, 0);
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), r, off_im, 0u, 0);
     } else {
-      bstore_cf(v, r, off, 0u);
+      u32x2 x;
+      x.x = __float_as_uint(v.x);
+      x.y = __float_as_uint(v.y);
+      __builtin_amdgcn_raw_buffer_store_b64(x, r, off, 0u, kStreamAux);
     }
   }
 };
@@ -459,6 +469,23 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
 #pragma unroll
   for (int a = 1; a < 16; ++a) u[a] = bload_cf(r_t1, vo8, a * 256 * 8);      // stage-1 twiddles
   IMP_MARK_MEM(1);
+#ifdef IMP_EXPERIMENT_ROWS_COPY
+  // ceiling probe: the row pass as a pure copy (alpha/beta still fetched), no butterflies, no LDS
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float4 ab = bload_f4(r_ab, vo16, q * 256 * 16);
+      acc += ab.x + ab.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      v[j].x += acc * 1e-30f;
+      bstore_cf(v[j], r_row, vo8, j * 256 * 8);
+    }
+    return;
+  }
+#endif
 
   // ---- forward FFT4096 ----
   fft16<-1>(v);                                            // over j -> a
@@ -494,22 +521,29 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   __syncthreads();
   IMP_MARK(3);
 
-  // ---- partner exchange: plane [kb2][u] ----
+  // ---- partner exchange: plane [kb2][17 ka + kb1] (pitch 17 keeps the mirrored read conflict-free) ----
 #pragma unroll
-  for (int q = 0; q < 16; ++q) buf[q * kRowPad + t] = v[q];
+  for (int q = 0; q < 16; ++q) buf[q * kRowPad + t + hi4] = v[q];
   __syncthreads();
 
-  // partner bins conj Z[Nc-k] (u[] is free here).  With k = k1 + N1 k2:
-  //   k1 != 0: Nc - k = (N1 - k1) + N1 (4095 - k2)  -> the other row of the pair, column 4095 - k2
+  // partner bins conj Z[Nc-k] (u[] is free here).  With k = k1 + N1 k2, k2 = ka + 16 kb1 + 256 kb2:
+  //   k1 != 0: Nc - k = (N1 - k1) + N1 (4095 - k2)  -> the other row of the pair, column 4095 - k2,
+  //            i.e. (15 - ka, 15 - kb1, 15 - kb2): one per-thread base + compile-time plane offsets
   //   k1 == 0: Nc - k = N1 (4096 - k2) mod Nc       -> row 0 itself, column (4096 - k2) mod 4096
   // In the self-paired workgroup (rows 0 and N1/2) the partner row is the thread's own row.
   const int phalf = (pair == 0) ? half : 1 - half;
   const cf* pbuf = lds + phalf * (16 * kRowPad);
+  if (k1 != 0) {                                           // wave-uniform
+    const cf* pm = pbuf + 17 * (15 - hi4) + (15 - lo4);
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const unsigned k2 = (unsigned)hi4 + 16u * (unsigned)lo4 + 256u * (unsigned)q;
-    const unsigned pk2 = (k1 != 0) ? (4095u - k2) : ((4096u - k2) & 4095u);
-    u[q] = pbuf[(pk2 >> 8) * kRowPad + 16 * (pk2 & 15u) + ((pk2 >> 4) & 15u)];
+    for (int q = 0; q < 16; ++q) u[q] = pm[(15 - q) * kRowPad];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const unsigned k2 = (unsigned)hi4 + 16u * (unsigned)lo4 + 256u * (unsigned)q;
+      const unsigned pk2 = (4096u - k2) & 4095u;
+      u[q] = pbuf[(pk2 >> 8) * kRowPad + 17 * (pk2 & 15u) + ((pk2 >> 4) & 15u)];
+    }
   }
   IMP_MARK(4);
   // bin 0 of the packed transform carries DC and Nyquist: ab.x = H[0]/Nc, ab.z = H[Nc]/Nc

@@ -18,13 +18,12 @@ def short(name):
 def main(root):
     out = defaultdict(lambda: defaultdict(list))
     dur = defaultdict(list)
-    for d in sorted(glob.glob(os.path.join(root, "*", "*"))):
-        for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
-            for row in csv.DictReader(open(f)):
-                out[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
-        for f in glob.glob(os.path.join(d, "*kernel_trace.csv")):
-            for row in csv.DictReader(open(f)):
-                dur[short(row["Kernel_Name"])].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
+    for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+        for row in csv.DictReader(open(f)):
+            out[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
+        for row in csv.DictReader(open(f)):
+            dur[short(row["Kernel_Name"])].append(float(row["End_Timestamp"]) - float(row["Start_Timestamp"]))
     res = {}
     for k in sorted(out):
         res[k] = {c: sum(v) / len(v) for c, v in sorted(out[k].items())}
