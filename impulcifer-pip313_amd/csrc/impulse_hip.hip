@@ -967,6 +967,65 @@ extern "C" int imp_peak_index(imp_ctx* ctx, const float* x, const int64_t* off, 
   return rc;
 }
 
+extern "C" int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_off, const int64_t* a_len,
+                                const double* b, const int64_t* b_off, const int64_t* b_len, int64_t B,
+                                int64_t* arg_out, double* val_out) {
+  if (!ctx || (B && (!a || !a_off || !a_len || !b || !b_off || !b_len || !arg_out)))
+    return fail(IMP_ERR_INVALID, "imp_xcorr_argmax: null argument");
+  if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
+  if (B == 0) return IMP_OK;
+  int64_t ta = 0, tb = 0, lds = 0;
+  for (int64_t p = 0; p < B; ++p) {
+    if (a_len[p] < 1 || b_len[p] < 1 || a_off[p] < 0 || b_off[p] < 0)
+      return fail(IMP_ERR_INVALID, "pair %lld: empty segment or negative offset", (long long)p);   // scipy raises on empty input
+    if (a_len[p] + b_len[p] > 16384)
+      return fail(IMP_ERR_UNSUPPORTED, "pair %lld: %lld + %lld samples exceed the 16384 the lag search holds in LDS",
+                  (long long)p, (long long)a_len[p], (long long)b_len[p]);
+    ta = std::max(ta, a_off[p] + a_len[p]);
+    tb = std::max(tb, b_off[p] + b_len[p]);
+    lds = std::max(lds, a_len[p] + b_len[p]);
+  }
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(ctx->mu);          // the context's scratch buffer is shared
+  hipStream_t s = ctx->stream;
+  // scratch: a, b (fp64), 4 x int64 meta, arg (int64), val (fp64)
+  const size_t meta = (size_t)B * sizeof(int64_t);
+  const size_t bytes = (size_t)(ta + tb) * sizeof(double) + 6 * meta;
+  void* scr = nullptr;
+  if ((rc = ctx_scratch(ctx, bytes, &scr))) return rc;
+  double* d_a = (double*)scr;
+  double* d_b = d_a + ta;
+  int64_t* d_meta = (int64_t*)(d_b + tb);
+  long long* d_arg = (long long*)(d_meta + 4 * B);
+  double* d_val = (double*)(d_arg + B);
+  HIP_TRY(hipMemcpyAsync(d_a, a, (size_t)ta * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_b, b, (size_t)tb * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_meta, a_off, meta, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_meta + B, a_len, meta, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_meta + 2 * B, b_off, meta, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_meta + 3 * B, b_len, meta, hipMemcpyHostToDevice, s));
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(imp::xcorr_argmax_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(double)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(imp::xcorr_argmax_kernel, dim3((unsigned)B), dim3(256), (size_t)lds * sizeof(double), s, d_a, d_meta,
+                     d_meta + B, d_b, d_meta + 2 * B, d_meta + 3 * B, d_arg, d_val);
+  HIP_TRY(hipGetLastError());
+  std::vector<long long> h_arg((size_t)B);
+  std::vector<double> h_val((size_t)B);
+  HIP_TRY(hipMemcpyAsync(h_arg.data(), d_arg, (size_t)B * sizeof(long long), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_val.data(), d_val, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int64_t p = 0; p < B; ++p) {
+    arg_out[p] = (int64_t)h_arg[(size_t)p];
+    if (val_out) val_out[p] = h_val[(size_t)p];
+  }
+  return IMP_OK;
+}
+
 extern "C" int imp_apply_window(imp_ctx* ctx, float* x, const int64_t* off, const int64_t* len, int64_t B,
                                 const imp_window_params* params) {
   if (!ctx || (B && (!x || !off || !len || !params))) return fail(IMP_ERR_INVALID, "imp_apply_window: null argument");

@@ -132,4 +132,58 @@ __global__ __launch_bounds__(256) void apply_window_kernel(float* __restrict__ x
   }
 }
 
+// K10: argmax of the full cross-correlation of B pairs of short segments (core/hrir.py:934-937, :946-949,
+// scipy.signal.correlate(a, b, "full") then np.argmax).  corr[k] = sum_l a[l + k - (nb - 1)] b[l],
+// k = 0 .. na + nb - 2, summed in fp64 in index order.  One workgroup per pair, both segments in LDS,
+// a thread owns lags k = tid, tid + 256, ...; the first maximum wins, as in np.argmax.
+__global__ __launch_bounds__(256) void xcorr_argmax_kernel(const double* __restrict__ a, const int64_t* __restrict__ a_off,
+                                                           const int64_t* __restrict__ a_len,
+                                                           const double* __restrict__ b, const int64_t* __restrict__ b_off,
+                                                           const int64_t* __restrict__ b_len,
+                                                           long long* __restrict__ arg_out, double* __restrict__ val_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* sa = reinterpret_cast<double*>(smem_raw);
+  const int p = blockIdx.x;
+  const int na = (int)a_len[p], nb = (int)b_len[p];
+  double* sb = sa + na;
+  for (int i = threadIdx.x; i < na; i += blockDim.x) sa[i] = a[a_off[p] + i];
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) sb[i] = b[b_off[p] + i];
+  __syncthreads();
+  double best = -__builtin_huge_val();
+  int best_k = 0x7fffffff;
+  const int nk = na + nb - 1;
+  for (int k = threadIdx.x; k < nk; k += blockDim.x) {
+    const int sh = k - (nb - 1);                   // a index = l + sh
+    const int lo = sh < 0 ? -sh : 0;
+    const int hi = (na - sh < nb) ? (na - sh) : nb;
+    double acc = 0.0;
+    for (int l = lo; l < hi; ++l) acc = fma(sa[l + sh], sb[l], acc);
+    if (acc > best) {
+      best = acc;
+      best_k = k;
+    }
+  }
+  // block argmax, ties to the smaller index
+  __shared__ double rv[256];
+  __shared__ int rk[256];
+  rv[threadIdx.x] = best;
+  rk[threadIdx.x] = best_k;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      const double ov = rv[threadIdx.x + s];
+      const int ok = rk[threadIdx.x + s];
+      if (ov > rv[threadIdx.x] || (ov == rv[threadIdx.x] && ok < rk[threadIdx.x])) {
+        rv[threadIdx.x] = ov;
+        rk[threadIdx.x] = ok;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    arg_out[p] = rk[0];
+    val_out[p] = rv[0];
+  }
+}
+
 }  // namespace imp

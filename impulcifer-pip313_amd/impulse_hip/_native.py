@@ -78,6 +78,7 @@ SIGNATURES = {
     "imp_debug_plan_geometry": (C.c_int, [_i64, _i64, C.c_int, _pi64, _pi64, _pi64]),
     "imp_debug_host_spectrum": (C.c_int, [_pd, _i64, C.c_int, _pf]),
     "imp_plan_debug_run_stage": (C.c_int, [_vp, _pf, _i64, _i64, C.c_int, _pf]),
+    "imp_xcorr_argmax": (C.c_int, [_vp, _pd, _pi64, _pi64, _pd, _pi64, _pi64, _i64, _pi64, _pd]),
     "imp_minphase_fir": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, _pd]),
     "imp_magnitude_db": (C.c_int, [_vp, _pd, _i64, _i64, _pd]),
     "imp_debug_minphase_stage": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, C.c_int, _pd]),
@@ -237,6 +238,31 @@ class Context:
         _check(self._lib.imp_peak_index(self._h, _ptr_f(flat), _ptr_i64(offs), _ptr_i64(lens), B,
                                         float(peak_height), _ptr_i64(idx), _ptr_f(mx)))
         return idx, mx
+
+    def xcorr_argmax(self, a_rows, b_rows):
+        """np.argmax(scipy.signal.correlate(a, b, "full")) for every pair (fp64 on the device).
+        Returns (argmax[int64], peak value[f64])."""
+        B = len(a_rows)
+        if B != len(b_rows):
+            raise ValueError("xcorr_argmax: the two lists differ in length")
+        arg = np.zeros(B, dtype=np.int64)
+        val = np.zeros(B, dtype=np.float64)
+        if B == 0:
+            return arg, val
+
+        def pack(rows):
+            rows = [np.ascontiguousarray(r, dtype=np.float64).ravel() for r in rows]
+            lens = np.array([len(r) for r in rows], dtype=np.int64)
+            offs = np.zeros(B, dtype=np.int64)
+            offs[1:] = np.cumsum(lens)[:-1]
+            return (np.concatenate(rows) if lens.sum() else np.zeros(1)), offs, lens
+
+        fa, oa, la = pack(a_rows)
+        fb, ob, lb = pack(b_rows)
+        _check(self._lib.imp_xcorr_argmax(self._h, fa.ctypes.data_as(_pd), _ptr_i64(oa), _ptr_i64(la),
+                                          fb.ctypes.data_as(_pd), _ptr_i64(ob), _ptr_i64(lb), B,
+                                          _ptr_i64(arg), val.ctypes.data_as(_pd)))
+        return arg, val
 
     def minphase_fir(self, gain, fs):
         """Batched firwin2 + homomorphic minimum_phase (fp64 on the device): gain [B, n] linear gains on

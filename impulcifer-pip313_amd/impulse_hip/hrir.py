@@ -343,29 +343,36 @@ class HRIR(_PlotBase):
 
     # ---- alignment (small host-side correlations; 'next' tier of the scope table) ----------
     def align_ipsilateral_all(self, speaker_pairs=None, segment_ms=30):
-        pairs = list(IPSILATERAL_PAIRS) if speaker_pairs is None else speaker_pairs
+        """core/hrir.py:921-958.  The lag searches (scipy.signal.correlate + argmax per pair) run as one
+        batch on the device (K10, imp_xcorr_argmax); pairs that touch a speaker an earlier pair of the
+        batch may have shifted are searched after that shift, as in the reference's loop."""
+        pairs = list(IPSILATERAL_PAIRS) if speaker_pairs is None else list(speaker_pairs)
         seg = int(self.fs * segment_ms / 1000)
-
-        def lag_of(a, b):
-            a, b = a[:seg], b[:seg]
-            corr = np.correlate(a, b, mode="full")
-            return int(np.arange(-len(a) + 1, len(a))[np.argmax(corr)])
-
-        for one, two in pairs:
-            if one not in self.irs or two not in self.irs:
-                continue
-            if one == two:
-                lag = lag_of(self.irs[one]["left"].data, self.irs[one]["right"].data)
-                if lag > 0:
-                    self.irs[one]["right"].shift(lag)
-                elif lag < 0:
-                    self.irs[one]["left"].shift(-lag)
-                continue
-            lag = lag_of(self.irs[one]["left"].data, self.irs[two]["right"].data)
-            target, amount = (two, lag) if lag > 0 else (one, -lag)
-            if lag != 0:
-                for sd in ("left", "right"):
-                    self.irs[target][sd].shift(amount)
+        pairs = [(one, two) for one, two in pairs if one in self.irs and two in self.irs]
+        ctx = _native.default_context()
+        i = 0
+        while i < len(pairs):
+            batch, touched = [], set()
+            while i < len(pairs) and not ({pairs[i][0], pairs[i][1]} & touched):
+                batch.append(pairs[i])
+                touched |= {pairs[i][0], pairs[i][1]}
+                i += 1
+            a = [self.irs[one]["left"].data[:seg] for one, _ in batch]
+            b = [self.irs[two]["right"].data[:seg] for _, two in batch]
+            arg, _ = ctx.xcorr_argmax(a, b)
+            for (one, two), k, xa in zip(batch, arg, a):
+                lags = np.arange(-len(xa) + 1, len(xa))        # the reference indexes this with the argmax
+                lag = int(lags[int(k)])
+                if one == two:
+                    if lag > 0:
+                        self.irs[one]["right"].shift(lag)
+                    elif lag < 0:
+                        self.irs[one]["left"].shift(-lag)
+                    continue
+                target, amount = (two, lag) if lag > 0 else (one, -lag)
+                if lag != 0:
+                    for sd in ("left", "right"):
+                        self.irs[target][sd].shift(amount)
 
     def align_onset_groups_peak_leftref(self, groups=None):
         if groups is None:

@@ -141,6 +141,18 @@ int imp_plan_debug_run_stage(imp_plan* plan, const float* x, int64_t B, int64_t 
  * db_out: host [B][ceil(n/2)].  Any n up to 2^22 (Bluestein on a power-of-two Stockham FFT). */
 int imp_magnitude_db(imp_ctx* ctx, const double* x, int64_t B, int64_t n, double* db_out);
 
+/* ---- K10: lag search of the ipsilateral alignment ----------------------------------------------
+ * core/hrir.py:934-937 and :946-949 (HRIR.align_ipsilateral_all):
+ *     corr = scipy.signal.correlate(a, b, mode="full"); lag = arange(-len(a)+1, len(a))[argmax(corr)]
+ * for B pairs at once.  a, b: host fp64, pair p at a + a_off[p] (a_len[p] samples) and b + b_off[p]
+ * (b_len[p]); corr[k] = sum_l a[l + k - (b_len-1)] b[l] in fp64, arg_out[p] = first index of the
+ * maximum (np.argmax), val_out[p] = that maximum (may be NULL).  The caller turns the index into
+ * the reference's lag.  a_len[p] + b_len[p] <= 16384 (both segments live in one CU's LDS; the
+ * reference's segments are 30 ms: 1 440 / 2 880 samples).
+ */
+int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_off, const int64_t* a_len, const double* b,
+                     const int64_t* b_off, const int64_t* b_len, int64_t B, int64_t* arg_out, double* val_out);
+
 /* ---- K3: first significant peak ---------------------------------------------------------------
  * core/impulse_response.py:32-70 ImpulseResponse.peak_index (twin core/decay.py:12-41):
  * normalise by max|x| of the searched range, scipy.signal.find_peaks(+x and -x, height), minimum

@@ -96,3 +96,46 @@ def normalization_gain_db(irs, fs, peak_target=-0.1, avg_target=None):
         band = np.concatenate([ml[np.logical_and(fl > 80, fl < 6000)], mr[np.logical_and(fr > 80, fr < 6000)]])
         return np.mean(band) * -1 + avg_target
     raise ValueError('One and only one of the parameters "peak_target" and "avg_target" must be given!')
+
+
+def ipsilateral_lag(a, b, segment_len):
+    """core/hrir.py:930-937 / :944-949 (HRIR.align_ipsilateral_all): lag of the cross-correlation peak of
+    the first `segment_len` samples.  scipy.signal.correlate(x, y, "full")[k] = sum_l x[l + k - (len(y)-1)] y[l]
+    (SciPy picks FFT or direct by size; both agree to rounding, np.correlate is the direct sum)."""
+    x, y = np.asarray(a, dtype=np.float64)[:segment_len], np.asarray(b, dtype=np.float64)[:segment_len]
+    corr = np.correlate(x, y, mode="full")
+    lags = np.arange(-len(x) + 1, len(x))
+    return int(lags[np.argmax(corr)])
+
+
+def align_ipsilateral_all(irs, fs, speaker_pairs, segment_ms=30):
+    """core/hrir.py:921-958 on a dict {speaker: {side: fp64 array}}; returns the shifted copies.
+    `shift` follows core/impulse_response.py:92-108 (length-preserving)."""
+    def shift(d, s):
+        n = len(d)
+        if s > 0:
+            return np.concatenate((np.zeros(s), d))[:n]
+        if s < 0:
+            t = d[-s:]
+            return np.pad(t, (0, n - len(t))) if len(t) < n else t
+        return d
+    out = {sp: {sd: np.array(x, dtype=np.float64) for sd, x in pair.items()} for sp, pair in irs.items()}
+    seg = int(fs * segment_ms / 1000)
+    for one, two in speaker_pairs:
+        if one not in out or two not in out:
+            continue
+        if one == two:
+            lag = ipsilateral_lag(out[one]["left"], out[one]["right"], seg)
+            if lag > 0:
+                out[one]["right"] = shift(out[one]["right"], lag)
+            elif lag < 0:
+                out[one]["left"] = shift(out[one]["left"], -lag)
+            continue
+        lag = ipsilateral_lag(out[one]["left"], out[two]["right"], seg)
+        if lag > 0:
+            for sd in ("left", "right"):
+                out[two][sd] = shift(out[two][sd], lag)
+        elif lag < 0:
+            for sd in ("left", "right"):
+                out[one][sd] = shift(out[one][sd], -lag)
+    return out

@@ -801,3 +801,80 @@ def test_pcm_wire_format_ingest(gpu_ctx, tmp_path):
     h = HRIR(e)
     h.open_recording(str(tmp_path / "f24.wav"), ["FL", "FR"])
     assert set(h.irs) == {"FL", "FR"}
+
+
+def test_k10_lag_search_matches_scipy_and_oracle(gpu_ctx):
+    """K10 (imp_xcorr_argmax): argmax of the full cross-correlation, fp64 on the device, against
+    scipy.signal.correlate (what the reference calls, core/hrir.py:934) and the oracle's alignment."""
+    from scipy import signal
+    from impulse_hip.constants import IPSILATERAL_PAIRS
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.impulse_response import ImpulseResponse
+    from oracle.hrir import align_ipsilateral_all
+    rng = np.random.default_rng(10)
+
+    def room_ir(delay, n=4096, fs=48000):
+        t = np.arange(n)
+        x = rng.standard_normal(n) * np.exp(-t / 600.0) * 0.2
+        x[:delay] = 0.0
+        x[delay] = 1.0
+        return x
+
+    a_rows, b_rows = [], []
+    for na, nb in ((1440, 1440), (2880, 2880), (1000, 1440), (1440, 777), (1, 1), (5, 1), (8191, 8193)):
+        a_rows.append(room_ir(int(rng.integers(0, max(na // 4, 1))), na) if na > 8 else rng.standard_normal(na))
+        b_rows.append(room_ir(int(rng.integers(0, max(nb // 4, 1))), nb) if nb > 8 else rng.standard_normal(nb))
+    a_rows.append(np.zeros(64)); b_rows.append(np.zeros(64))                 # all-zero: first index wins
+    a_rows.append(np.ones(16)); b_rows.append(np.ones(16))                   # symmetric triangle, single max
+    arg, val = gpu_ctx.xcorr_argmax(a_rows, b_rows)
+    for a, b, k, v in zip(a_rows, b_rows, arg, val):
+        corr = signal.correlate(a, b, mode="full")
+        assert int(k) == int(np.argmax(corr)), (len(a), len(b))
+        assert abs(v - corr.max()) <= 1e-12 * max(1.0, abs(corr).max())
+    with pytest.raises(Exception):
+        gpu_ctx.xcorr_argmax([np.zeros(9000)], [np.zeros(9000)])             # beyond the LDS-resident size
+
+    class Est:
+        fs = 48000
+    speakers = ["FL", "FR", "SL", "SR", "BL", "BR", "FC", "WL", "WR"]
+    irs = {sp: {"left": room_ir(40 + 9 * i), "right": room_ir(52 + 5 * i)} for i, sp in enumerate(speakers)}
+    h = HRIR(Est())
+    h.irs = {sp: {sd: ImpulseResponse(x.copy(), 48000) for sd, x in pair.items()} for sp, pair in irs.items()}
+    h.align_ipsilateral_all()
+    want = align_ipsilateral_all(irs, 48000, IPSILATERAL_PAIRS)
+    for sp in speakers:
+        for sd in ("left", "right"):
+            np.testing.assert_array_equal(h.irs[sp][sd].data, want[sp][sd])
+    # a pair list that revisits a speaker: the second search must see the first shift
+    chain = [("FL", "FR"), ("FR", "SL"), ("SL", "FL")]
+    h.irs = {sp: {sd: ImpulseResponse(x.copy(), 48000) for sd, x in pair.items()} for sp, pair in irs.items()}
+    h.align_ipsilateral_all(speaker_pairs=chain)
+    want = align_ipsilateral_all(irs, 48000, chain)
+    for sp in ("FL", "FR", "SL"):
+        for sd in ("left", "right"):
+            np.testing.assert_array_equal(h.irs[sp][sd].data, want[sp][sd])
+
+
+def test_alignment_matches_reference_run(gpu_ctx, golden):
+    """HRIR.align_ipsilateral_all (device lag search) and align_onset_groups_peak_leftref (device peak
+    search) against the reference's own run on the seeded nine-speaker set (fixture section 11)."""
+    from make_goldens import alignment_inputs
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.impulse_response import ImpulseResponse
+    g = golden("alignment")
+    irs = alignment_inputs()
+
+    class Est:
+        fs = 48000
+    for name, call in (("ipsi", lambda hh: hh.align_ipsilateral_all()),
+                       ("chain", lambda hh: hh.align_ipsilateral_all(speaker_pairs=[("FL", "FR"), ("FR", "SL"), ("SL", "FL")])),
+                       ("onset", lambda hh: hh.align_onset_groups_peak_leftref())):
+        h = HRIR(Est())
+        h.irs = {sp: {sd: ImpulseResponse(x.copy(), 48000) for sd, x in pair.items()} for sp, pair in irs.items()}
+        call(h)
+        for sp in irs:
+            for sd in ("left", "right"):
+                d = h.irs[sp][sd].data
+                assert int(np.argmax(np.abs(d))) == int(g[f"{name}_{sp}_{sd}_peak"]), (name, sp, sd)
+                np.testing.assert_array_equal(d[:96], g[f"{name}_{sp}_{sd}_head"])
+                np.testing.assert_array_equal(d[-96:], g[f"{name}_{sp}_{sd}_tail"])

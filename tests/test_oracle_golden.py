@@ -323,3 +323,26 @@ def test_pipeline_slice(golden):
     assert gain == pytest.approx(float(g["norm_gain_db"]), abs=1e-7)
     for sp, sd in order:
         np.testing.assert_allclose(irs[sp][sd] * 10 ** (gain / 20), g[f"final_{sp}_{sd}"], rtol=0, atol=1e-8)
+
+
+def test_ipsilateral_alignment(golden):
+    """Oracle restatement of HRIR.align_ipsilateral_all against the reference run (fixture section 11),
+    plus the reference's own assertion (tests/test_dsp_stages.py:105-121: a 7-sample offset is found)."""
+    from make_goldens import alignment_inputs
+    from impulse_hip.constants import IPSILATERAL_PAIRS
+    g = golden("alignment")
+    irs = alignment_inputs()
+    for name, pairs in (("ipsi", IPSILATERAL_PAIRS), ("chain", [("FL", "FR"), ("FR", "SL"), ("SL", "FL")])):
+        out = ohrir.align_ipsilateral_all(irs, 48000, pairs)
+        for sp in irs:
+            for sd in ("left", "right"):
+                d = out[sp][sd]
+                assert int(np.argmax(np.abs(d))) == int(g[f"{name}_{sp}_{sd}_peak"])
+                np.testing.assert_array_equal(d[:96], g[f"{name}_{sp}_{sd}_head"])
+                np.testing.assert_array_equal(d[-96:], g[f"{name}_{sp}_{sd}_tail"])
+                assert float(np.sum(d)) == float(g[f"{name}_{sp}_{sd}_sum"])
+    a = np.zeros(2048)
+    b = np.zeros(2048)
+    a[60] = 1.0
+    b[67] = 1.0
+    assert abs(ohrir.ipsilateral_lag(a, b, 1440)) == 7
