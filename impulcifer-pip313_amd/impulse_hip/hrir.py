@@ -22,6 +22,29 @@ except Exception:                                           # noqa: BLE001
         pass
 
 
+def _unit_impulse(n):
+    x = np.zeros(int(n))
+    x[0] = 1.0
+    return x
+
+
+def channel_balance_groups():
+    """core/hrir.py:38-40: one group per ipsilateral pair (a centre speaker stands alone)."""
+    return [[one] if one == two else [one, two] for one, two in IPSILATERAL_PAIRS]
+
+
+def get_center_value(fr, frequency_range):
+    """core/hrir.py:43-73: minus the shift FrequencyResponse.center would apply, without mutating `fr`
+    (band mean of `raw` on the curve's own grid, or the log-frequency linear interpolation at a point)."""
+    from .frequency_response import log_interp
+    if isinstance(frequency_range, (list, np.ndarray)) and len(frequency_range) > 1:
+        band = np.logical_and(fr.frequency >= frequency_range[0], fr.frequency <= frequency_range[1])
+        return -np.mean(fr.raw[band])
+    if isinstance(frequency_range, (list, np.ndarray)):
+        frequency_range = frequency_range[0]
+    return -float(log_interp(fr.frequency, fr.raw, np.array([float(frequency_range)]))[0])
+
+
 def _hann(M):
     if M <= 0:
         return np.zeros(0)
@@ -337,6 +360,71 @@ class HRIR(_PlotBase):
         for pair in self.irs.values():
             for sd, ir in pair.items():
                 ir.equalize(fir[0] if sd == "left" else fir[1])
+
+    # ---- channel balance (core/hrir.py:655-799) ---------------------------------------------
+    def channel_balance_firs(self, left_fr, right_fr, method):
+        """Two FIRs (left, right) that bring the ears of a speaker group to a common response.
+        Curve logic on the host (FrequencyResponse), FIR design on the device (K6, fp64)."""
+        from .frequency_response import FrequencyResponse
+        if method == "mids":
+            gain = 10 ** ((get_center_value(right_fr, [100, 3000]) - get_center_value(left_fr, [100, 3000])) / 20)
+            n = int(round(self.fs * 0.1))
+            return [_unit_impulse(n), _unit_impulse(n) * gain]
+        if method == "trend":
+            trend = FrequencyResponse(name="trend", frequency=left_fr.frequency, raw=left_fr.raw - right_fr.raw)
+            trend.smoothen_fractional_octave(window_size=2, treble_f_lower=20000,
+                                             treble_f_upper=int(round(self.fs / 2)))
+            right_fr.equalization = trend.smoothed
+            fir = right_fr.minimum_phase_impulse_response(fs=self.fs, normalize=False)
+            return [_unit_impulse(len(fir)), fir]
+        if method in ("left", "right"):
+            ref, subj = (left_fr, right_fr) if method == "left" else (right_fr, left_fr)
+            ref.smoothen_fractional_octave(window_size=1 / 3, treble_f_lower=20000,
+                                           treble_f_upper=int(round(self.fs / 2)))
+            gain = ref.center([100, 10000])
+            subj.raw += gain
+            subj.target = ref.smoothed
+            subj.error = subj.raw - subj.target
+            subj.smoothen_heavy_light()
+            subj.equalize(max_gain=15, treble_f_lower=20000, treble_f_upper=self.fs / 2)
+            fir = subj.minimum_phase_impulse_response(fs=self.fs, normalize=False)
+            return [_unit_impulse(len(fir)), fir] if method == "left" else [fir, _unit_impulse(len(fir))]
+        if method in ("avg", "min"):
+            gain = (get_center_value(left_fr, [100, 10000]) + get_center_value(right_fr, [100, 10000])) / 2
+            left_fr.raw += gain
+            right_fr.raw += gain
+            for fr in (left_fr, right_fr):
+                fr.smoothen_fractional_octave(window_size=1 / 3, treble_f_lower=20000, treble_f_upper=23999)
+            target = (left_fr.raw + right_fr.raw) / 2 if method == "avg" else np.min([left_fr.raw, right_fr.raw], axis=0)
+            firs = []
+            for fr in (left_fr, right_fr):
+                fr.target = target
+                fr.error = fr.raw - fr.target
+                fr.smoothen_fractional_octave(window_size=1 / 3, treble_f_lower=20000, treble_f_upper=23999)
+                fr.equalize(max_gain=15, treble_f_lower=2000, treble_f_upper=self.fs / 2)
+                firs.append(fr.minimum_phase_impulse_response(fs=self.fs, normalize=False))
+            return firs
+        try:
+            gain = 10 ** (float(method) / 20)
+        except ValueError:
+            raise ValueError(f'"{method}" is not valid value for channel balance method.')
+        n = int(round(self.fs * 0.1))
+        return [_unit_impulse(n), _unit_impulse(n) * gain]
+
+    def correct_channel_balance(self, method):
+        """core/hrir.py:766-799: per speaker group, equalize the ears to the same response."""
+        eqir = HRIR(self.estimator)
+        for speakers in channel_balance_groups():
+            if any(sp not in self.irs for sp in speakers):
+                continue                                   # balancing needs the whole group
+            left = np.mean(np.vstack([self.irs[sp]["left"].data for sp in speakers]), axis=0)
+            right = np.mean(np.vstack([self.irs[sp]["right"].data for sp in speakers]), axis=0)
+            firs = self.channel_balance_firs(ImpulseResponse(left, self.fs).frequency_response(),
+                                             ImpulseResponse(right, self.fs).frequency_response(), method)
+            for sp in speakers:
+                self.irs[sp]["left"].equalize(firs[0])
+                self.irs[sp]["right"].equalize(firs[1])
+        return eqir
 
     def resample(self, fs):
         raise NotImplementedError("resample depends on nnresample (no oracle here, parity unpinned)")
