@@ -171,6 +171,13 @@ def main():
                          "event records from perturbing the throughput being measured)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 at communicator
+    # creation, so everything the run writes to stdout is sent to stderr and the JSON line goes to the
+    # real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,9 +190,14 @@ def main():
     # folded onto the visible devices and the spectrum broadcast is staged through host memory.
     backend = os.environ.get("IMPULSE_BENCH_BACKEND", "nccl")
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
-    if world > 1:
+    # IMPULSE_BENCH_FORCE_DIST=1 takes the collective path with a single rank too (a one-GPU box can
+    # then exercise RCCL init, the spectrum broadcast and the reductions)
+    if world > 1 or os.environ.get("IMPULSE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(dev_index)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -220,7 +232,7 @@ def main():
     else:
         plan = ConvPlan(ctx, None, L, "same", ws_channels=ws_channels, empty_M=M, n_filters=1)
     bcast_bytes = 0
-    if world > 1:
+    if dist is not None:
         bcast_bytes = broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0,
                                               via_host=(backend != "nccl"))   # RCCL over xGMI
 
@@ -346,8 +358,8 @@ def main():
                        f"{bcast_bytes} B spectrum at plan creation"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity,
         }
-        print(json.dumps(result))
         sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     plan.close()
     del d_x, d_y, d_ys
     ctx.close()
