@@ -70,7 +70,7 @@ static int ctx_row_tables(imp_ctx* ctx) {
 }
 
 static int ctx_twiddles(imp_ctx* ctx, int n1, TwSet* out) {
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   auto it = ctx->tw_by_n1.find(n1);
   if (it != ctx->tw_by_n1.end()) {
     *out = it->second;
@@ -158,6 +158,7 @@ extern "C" int imp_ctx_create(int device_id, imp_ctx** out) {
 
 extern "C" int imp_ctx_set_stream(imp_ctx* ctx, void* hip_stream) {
   if (!ctx) return fail(IMP_ERR_INVALID, "null ctx");
+  IMP_CTX_LOCK(ctx);
   if (ctx->own_stream && ctx->stream) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipStreamDestroy(ctx->stream));
@@ -523,6 +524,7 @@ static int plan_sync_lanes(imp_plan* p);
 
 extern "C" void imp_plan_destroy(imp_plan* p) {
   if (!p) return;
+  IMP_CTX_LOCK(p->ctx);
   (void)hipSetDevice(p->ctx->device);
   (void)plan_sync_lanes(p);
   if (p->ab) (void)hipFree(p->ab);
@@ -536,6 +538,7 @@ extern "C" void imp_plan_destroy(imp_plan* p) {
 extern "C" int imp_conv_plan_create_empty(imp_ctx* ctx, int64_t M, int64_t n_filters, int64_t L, int mode,
                                           int64_t ws_channels, imp_plan** out) {
   if (!ctx || !out) return fail(IMP_ERR_INVALID, "imp_conv_plan_create_empty: null argument");
+  IMP_CTX_LOCK(ctx);
   *out = nullptr;
   imp_plan* p = new (std::nothrow) imp_plan();
   if (!p) return fail(IMP_ERR_ALLOC, "out of host memory");
@@ -553,7 +556,9 @@ extern "C" int imp_conv_plan_create_empty(imp_ctx* ctx, int64_t M, int64_t n_fil
 extern "C" int imp_conv_plan_create(imp_ctx* ctx, const double* filter, int64_t M, int64_t n_filters,
                                     int64_t filter_ld, int64_t L, int mode, int64_t ws_channels,
                                     imp_plan** out) {
+  if (!ctx || !out) return fail(IMP_ERR_INVALID, "imp_conv_plan_create: null argument");
   if (!filter) return fail(IMP_ERR_INVALID, "imp_conv_plan_create: null filter");
+  IMP_CTX_LOCK(ctx);
   if (n_filters > 1 && filter_ld < M) return fail(IMP_ERR_INVALID, "filter_ld < M");
   imp_plan* p = nullptr;
   int rc = imp_conv_plan_create_empty(ctx, M, n_filters, L, mode, ws_channels, &p);
@@ -609,6 +614,7 @@ extern "C" int imp_plan_info(const imp_plan* p, int64_t* nfft, int64_t* out_len,
 
 extern "C" int imp_plan_spectrum(imp_plan* p, void** dptr, size_t* bytes) {
   if (!p || !dptr || !bytes) return fail(IMP_ERR_INVALID, "imp_plan_spectrum: null argument");
+  IMP_CTX_LOCK(p->ctx);
   *dptr = p->ab;
   *bytes = (size_t)p->N1 * imp::kN2 * (size_t)p->n_filters * sizeof(float4);
   return IMP_OK;
@@ -616,6 +622,7 @@ extern "C" int imp_plan_spectrum(imp_plan* p, void** dptr, size_t* bytes) {
 
 extern "C" int imp_plan_set_timing(imp_plan* p, int enable) {
   if (!p) return fail(IMP_ERR_INVALID, "null plan");
+  IMP_CTX_LOCK(p->ctx);
   int rc = ctx_bind(p->ctx);
   if (rc) return rc;
   p->timing = enable < 0 ? 0 : enable;
@@ -648,6 +655,7 @@ static int plan_collect_timing(imp_plan* p) {
 
 extern "C" int imp_plan_get_timing(imp_plan* p, double ms[3], int64_t* launches, int reset) {
   if (!p || !ms || !launches) return fail(IMP_ERR_INVALID, "imp_plan_get_timing: null argument");
+  IMP_CTX_LOCK(p->ctx);
   int rc = ctx_bind(p->ctx);
   if (rc) return rc;
   if ((rc = plan_collect_timing(p))) return rc;
@@ -725,6 +733,7 @@ static int run_group_with(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64
 extern "C" int imp_conv_execute_device(imp_plan* p, const float* d_x, int64_t B, int64_t chan_stride_in,
                                        int64_t elem_stride_in, float* d_y, int64_t chan_stride_out) {
   if (!p || !d_x || !d_y) return fail(IMP_ERR_INVALID, "imp_conv_execute_device: null argument");
+  IMP_CTX_LOCK(p->ctx);
   if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
   if (elem_stride_in < 1) return fail(IMP_ERR_INVALID, "elem_stride_in must be >= 1");
   // one channel is addressed through a 32-bit buffer range
@@ -750,6 +759,7 @@ extern "C" int imp_conv_execute_device(imp_plan* p, const float* d_x, int64_t B,
 extern "C" int imp_conv_execute_device_pcm(imp_plan* p, const void* d_pcm, int bits, int64_t B, int64_t chan_stride_in,
                                            int64_t elem_stride_in, float* d_y, int64_t chan_stride_out) {
   if (!p || !d_pcm || !d_y) return fail(IMP_ERR_INVALID, "imp_conv_execute_device_pcm: null argument");
+  IMP_CTX_LOCK(p->ctx);
   if (bits != 16 && bits != 32) return fail(IMP_ERR_INVALID, "PCM width must be 16 or 32 bits");
   if (B < 0 || elem_stride_in < 1) return fail(IMP_ERR_INVALID, "bad B or elem_stride_in");
   if ((double)p->L * (double)elem_stride_in * 4.0 >= 4294967296.0)
@@ -776,6 +786,7 @@ extern "C" int imp_conv_execute_device_pcm(imp_plan* p, const void* d_pcm, int b
 
 extern "C" int imp_plan_set_overlap(imp_plan* p, int lanes) {
   if (!p) return fail(IMP_ERR_INVALID, "null plan");
+  IMP_CTX_LOCK(p->ctx);
   if (lanes < 1 || lanes > 4) return fail(IMP_ERR_INVALID, "lanes must be in [1, 4]");
   if (p->ws_channels / lanes < 1) return fail(IMP_ERR_INVALID, "workspace of %lld channels cannot be split %d ways",
                                               (long long)p->ws_channels, lanes);
@@ -814,6 +825,7 @@ static int plan_staging(imp_plan* p, size_t in_bytes, size_t out_bytes) {
 
 extern "C" int imp_conv_execute(imp_plan* p, const float* x, int64_t B, int64_t ld_in, float* y, int64_t ld_out) {
   if (!p || (!x && B) || (!y && B)) return fail(IMP_ERR_INVALID, "imp_conv_execute: null argument");
+  IMP_CTX_LOCK(p->ctx);
   if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
   if (ld_in < p->L) return fail(IMP_ERR_INVALID, "ld_in %lld < L %lld", (long long)ld_in, (long long)p->L);
   if (ld_out < p->out_len) return fail(IMP_ERR_INVALID, "ld_out %lld < out_len %lld", (long long)ld_out, (long long)p->out_len);
@@ -840,6 +852,7 @@ extern "C" int imp_conv_execute(imp_plan* p, const float* x, int64_t B, int64_t 
 
 extern "C" int imp_conv_execute_interleaved(imp_plan* p, const float* frames, int64_t C, float* y, int64_t ld_out) {
   if (!p || !frames || !y) return fail(IMP_ERR_INVALID, "imp_conv_execute_interleaved: null argument");
+  IMP_CTX_LOCK(p->ctx);
   if (C < 1) return fail(IMP_ERR_INVALID, "C < 1");
   if (ld_out < p->out_len) return fail(IMP_ERR_INVALID, "ld_out < out_len");
   int rc = ctx_bind(p->ctx);
@@ -864,6 +877,7 @@ extern "C" int imp_conv_execute_interleaved(imp_plan* p, const float* frames, in
 extern "C" int imp_plan_debug_run_stage(imp_plan* p, const float* x, int64_t B, int64_t ld_in, int stage,
                                         float* ws_out_host) {
   if (!p || !x || !ws_out_host) return fail(IMP_ERR_INVALID, "imp_plan_debug_run_stage: null argument");
+  IMP_CTX_LOCK(p->ctx);
   if (B < 1 || B > p->ws_channels) return fail(IMP_ERR_INVALID, "debug stage: B must be in [1, ws_channels]");
   if (stage < 0 || stage > 1) return fail(IMP_ERR_INVALID, "stage must be 0 (after pass A) or 1 (after pass B)");
   int rc = ctx_bind(p->ctx);
@@ -931,6 +945,7 @@ static int peak_index_impl(imp_ctx* ctx, const float* d_x, const int64_t* off, c
 extern "C" int imp_peak_index_device(imp_ctx* ctx, const float* d_x, const int64_t* off, const int64_t* len,
                                      int64_t B, double peak_height, int64_t* idx_out, float* maxabs_out) {
   if (!ctx || (B && (!d_x || !off || !len || !idx_out))) return fail(IMP_ERR_INVALID, "imp_peak_index_device: null argument");
+  IMP_CTX_LOCK(ctx);
   if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
   for (int64_t b = 0; b < B; ++b)
     if (len[b] < 0 || off[b] < 0) return fail(IMP_ERR_INVALID, "negative offset/length in row %lld", (long long)b);
@@ -942,6 +957,7 @@ extern "C" int imp_peak_index_device(imp_ctx* ctx, const float* d_x, const int64
 extern "C" int imp_peak_index(imp_ctx* ctx, const float* x, const int64_t* off, const int64_t* len, int64_t B,
                               double peak_height, int64_t* idx_out, float* maxabs_out) {
   if (!ctx || (B && (!x || !off || !len || !idx_out))) return fail(IMP_ERR_INVALID, "imp_peak_index: null argument");
+  IMP_CTX_LOCK(ctx);
   if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
   if (B == 0) return IMP_OK;
   int64_t total = 0;
@@ -987,7 +1003,7 @@ extern "C" int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_
   }
   int rc = ctx_bind(ctx);
   if (rc) return rc;
-  std::lock_guard<std::mutex> lk(ctx->mu);          // the context's scratch buffer is shared
+  IMP_CTX_LOCK(ctx);
   hipStream_t s = ctx->stream;
   // scratch: a, b (fp64), 4 x int64 meta, arg (int64), val (fp64)
   const size_t meta = (size_t)B * sizeof(int64_t);
@@ -1029,6 +1045,7 @@ extern "C" int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_
 extern "C" int imp_apply_window(imp_ctx* ctx, float* x, const int64_t* off, const int64_t* len, int64_t B,
                                 const imp_window_params* params) {
   if (!ctx || (B && (!x || !off || !len || !params))) return fail(IMP_ERR_INVALID, "imp_apply_window: null argument");
+  IMP_CTX_LOCK(ctx);
   if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
   if (B == 0) return IMP_OK;
   int64_t total = 0, maxlen = 0;

@@ -40,7 +40,7 @@ struct imp_ctx {
   cf* tw_t2 = nullptr;
   cf* tw_t4 = nullptr;
   std::map<int, TwSet> tw_by_n1;        // keyed by N1
-  std::mutex mu;
+  std::recursive_mutex mu;          // serialises the entry points that touch this context (IMP_CTX_LOCK)
   // scratch for the small ragged kernels
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -51,6 +51,12 @@ struct imp_ctx {
   // K2 plans keyed by row length n
   std::map<long long, struct MagPlan*> magnitude_plans;
 };
+
+// Every compute entry point holds the context's lock from argument check to return: the Python host
+// shares one context between threads (reference: ThreadPoolExecutor workers, core/hrir.py:529-537,
+// core/parallel_utils.py:53-55) and ctypes drops the GIL during calls.  GPU work is stream ordered
+// per context anyway, so the lock costs no overlap.
+#define IMP_CTX_LOCK(ctx) std::lock_guard<std::recursive_mutex> imp_ctx_lock_((ctx)->mu)
 
 int ctx_bind(imp_ctx* ctx);
 void minphase_plans_destroy(imp_ctx* ctx);

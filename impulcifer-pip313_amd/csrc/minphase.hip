@@ -308,12 +308,13 @@ static int minphase_run(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, 
   for (int64_t b = 0; b < B; ++b)
     if (gain[b * n + n - 1] != 0.0)
       return fail(IMP_ERR_INVALID, "A Type II filter must have zero gain at the Nyquist frequency (channel %lld)", (long long)b);
+  IMP_CTX_LOCK(ctx);                               // plan buffers are shared by all callers of this context
   int rc = ctx_bind(ctx);
   if (rc) return rc;
 
   MinPhasePlan* p = nullptr;
   {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     const auto key = std::make_pair((long long)n, (long long)std::llround(fs * 1000.0));
     auto it = ctx->minphase_plans.find(key);
     if (it != ctx->minphase_plans.end()) {
@@ -424,7 +425,7 @@ static void mag_plan_free(MagPlan* p) {
 }
 
 void magnitude_plans_destroy(imp_ctx* ctx) {
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   auto& m = mag_plans(ctx);
   for (auto& kv : m) mag_plan_free(kv.second);
   m.clear();
@@ -432,6 +433,7 @@ void magnitude_plans_destroy(imp_ctx* ctx) {
 
 extern "C" int imp_magnitude_db(imp_ctx* ctx, const double* x, int64_t B, int64_t n, double* db_out) {
   if (!ctx || (B && n && (!x || !db_out))) return fail(IMP_ERR_INVALID, "imp_magnitude_db: null argument");
+  IMP_CTX_LOCK(ctx);
   if (B < 0 || n < 0 || n > (1 << 22)) return fail(IMP_ERR_INVALID, "imp_magnitude_db: bad B or n");
   if (B == 0 || n == 0) return IMP_OK;
   int rc = ctx_bind(ctx);
@@ -439,7 +441,7 @@ extern "C" int imp_magnitude_db(imp_ctx* ctx, const double* x, int64_t B, int64_
   const int half = (int)((n + 1) / 2);
   MagPlan* p = nullptr;
   {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     auto& plans = mag_plans(ctx);
     auto it = plans.find((long long)n);
     if (it != plans.end()) {

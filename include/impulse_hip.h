@@ -12,8 +12,9 @@
  *   - no exceptions and no torch / numpy types cross the boundary: plain pointers and sizes
  *   - "host" pointers are ordinary process memory, "device" pointers are HIP device memory of
  *     the context's GPU (e.g. obtained from imp_malloc or any other HIP allocator)
- *   - a context owns one GPU and one stream; calls on one context are stream ordered; distinct
- *     contexts may be used from distinct threads concurrently
+ *   - a context owns one GPU and one stream; calls on one context are stream ordered.  Every entry
+ *     point is thread safe: calls that share a context (or plans of one context) serialise on the
+ *     context's lock, distinct contexts run concurrently
  *   - arithmetic is IEEE fp32 on the device; filter spectra of deconvolution plans are prepared
  *     in fp64 on the host and rounded once
  */

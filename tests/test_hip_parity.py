@@ -912,3 +912,37 @@ def test_channel_balance_matches_reference_run(gpu_ctx, golden, method):
             assert err.max() <= (2e-6 if method in ("mids", "-1.5") else 5e-4)   # the Nyquist bin itself (K6 note)
     with pytest.raises(ValueError):
         h.correct_channel_balance("loud")
+
+
+def test_shared_context_from_many_threads(gpu_ctx):
+    """The reference calls these methods from ThreadPoolExecutor workers (core/hrir.py:529-537) and, on
+    no-GIL builds, runs the EQ workers as threads (core/parallel_utils.py:53-55); ctypes drops the GIL, so
+    one context really is entered concurrently.  Results must equal the single-threaded ones."""
+    from concurrent.futures import ThreadPoolExecutor
+    from impulse_hip import ConvPlan
+    rng = np.random.default_rng(99)
+    rows = [rng.standard_normal(5000 + 37 * i).astype(np.float32) for i in range(24)]
+    gains = [np.abs(1.0 + 0.2 * rng.standard_normal((2, 1200))) for _ in range(6)]
+    for g in gains:
+        g[:, -1] = 0.0
+    xs = [rng.standard_normal((2, 30000)).astype(np.float32) for _ in range(6)]
+    plan = ConvPlan(gpu_ctx, rng.standard_normal(2000), 30000, "same")
+    want_pk = [gpu_ctx.peak_index([r])[0][0] for r in rows]
+    want_fir = [gpu_ctx.minphase_fir(g, 48000) for g in gains]
+    want_mag = [gpu_ctx.magnitude_db(r[None, :4096].astype(np.float64)) for r in rows[:6]]
+    want_y = [plan.execute(x) for x in xs]
+
+    def job(i):
+        kind = i % 4
+        if kind == 0:
+            return gpu_ctx.peak_index([rows[i % 24]])[0][0] == want_pk[i % 24]
+        if kind == 1:
+            return np.array_equal(gpu_ctx.minphase_fir(gains[i % 6], 48000), want_fir[i % 6])
+        if kind == 2:
+            return np.array_equal(gpu_ctx.magnitude_db(rows[i % 6][None, :4096].astype(np.float64)), want_mag[i % 6])
+        return np.array_equal(plan.execute(xs[i % 6]), want_y[i % 6])
+
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        ok = list(pool.map(job, range(96)))
+    plan.close()
+    assert all(ok)
