@@ -190,6 +190,7 @@ extern "C" void imp_ctx_destroy(imp_ctx* ctx) {
   if (ctx->tw_t4) (void)hipFree(ctx->tw_t4);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   minphase_plans_destroy(ctx);
+  fft_roots_destroy(ctx);
   magnitude_plans_destroy(ctx);
   for (auto st : ctx->side_streams) {
     (void)hipStreamSynchronize(st);
@@ -563,19 +564,27 @@ extern "C" int imp_conv_plan_create(imp_ctx* ctx, const double* filter, int64_t 
   imp_plan* p = nullptr;
   int rc = imp_conv_plan_create_empty(ctx, M, n_filters, L, mode, ws_channels, &p);
   if (rc) return rc;
-  const size_t plane = (size_t)p->N1 * imp::kN2;
-  std::vector<float4> ab(plane);
-  std::vector<cd> H;
-  for (int64_t f = 0; f < n_filters; ++f) {
-    host_rfft(filter + f * filter_ld, M, p->Nc, H);
-    host_alpha_beta(H, p->Nc, p->N1, ab.data());
-    hipError_t e = hipMemcpyAsync(p->ab + (size_t)f * plane, ab.data(), plane * sizeof(float4),
-                                  hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) {
-      imp_plan_destroy(p);
-      return fail(IMP_ERR_HIP, "spectrum upload: %s", hipGetErrorString(e));
+  // IMPULSE_HIP_HOST_SPECTRUM=1 keeps the fp64 host preparation (the cross-check path of the tests)
+  const char* host_env = std::getenv("IMPULSE_HIP_HOST_SPECTRUM");
+  if (host_env && host_env[0] == '1') {
+    const size_t plane = (size_t)p->N1 * imp::kN2;
+    std::vector<float4> ab(plane);
+    std::vector<cd> H;
+    for (int64_t f = 0; f < n_filters; ++f) {
+      host_rfft(filter + f * filter_ld, M, p->Nc, H);
+      host_alpha_beta(H, p->Nc, p->N1, ab.data());
+      hipError_t e = hipMemcpyAsync(p->ab + (size_t)f * plane, ab.data(), plane * sizeof(float4),
+                                    hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) {
+        imp_plan_destroy(p);
+        return fail(IMP_ERR_HIP, "spectrum upload: %s", hipGetErrorString(e));
+      }
     }
+  } else if ((rc = spectrum_alpha_beta_device(ctx, filter, M, n_filters, n_filters > 1 ? filter_ld : M, p->Nc, p->N1,
+                                               p->ab))) {
+    imp_plan_destroy(p);
+    return rc;
   }
   *out = p;
   return IMP_OK;

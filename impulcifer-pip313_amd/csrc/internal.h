@@ -50,6 +50,8 @@ struct imp_ctx {
   std::map<std::pair<long long, long long>, MinPhasePlan*> minphase_plans;
   // K2 plans keyed by row length n
   std::map<long long, struct MagPlan*> magnitude_plans;
+  // fp64 roots of unity on the device, keyed by transform length (filter-spectrum preparation)
+  std::map<long long, void*> fft_roots;
 };
 
 // Every compute entry point holds the context's lock from argument check to return: the Python host
@@ -61,3 +63,9 @@ struct imp_ctx {
 int ctx_bind(imp_ctx* ctx);
 void minphase_plans_destroy(imp_ctx* ctx);
 void magnitude_plans_destroy(imp_ctx* ctx);
+void fft_roots_destroy(imp_ctx* ctx);
+// alpha/beta planes of `n_filters` real filters (host fp64, row pitch filter_ld) for circular length
+// 2 Nc, computed in fp64 ON THE DEVICE and rounded once to fp32 into d_ab[n_filters][N1*4096]
+// (register order of the row pass).  minphase.hip, next to the fp64 Stockham FFT it uses.
+int spectrum_alpha_beta_device(imp_ctx* ctx, const double* filters, int64_t M, int64_t n_filters, int64_t filter_ld,
+                               int64_t Nc, int N1, float4* d_ab);

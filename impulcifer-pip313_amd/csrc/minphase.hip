@@ -513,3 +513,131 @@ extern "C" int imp_magnitude_db(imp_ctx* ctx, const double* x, int64_t B, int64_
   HIP_TRY(hipStreamSynchronize(s));
   return IMP_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Filter spectra of convolution plans (alpha/beta planes), fp64 on the device.
+// The same arithmetic as host_rfft + host_alpha_beta in impulse_hip.hip (kept there as the debug /
+// cross-check path): one packed Nc-point complex FFT per filter, real-FFT unpack, then
+//   alpha = (H_k (1+s) + G_k (1-s)) / (2 Nc), beta = i c (H_k - G_k) / (2 Nc),  G_k = conj H[Nc-k],
+//   s + i c ... = sin/cos(-pi k / Nc),
+// rounded once to fp32 in the row pass's register order.  A 16-filter equalisation plan costs ~8 ms per
+// filter on one host core; here the whole batch is a few launches.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void roots_kernel(cdbl* __restrict__ roots, int N) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  double sn, cs;
+  sincospi(-2.0 * (double)k / (double)N, &sn, &cs);
+  roots[k] = make_double2(cs, sn);
+}
+
+// z[f][n] = h[f][2n] + i h[f][2n+1], zero beyond M
+__global__ __launch_bounds__(256) void pack_filter_kernel(const double* __restrict__ h, cdbl* __restrict__ z, long long M,
+                                                          long long ld, int Nc) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= Nc) return;
+  const double* row = h + (long long)blockIdx.y * ld;
+  const long long i = 2ll * n;
+  z[(long long)blockIdx.y * Nc + n] = make_double2(i < M ? row[i] : 0.0, i + 1 < M ? row[i + 1] : 0.0);
+}
+
+__device__ __forceinline__ cdbl zconj(cdbl a) { return make_double2(a.x, -a.y); }
+
+// H[k] of the real filter from the packed transform z (k in [0, Nc])
+__device__ __forceinline__ cdbl unpack_bin(const cdbl* __restrict__ z, int k, int Nc) {
+  const cdbl zk = z[k % Nc];
+  const cdbl zm = zconj(z[(Nc - k) % Nc]);
+  const cdbl E = make_double2(0.5 * (zk.x + zm.x), 0.5 * (zk.y + zm.y));
+  const cdbl d = make_double2(zk.x - zm.x, zk.y - zm.y);
+  const cdbl O = make_double2(0.5 * d.y, -0.5 * d.x);                 // -i/2 (zk - zm)
+  double sn, cs;
+  sincospi(-(double)k / (double)Nc, &sn, &cs);
+  const cdbl wO = zmul(make_double2(cs, sn), O);
+  return make_double2(E.x + wO.x, E.y + wO.y);
+}
+
+__global__ __launch_bounds__(256) void alpha_beta_kernel(const cdbl* __restrict__ zall, float4* __restrict__ ab, int Nc,
+                                                         int N1) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // position in the plane: k1*4096 + q*256 + u
+  if (idx >= Nc) return;
+  const cdbl* z = zall + (long long)blockIdx.y * Nc;
+  const int k1 = idx >> 12, r = idx & 4095, q = r >> 8, u = r & 255;
+  const int k2 = (u >> 4) + 16 * (u & 15) + 256 * q;
+  const long long k = (long long)k1 + (long long)N1 * k2;
+  const double inv = 1.0 / (double)Nc;
+  float4 o;
+  if (k == 0) {
+    const cdbl z0 = z[0];
+    o = make_float4((float)((z0.x + z0.y) * inv), 0.f, (float)((z0.x - z0.y) * inv), 0.f);
+  } else {
+    const cdbl Hk = unpack_bin(z, (int)k, Nc);
+    const cdbl Gk = zconj(unpack_bin(z, Nc - (int)k, Nc));
+    double sn, cs;
+    sincospi(-(double)k / (double)Nc, &sn, &cs);
+    const double a = 0.5 * inv;
+    const cdbl alpha = make_double2(a * (Hk.x * (1.0 + sn) + Gk.x * (1.0 - sn)), a * (Hk.y * (1.0 + sn) + Gk.y * (1.0 - sn)));
+    const cdbl dd = make_double2(Hk.x - Gk.x, Hk.y - Gk.y);
+    const cdbl beta = make_double2(-a * cs * dd.y, a * cs * dd.x);    // i (a c) (Hk - Gk)
+    o = make_float4((float)alpha.x, (float)alpha.y, (float)beta.x, (float)beta.y);
+  }
+  ab[(long long)blockIdx.y * Nc + idx] = o;
+}
+
+}  // namespace
+
+void fft_roots_destroy(imp_ctx* ctx) {
+  for (auto& kv : ctx->fft_roots) (void)hipFree(kv.second);
+  ctx->fft_roots.clear();
+}
+
+int spectrum_alpha_beta_device(imp_ctx* ctx, const double* filters, int64_t M, int64_t n_filters, int64_t filter_ld,
+                               int64_t Nc, int N1, float4* d_ab) {
+  const std::vector<int> fac = factorise((int)Nc);
+  if (fac.empty()) return fail(IMP_ERR_UNSUPPORTED, "spectrum length %lld is not 2^a 3^b 5^c", (long long)Nc);
+  hipStream_t s = ctx->stream;
+  cdbl* roots = nullptr;
+  auto it = ctx->fft_roots.find((long long)Nc);
+  if (it != ctx->fft_roots.end()) {
+    roots = (cdbl*)it->second;
+  } else {
+    HIP_TRY(hipMalloc((void**)&roots, (size_t)Nc * sizeof(cdbl)));
+    hipLaunchKernelGGL(roots_kernel, dim3((unsigned)((Nc + 255) / 256)), dim3(256), 0, s, roots, (int)Nc);
+    HIP_TRY(hipGetLastError());
+    ctx->fft_roots[(long long)Nc] = roots;
+  }
+  // filters go through in chunks of <= 64 MiB per ping-pong buffer
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n_filters, ((int64_t)64 << 20) / (Nc * (int64_t)sizeof(cdbl))));
+  cdbl *a = nullptr, *b = nullptr;
+  double* d_h = nullptr;
+  auto cleanup = [&](int code) {
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    (void)hipFree(d_h);
+    return code;
+  };
+  if (hipMalloc((void**)&a, (size_t)chunk * Nc * sizeof(cdbl)) != hipSuccess ||
+      hipMalloc((void**)&b, (size_t)chunk * Nc * sizeof(cdbl)) != hipSuccess ||
+      hipMalloc((void**)&d_h, (size_t)chunk * M * sizeof(double)) != hipSuccess)
+    return cleanup(fail(IMP_ERR_ALLOC, "device buffers for the filter spectra (%lld filters of %lld points)",
+                        (long long)chunk, (long long)Nc));
+  for (int64_t f0 = 0; f0 < n_filters; f0 += chunk) {
+    const int64_t nf = std::min(chunk, n_filters - f0);
+    if (hipMemcpy2DAsync(d_h, (size_t)M * sizeof(double), filters + f0 * filter_ld, (size_t)filter_ld * sizeof(double),
+                         (size_t)M * sizeof(double), (size_t)nf, hipMemcpyHostToDevice, s) != hipSuccess)
+      return cleanup(fail(IMP_ERR_HIP, "filter upload failed"));
+    const dim3 grid((unsigned)((Nc + 255) / 256), (unsigned)nf);
+    hipLaunchKernelGGL(pack_filter_kernel, grid, dim3(256), 0, s, d_h, a, (long long)M, (long long)M, (int)Nc);
+    cdbl *cur = a, *oth = b;
+    int rc = run_fft(ctx, fac, roots, (int)Nc, nf, -1, &cur, &oth);
+    if (rc) return cleanup(rc);
+    hipLaunchKernelGGL(alpha_beta_kernel, grid, dim3(256), 0, s, cur, d_ab + f0 * Nc, (int)Nc, N1);
+    if (hipGetLastError() != hipSuccess) return cleanup(fail(IMP_ERR_HIP, "alpha/beta launch failed"));
+    // the host rows of this chunk may be reused by the caller after return: drain before the next upload
+    if (hipStreamSynchronize(s) != hipSuccess) return cleanup(fail(IMP_ERR_HIP, "filter spectrum: stream error"));
+  }
+  return cleanup(IMP_OK);
+}

@@ -235,8 +235,9 @@ class FrequencyResponse(object):
     # ---- smoothing ------------------------------------------------------------------------
     def _window_size(self, octaves):
         """Odd Savitzky-Golay window covering ``octaves`` on this grid."""
-        ratios = [self.frequency[i] / self.frequency[i - 1] for i in range(1, len(self.frequency))]
-        step = sum(ratios) / len(ratios)
+        f = np.asarray(self.frequency, dtype=np.float64)
+        # mean neighbour ratio; cumsum adds left to right, i.e. the same roundings as a running Python sum
+        step = float(np.cumsum(f[1:] / f[:-1])[-1]) / (len(f) - 1)
         size = round(math.log(2 ** octaves) / math.log(step))
         return size + 1 if size % 2 == 0 else size
 

@@ -426,6 +426,15 @@ class HRIR(_PlotBase):
                 self.irs[sp]["right"].equalize(firs[1])
         return eqir
 
+    def equalize_channels(self, firs):
+        """`firs`: {(speaker, side): taps}.  Same result as calling ir.equalize(taps) on each channel
+        (core/pipeline.py:690-691 does exactly that loop), sent to the device as one batch."""
+        from .impulse_response import fir_convolve_full_batch
+        keys = [k for k in firs if k[0] in self.irs and k[1] in self.irs[k[0]]]
+        ys = fir_convolve_full_batch([self.irs[sp][sd].data for sp, sd in keys], [firs[k] for k in keys])
+        for (sp, sd), y in zip(keys, ys):
+            self.irs[sp][sd].data = y
+
     def resample(self, fs):
         raise NotImplementedError("resample depends on nnresample (no oracle here, parity unpinned)")
 

@@ -33,6 +33,35 @@ def fir_convolve_full(x, taps):
         plan.close()
 
 
+def fir_convolve_full_batch(signals, taps):
+    """[scipy.signal.convolve(x_i, taps_i, 'full')] for equally long signals and equally long FIRs, as ONE
+    plan with per-channel filters and one launch group (K5) instead of a plan per channel."""
+    xs = [np.asarray(x) for x in signals]
+    hs = [np.asarray(h, dtype=np.float64) for h in taps]
+    if len(xs) != len(hs):
+        raise ValueError("fir_convolve_full_batch: one FIR per signal")
+    out = [None] * len(xs)
+    groups = {}
+    for i, (x, h) in enumerate(zip(xs, hs)):
+        if len(x) == 0 or len(h) == 0:
+            out[i] = np.zeros(0)
+        else:
+            groups.setdefault((len(x), len(h)), []).append(i)
+    ctx = _native.default_context()
+    for (n, m), idx in groups.items():
+        if len(idx) == 1:
+            out[idx[0]] = fir_convolve_full(xs[idx[0]], hs[idx[0]])
+            continue
+        plan = _native.ConvPlan(ctx, np.stack([hs[i] for i in idx]), n, "full", ws_channels=len(idx))
+        try:
+            y = plan.execute(np.stack([xs[i] for i in idx]))
+        finally:
+            plan.close()
+        for row, i in zip(y, idx):
+            out[i] = row.astype(np.float64)
+    return out
+
+
 class ImpulseResponse(_PlotBase):
     def __init__(self, data, fs, recording=None):
         self.fs = fs

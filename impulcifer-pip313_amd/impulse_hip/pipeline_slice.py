@@ -43,9 +43,9 @@ def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, deca
     if target is None:
         target = FrequencyResponse(name="target", frequency=common.copy(), raw=0)
     tasks = [(sp, sd) for sp, pair in hrir.irs.items() for sd in pair]
-    for sp, sd, fir in process_equalization_batch(tasks, room_frs, hp_left, hp_right, eq_left, eq_right, target,
-                                                  common, fs):
-        hrir.irs[sp][sd].equalize(fir)
+    hrir.equalize_channels({(sp, sd): fir for sp, sd, fir in
+                            process_equalization_batch(tasks, room_frs, hp_left, hp_right, eq_left, eq_right, target,
+                                                       common, fs)})
     snap("equalize")
 
     if decay is not None:

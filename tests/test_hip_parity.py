@@ -15,6 +15,8 @@ reference's demo measurements are cropped to).  On a w
 inputs, DESIGN.md "Accuracy"): the white rounding noise of the transform gains sqrt(L) in the
 spectrum while the IR itself is a compact pulse.  That case is held to FULL_COLUMN_TOL.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -946,3 +948,49 @@ def test_shared_context_from_many_threads(gpu_ctx):
         ok = list(pool.map(job, range(96)))
     plan.close()
     assert all(ok)
+
+
+def test_device_filter_spectrum_matches_host_fp64(gpu_ctx):
+    """Plans prepare alpha/beta in fp64 on the device (Stockham FFT + unpack, rounded once); the host fp64
+    preparation (IMPULSE_HIP_HOST_SPECTRUM=1) must give the same fp32 planes to the last bit or two."""
+    from impulse_hip import ConvPlan
+    rng = np.random.default_rng(123)
+    for M, L, mode, nf in ((1, 1, "same", 1), (999, 1000, "same", 1), (9600, 32640, "full", 3),
+                           (147635, 243635, "same", 1), (100001, 150000, "full", 1)):
+        h = rng.standard_normal((nf, M)) * np.exp(-np.arange(M) / max(M / 4.0, 1.0))
+        planes = []
+        for host in ("0", "1"):
+            os.environ["IMPULSE_HIP_HOST_SPECTRUM"] = host
+            try:
+                p = ConvPlan(gpu_ctx, h if nf > 1 else h[0], L, mode)
+            finally:
+                os.environ.pop("IMPULSE_HIP_HOST_SPECTRUM", None)
+            dptr, nbytes = p.spectrum_buffer()
+            ab = np.empty(nbytes // 4, dtype=np.float32)
+            gpu_ctx.d2h(ab, dptr)
+            planes.append(ab)
+            p.close()
+        dev, host = planes
+        scale = np.max(np.abs(host))
+        assert np.max(np.abs(dev - host)) <= 2.5e-7 * scale, (M, L, mode)      # <= 2 ulp of the largest bin
+        assert np.mean(dev == host) > 0.98                                     # and almost always bit-identical
+
+
+def test_equalize_channels_equals_per_channel_equalize(gpu_ctx):
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.impulse_response import ImpulseResponse
+    rng = np.random.default_rng(321)
+
+    class Est:
+        fs = 48000
+    data = {sp: {sd: rng.standard_normal(3000 if sp != "FC" else 2500) for sd in ("left", "right")} for sp in ("FL", "FR", "FC")}
+    firs = {(sp, sd): rng.standard_normal(700) * 0.1 for sp in data for sd in ("left", "right")}
+    a, b = HRIR(Est()), HRIR(Est())
+    for h in (a, b):
+        h.irs = {sp: {sd: ImpulseResponse(x.copy(), 48000) for sd, x in pair.items()} for sp, pair in data.items()}
+    a.equalize_channels(firs)
+    for (sp, sd), fir in firs.items():
+        b.irs[sp][sd].equalize(fir)
+    for sp in data:
+        for sd in ("left", "right"):
+            np.testing.assert_array_equal(a.irs[sp][sd].data, b.irs[sp][sd].data)   # same kernels, same bits
