@@ -992,6 +992,132 @@ extern "C" int imp_peak_index(imp_ctx* ctx, const float* x, const int64_t* off, 
   return rc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K7 segment sets
+// ------------------------------------------------------------------------------------------------
+struct imp_segset {
+  imp_ctx* ctx = nullptr;
+  int64_t B = 0;
+  double* e = nullptr;               // squared, normalised segments, concatenated
+  int64_t* off = nullptr;            // device copies of the row table
+  int64_t* len = nullptr;
+  std::vector<int64_t> h_len;
+  void* qbuf = nullptr;              // query staging: 3 x int64 + 1 x double per query
+  size_t qcap = 0;
+};
+
+extern "C" void imp_segset_destroy(imp_segset* s) {
+  if (!s) return;
+  IMP_CTX_LOCK(s->ctx);
+  (void)hipSetDevice(s->ctx->device);
+  (void)hipStreamSynchronize(s->ctx->stream);
+  (void)hipFree(s->e);
+  (void)hipFree(s->off);
+  (void)hipFree(s->qbuf);
+  delete s;
+}
+
+extern "C" int imp_segset_create(imp_ctx* ctx, const double* x, const int64_t* off, const int64_t* len, int64_t B,
+                                 imp_segset** out, double* maxabs_out) {
+  if (!ctx || !out || (B && (!x || !off || !len))) return fail(IMP_ERR_INVALID, "imp_segset_create: null argument");
+  IMP_CTX_LOCK(ctx);
+  *out = nullptr;
+  if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
+  int64_t total = 0, maxlen = 0;
+  for (int64_t b = 0; b < B; ++b) {
+    if (off[b] < 0 || len[b] < 0) return fail(IMP_ERR_INVALID, "negative offset/length in segment %lld", (long long)b);
+    total = std::max(total, off[b] + len[b]);
+    maxlen = std::max(maxlen, len[b]);
+  }
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  imp_segset* s = new (std::nothrow) imp_segset();
+  if (!s) return fail(IMP_ERR_ALLOC, "out of host memory");
+  s->ctx = ctx;
+  s->B = B;
+  s->h_len.assign(len, len + B);
+  hipStream_t st = ctx->stream;
+  unsigned long long* d_max = nullptr;
+  auto bail = [&](int code) {
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(d_max);
+    imp_segset_destroy(s);
+    return code;
+  };
+  if (hipMalloc((void**)&s->e, (size_t)std::max<int64_t>(total, 1) * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&s->off, (size_t)std::max<int64_t>(2 * B, 1) * sizeof(int64_t)) != hipSuccess ||
+      hipMalloc((void**)&d_max, (size_t)std::max<int64_t>(B, 1) * sizeof(unsigned long long)) != hipSuccess)
+    return bail(fail(IMP_ERR_ALLOC, "imp_segset_create: device allocation of %lld samples failed", (long long)total));
+  s->len = s->off + B;
+  if (B == 0 || total == 0) {
+    (void)hipFree(d_max);
+    *out = s;
+    if (maxabs_out)
+      for (int64_t b = 0; b < B; ++b) maxabs_out[b] = 0.0;
+    return IMP_OK;
+  }
+  if (hipMemcpyAsync(s->e, x, (size_t)total * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(s->off, off, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(s->len, len, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemsetAsync(d_max, 0, (size_t)B * sizeof(unsigned long long), st) != hipSuccess)
+    return bail(fail(IMP_ERR_HIP, "imp_segset_create: upload failed"));
+  const int bpr = (int)std::max<int64_t>(1, std::min<int64_t>(256, (maxlen + 4095) / 4096));
+  dim3 grid((unsigned)bpr, (unsigned)B), block(256);
+  hipLaunchKernelGGL(imp::seg_maxabs_kernel, grid, block, 0, st, s->e, s->off, s->len, d_max);
+  hipLaunchKernelGGL(imp::seg_square_kernel, grid, block, 0, st, s->e, s->off, s->len, d_max);
+  if (hipGetLastError() != hipSuccess) return bail(fail(IMP_ERR_HIP, "imp_segset_create: launch failed"));
+  std::vector<unsigned long long> h((size_t)B);
+  if (hipMemcpyAsync(h.data(), d_max, (size_t)B * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return bail(fail(IMP_ERR_HIP, "imp_segset_create: readback failed"));
+  (void)hipFree(d_max);
+  d_max = nullptr;
+  if (maxabs_out)
+    for (int64_t b = 0; b < B; ++b) std::memcpy(&maxabs_out[b], &h[(size_t)b], sizeof(double));
+  *out = s;
+  return IMP_OK;
+}
+
+extern "C" int imp_segset_range_means(imp_segset* s, const int64_t* q_seg, const int64_t* q_a, const int64_t* q_b,
+                                      int64_t Q, double* mean_out) {
+  if (!s || (Q && (!q_seg || !q_a || !q_b || !mean_out))) return fail(IMP_ERR_INVALID, "imp_segset_range_means: null argument");
+  IMP_CTX_LOCK(s->ctx);
+  if (Q < 0) return fail(IMP_ERR_INVALID, "Q < 0");
+  if (Q == 0) return IMP_OK;
+  for (int64_t q = 0; q < Q; ++q) {
+    if (q_seg[q] < 0 || q_seg[q] >= s->B) return fail(IMP_ERR_INVALID, "query %lld: segment %lld out of range", (long long)q, (long long)q_seg[q]);
+    // NumPy slicing clips; the caller passes clipped bounds, anything else is a bug on the host side
+    if (q_a[q] < 0 || q_b[q] > s->h_len[(size_t)q_seg[q]] || q_a[q] > q_b[q])
+      return fail(IMP_ERR_INVALID, "query %lld: range [%lld, %lld) outside segment of %lld samples", (long long)q,
+                  (long long)q_a[q], (long long)q_b[q], (long long)s->h_len[(size_t)q_seg[q]]);
+  }
+  int rc = ctx_bind(s->ctx);
+  if (rc) return rc;
+  hipStream_t st = s->ctx->stream;
+  const size_t need = (size_t)Q * (3 * sizeof(int64_t) + sizeof(double));
+  if (s->qcap < need) {
+    (void)hipFree(s->qbuf);
+    s->qbuf = nullptr;
+    s->qcap = 0;
+    const size_t want = std::max(need, (size_t)1 << 16);
+    HIP_TRY(hipMalloc(&s->qbuf, want));
+    s->qcap = want;
+  }
+  int64_t* d_seg = (int64_t*)s->qbuf;
+  int64_t* d_a = d_seg + Q;
+  int64_t* d_b = d_a + Q;
+  double* d_m = (double*)(d_b + Q);
+  HIP_TRY(hipMemcpyAsync(d_seg, q_seg, (size_t)Q * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_a, q_a, (size_t)Q * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_b, q_b, (size_t)Q * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(imp::seg_range_mean_kernel, dim3((unsigned)((Q + 63) / 64)), dim3(64), 0, st, s->e, s->off, d_seg, d_a,
+                     d_b, (long long)Q, d_m);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(mean_out, d_m, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return IMP_OK;
+}
+
 extern "C" int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_off, const int64_t* a_len,
                                 const double* b, const int64_t* b_off, const int64_t* b_len, int64_t B,
                                 int64_t* arg_out, double* val_out) {

@@ -186,4 +186,118 @@ __global__ __launch_bounds__(256) void xcorr_argmax_kernel(const double* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K7: reductions of the decay analysis (core/decay.py:44-253, Lundeby) on fp64 segments kept on the
+// device.  The reference works on e = (x / max|x|)^2 and takes np.mean over windows and ranges of it;
+// the means below add in NumPy's pairwise order (numpy/_core/src/umath/loops_utils.h.src,
+// @TYPE@_pairwise_sum: < 8 elements sequentially, <= 128 with eight strided accumulators, longer runs
+// split at n/2 rounded down to a multiple of 8; runs beyond the 8192-element ufunc buffer are reduced
+// piece by piece), so every level the host compares against a threshold has the bits the reference sees.
+// ---------------------------------------------------------------------------------------------
+
+// max |x| per segment (exact: max is order independent); bits of a non-negative double order like integers
+__global__ __launch_bounds__(256) void seg_maxabs_kernel(const double* __restrict__ x, const int64_t* __restrict__ off,
+                                                         const int64_t* __restrict__ len,
+                                                         unsigned long long* __restrict__ maxbits) {
+  const int b = blockIdx.y;
+  const int64_t n = len[b];
+  const double* row = x + off[b];
+  double m = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    m = fmax(m, fabs(row[i]));
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) m = fmax(m, __shfl_xor(m, s, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(&maxbits[b], (unsigned long long)__double_as_longlong(m));
+}
+
+// e = (x / top)^2 when top >= 1e-20 (core/decay.py:96-100), else x^2; in place
+__global__ __launch_bounds__(256) void seg_square_kernel(double* __restrict__ x, const int64_t* __restrict__ off,
+                                                         const int64_t* __restrict__ len,
+                                                         const unsigned long long* __restrict__ maxbits) {
+  const int b = blockIdx.y;
+  const int64_t n = len[b];
+  double* row = x + off[b];
+  const double top = __longlong_as_double((long long)maxbits[b]);
+  const bool norm = top >= 1e-20;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = norm ? row[i] / top : row[i];
+    row[i] = v * v;
+  }
+}
+
+__device__ inline double np_block_sum(const double* a, int n) {      // n <= 128
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r += a[i];
+    return r;
+  }
+  double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+    r0 += a[i];
+    r1 += a[i + 1];
+    r2 += a[i + 2];
+    r3 += a[i + 3];
+    r4 += a[i + 4];
+    r5 += a[i + 5];
+    r6 += a[i + 6];
+    r7 += a[i + 7];
+  }
+  double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (; i < n; ++i) res += a[i];
+  return res;
+}
+
+// NumPy's pairwise sum of a[0..n), recursion unrolled onto an explicit stack (depth <= 40 for any int64 n)
+__device__ inline double np_pairwise_sum(const double* a, long long n) {
+  struct Frame { const double* p; long long n; int state; double left; };
+  Frame st[48];
+  int sp = 0;
+  st[0] = Frame{a, n, 0, 0.0};
+  double ret = 0.0;
+  while (sp >= 0) {
+    Frame& f = st[sp];
+    if (f.n <= 128) {
+      ret = np_block_sum(f.p, (int)f.n);
+      --sp;
+      continue;
+    }
+    long long n2 = f.n / 2;
+    n2 -= n2 % 8;
+    if (f.state == 0) {                   // descend left
+      f.state = 1;
+      st[++sp] = Frame{f.p, n2, 0, 0.0};
+    } else if (f.state == 1) {            // left done -> descend right
+      f.left = ret;
+      f.state = 2;
+      st[++sp] = Frame{f.p + n2, f.n - n2, 0, 0.0};
+    } else {                              // both done
+      ret = f.left + ret;
+      --sp;
+    }
+  }
+  return ret;
+}
+
+// mean_out[q] = np.mean(e[seg][a:b]); an empty range gives NaN like NumPy
+__global__ __launch_bounds__(64) void seg_range_mean_kernel(const double* __restrict__ e, const int64_t* __restrict__ off,
+                                                            const int64_t* __restrict__ q_seg,
+                                                            const int64_t* __restrict__ q_a,
+                                                            const int64_t* __restrict__ q_b, long long Q,
+                                                            double* __restrict__ mean_out) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= Q) return;
+  const long long n = q_b[q] - q_a[q];
+  if (n <= 0) {
+    mean_out[q] = __longlong_as_double(0x7ff8000000000000ll);
+    return;
+  }
+  // np.add.reduce hands its inner loop the run in pieces of the ufunc buffer size (8192 elements) and
+  // adds the pieces' pairwise sums left to right (observed on NumPy 2.2: tests pin it against np.mean)
+  const double* a = e + off[q_seg[q]] + q_a[q];
+  double acc = np_pairwise_sum(a, n < 8192 ? n : 8192);
+  for (long long i = 8192; i < n; i += 8192) acc += np_pairwise_sum(a + i, (n - i) < 8192 ? (n - i) : 8192);
+  mean_out[q] = acc / (double)n;
+}
+
 }  // namespace imp

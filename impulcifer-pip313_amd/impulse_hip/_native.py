@@ -78,6 +78,9 @@ SIGNATURES = {
     "imp_debug_plan_geometry": (C.c_int, [_i64, _i64, C.c_int, _pi64, _pi64, _pi64]),
     "imp_debug_host_spectrum": (C.c_int, [_pd, _i64, C.c_int, _pf]),
     "imp_plan_debug_run_stage": (C.c_int, [_vp, _pf, _i64, _i64, C.c_int, _pf]),
+    "imp_segset_create": (C.c_int, [_vp, _pd, _pi64, _pi64, _i64, C.POINTER(_vp), _pd]),
+    "imp_segset_range_means": (C.c_int, [_vp, _pi64, _pi64, _pi64, _i64, _pd]),
+    "imp_segset_destroy": (None, [_vp]),
     "imp_xcorr_argmax": (C.c_int, [_vp, _pd, _pi64, _pi64, _pd, _pi64, _pi64, _i64, _pi64, _pd]),
     "imp_minphase_fir": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, _pd]),
     "imp_magnitude_db": (C.c_int, [_vp, _pd, _i64, _i64, _pd]),
@@ -311,6 +314,51 @@ class Context:
                                   int(p.get("decay_knee", 0)), float(p.get("decay_level_db", 0.0)))
         _check(self._lib.imp_apply_window(self._h, _ptr_f(flat), _ptr_i64(offs), _ptr_i64(lens), B, arr))
         return [flat[o:o + n].copy() for o, n in zip(offs, lens)]
+
+
+class SegSet:
+    """K7: fp64 analysis segments kept on the device as e = (x / max|x|)^2; range_means() answers
+    np.mean(e[seg][a:b]) queries with NumPy's summation order (bit-identical levels)."""
+
+    def __init__(self, ctx, rows):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        rows = [np.ascontiguousarray(r, dtype=np.float64).ravel() for r in rows]
+        self.lens = np.array([len(r) for r in rows], dtype=np.int64)
+        B = len(rows)
+        offs = np.zeros(max(B, 1), dtype=np.int64)[:B]
+        if B:
+            offs[1:] = np.cumsum(self.lens)[:-1]
+        flat = np.concatenate(rows) if B and self.lens.sum() else np.zeros(1)
+        self.maxabs = np.zeros(max(B, 1), dtype=np.float64)[:B]
+        h = _vp()
+        _check(self._lib.imp_segset_create(ctx.handle, flat.ctypes.data_as(_pd), _ptr_i64(offs), _ptr_i64(self.lens), B,
+                                           C.byref(h), self.maxabs.ctypes.data_as(_pd)))
+        self._h = h
+        ctx._plans.add(self)
+
+    def range_means(self, queries):
+        """queries: iterable of (segment, a, b) with 0 <= a <= b <= len(segment).  Returns float64 means."""
+        q = np.asarray(list(queries), dtype=np.int64).reshape(-1, 3)
+        out = np.zeros(len(q), dtype=np.float64)
+        if len(q) == 0:
+            return out
+        seg, a, b = (np.ascontiguousarray(q[:, i]) for i in range(3))
+        _check(self._lib.imp_segset_range_means(self._h, _ptr_i64(seg), _ptr_i64(a), _ptr_i64(b), len(q),
+                                                out.ctypes.data_as(_pd)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if getattr(self.ctx, "_h", None):
+                self._lib.imp_segset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                  # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 class ConvPlan:

@@ -1,9 +1,10 @@
 """Decay analysis (Lundeby knee, Schroeder decay times) and decay-window adjustment.
 
-Surface of reference core/decay.py:12-403.  The analysis is scalar control flow over at most
-~70 window levels plus reductions over <= 2 s of samples; it runs on the host in float64 (SURVEY
-section 2.2 row K7 keeps this control flow host-side).  The first-peak search (K3) and the
-application of the decay window (K8) run on the device.
+Surface of reference core/decay.py:12-403.  The Lundeby knee search is scalar control flow over at
+most ~200 window levels; the reductions it asks for - max|x|, squaring, np.mean over windows and
+ranges of <= 2 s of samples - run on the device in fp64 with NumPy's summation order (K7), the
+first-peak search (K3) and the decay window (K8) too.  decay_times (Schroeder integral, only needed
+when a decay target is set) is host float64.
 """
 import numpy as np
 
@@ -27,23 +28,31 @@ def _peak_index(data, start=0, end=None, peak_height=0.12589):
     return int(idx[0]) + start
 
 
-class _Levels:
-    """Window-mean levels of the squared, peak-normalised analysis segment."""
+class _Grid:
+    """t = np.linspace(0, n / fs, n) of the analysis segment, without materialising it: NumPy forms
+    t[i] = i * step with step = (n / fs) / (n - 1) and pins the last sample to n / fs."""
 
-    def __init__(self, sq, fs):
-        self.sq = sq
-        self.fs = fs
-        self.t = np.linspace(0, len(sq) / fs, len(sq))
+    def __init__(self, n, fs):
+        self.n = n
+        self.stop = n / fs
+        self.step = self.stop / (n - 1) if n > 1 else 0.0
 
-    def windows(self, n, w, wd):
-        lv = 10 * np.log10(np.maximum(self.sq[: n * w].reshape(n, w).mean(axis=1), EPSILON))
-        return np.arange(n) * wd + wd / 2, lv
-
-    def mean_db(self, a, b):
-        return 10 * np.log10(np.maximum(np.mean(self.sq[a:b]), EPSILON))
+    def at(self, i):
+        if self.n == 1:
+            return 0.0
+        return self.stop if i == self.n - 1 else i * self.step
 
     def nearest(self, time):
-        return int(np.argmin(np.abs(self.t - time)))
+        """int(np.argmin(np.abs(t - time))): the exact float comparison on the few candidates around time/step."""
+        if self.n <= 1 or self.step == 0.0:
+            return 0
+        guess = int(min(max(time / self.step, 0.0), self.n - 1))
+        best, best_d = None, None
+        for i in range(max(guess - 2, 0), min(guess + 3, self.n)):
+            d = abs(self.at(i) - time)
+            if best is None or d < best_d:          # first minimum wins, like argmin
+                best, best_d = i, d
+        return best
 
 
 def _fit_line(x, y):
@@ -59,55 +68,48 @@ def _first_le(values, level):
     return int(hit[0]) if hit.size else None
 
 
-def decay_params(data, fs):
-    """(peak_index, knee_point_index, noise_floor_dB, window_size) by the Lundeby method."""
-    ir = np.asarray(data, dtype=np.float64)
-    n_ir = len(ir)
-    if n_ir < 10:
-        return 0, n_ir, -200.0, n_ir if n_ir > 0 else 1
+def _db(mean):
+    return 10 * np.log10(np.maximum(mean, EPSILON))
 
-    peak = _peak_index(ir)
-    end = min(peak + int(2 * fs), n_ir)
-    if peak >= end:
-        peak = min(max(peak, 0), n_ir - 1)
-        seg = ir[peak:peak + 1].copy()
-    else:
-        seg = ir[peak:end].copy()
-    top = np.max(np.abs(seg))
-    if top >= EPSILON:
-        seg = seg / top
-    lv = _Levels(seg ** 2, fs)
-    n_sq = len(lv.sq)
-    whole_db = lambda: 10 * np.log10(max(np.mean(lv.sq), EPSILON))   # noqa: E731
 
+def _lundeby(n_sq, fs):
+    """The Lundeby knee search of core/decay.py:103-253 as a coroutine over the squared, peak-normalised
+    segment of n_sq samples: it yields lists of (a, b) ranges and is sent np.mean(sq[a:b]) for each
+    (device K7, NumPy's summation order); everything else is scalar control flow on <= ~200 window levels.
+    Returns (knee offset in samples, noise floor dB, window size)."""
+    grid = _Grid(n_sq, fs)
     wd = 0.03
     n = int(n_sq / fs / wd) if fs > 0 else 0
     if n == 0:
-        return peak, peak + n_sq, whole_db(), max(1, n_sq)
+        (whole,) = yield [(0, n_sq)]
+        return n_sq, float(_db(whole)), max(1, n_sq)
     w0 = max(int(n_sq / n), 1)
-    t_win, levels = lv.windows(n, w0, wd)
-
     tail_from = int(n_sq * 0.9)
-    floor = lv.mean_db(tail_from, n_sq) if tail_from < n_sq else lv.mean_db(0, n_sq)
+    means = yield [(i * w0, (i + 1) * w0) for i in range(n)] + [(tail_from, n_sq) if tail_from < n_sq else (0, n_sq)]
+    levels, floor = _db(np.asarray(means[:n])), float(_db(means[n]))
+    t_win = np.arange(n) * wd + wd / 2
 
     close = np.flatnonzero(levels <= floor + 10.0)
     stop = int(close[0]) if close.size and close[0] > 0 else len(levels)
     if stop < 2:
         if len(levels) < 2:
-            return peak, peak + n_sq, floor, w0
+            return n_sq, floor, w0
         stop = len(levels)
     slope, icpt = _fit_line(t_win[:stop], levels[:stop])
     if np.isnan(slope) or abs(slope) < EPSILON:
-        return peak, peak + n_sq, floor, w0
-    knee_time = np.clip((floor - icpt) / slope, lv.t[0], lv.t[-1])
+        return n_sq, floor, w0
+    t_first, t_last = grid.at(0), grid.at(n_sq - 1)
+    knee_time = np.clip((floor - icpt) / slope, t_first, t_last)
 
     # re-window: three windows per 10 dB of decay
     per10 = abs(slope) * 3
-    wd = lv.t[-1] / 3.0 if per10 < EPSILON else 10 / per10
+    wd = t_last / 3.0 if per10 < EPSILON else 10 / per10
     n = int(n_sq / fs / wd) if (fs > 0 and wd > EPSILON) else 1
     n = max(n, 1)
     w = max(int(n_sq / n), 1)
-    t_win, levels = lv.windows(n, w, wd)
+    means = yield [(i * w, (i + 1) * w) for i in range(n)]
+    levels = _db(np.asarray(means))
+    t_win = np.arange(n) * wd + wd / 2
 
     after = np.flatnonzero(t_win >= knee_time)
     if after.size:
@@ -117,7 +119,7 @@ def decay_params(data, fs):
         knee_time = t_win[-1]
     k_level = levels[k_idx]
 
-    total = lv.t[-1]
+    total = t_last
     for _ in range(5):
         i0 = _first_le(levels, k_level - 5)
         if i0 is None:
@@ -125,10 +127,11 @@ def decay_params(data, fs):
         t0 = max(t_win[i0], 0.1 * total)
         if t0 > t_win[-1]:
             break
-        a, b = lv.nearest(t0), lv.nearest(min(t0 + knee_time, total))
+        a, b = grid.nearest(t0), grid.nearest(min(t0 + knee_time, total))
         if a >= b:
             break
-        floor = lv.mean_db(a, b)
+        (m,) = yield [(a, b)]
+        floor = float(_db(m))
         hi = _first_le(levels, floor + 8)
         lo = _first_le(levels, floor + 28)
         if hi is None or lo is None:
@@ -149,7 +152,65 @@ def decay_params(data, fs):
             break
         k_level = levels[k_idx]
 
-    return peak, peak + lv.nearest(knee_time), floor, w
+    return grid.nearest(knee_time), floor, w
+
+
+def decay_params_batch(datas, fs):
+    """decay_params for many responses at once: one upload of all analysis segments, then the knee
+    searches advance in lock step so that each round of np.mean queries is ONE device call (K7)."""
+    datas = [np.asarray(d, dtype=np.float64) for d in datas]
+    results = [None] * len(datas)
+    ctx = _native.default_context()
+    live = []
+    for k, ir in enumerate(datas):
+        if len(ir) < 10:
+            results[k] = (0, len(ir), -200.0, len(ir) if len(ir) > 0 else 1)
+        else:
+            live.append(k)
+    if not live:
+        return results
+    peaks, _ = ctx.peak_index([datas[k] for k in live])
+    segs, seg_peak = [], {}
+    for k, pk in zip(live, peaks):
+        ir, pk = datas[k], int(pk)
+        end = min(pk + int(2 * fs), len(ir))
+        if pk >= end:
+            pk = min(max(pk, 0), len(ir) - 1)
+            segs.append(ir[pk:pk + 1])
+        else:
+            segs.append(ir[pk:end])
+        seg_peak[k] = pk
+    segset = _native.SegSet(ctx, segs)
+    try:
+        runs = {}
+        pending = {}
+        for j, k in enumerate(live):
+            gen = _lundeby(len(segs[j]), fs)
+            runs[k] = (j, gen)
+            pending[k] = next(gen)                         # every search asks at least one question
+        while pending:
+            order = list(pending)
+            queries = [(runs[k][0], a, b) for k in order for (a, b) in pending[k]]
+            means = segset.range_means(queries)
+            pos = 0
+            nxt = {}
+            for k in order:
+                cnt = len(pending[k])
+                try:
+                    nxt[k] = runs[k][1].send(means[pos:pos + cnt])
+                except StopIteration as done:
+                    knee_off, floor, w = done.value
+                    results[k] = (seg_peak[k], seg_peak[k] + int(knee_off), floor, w)
+                pos += cnt
+            pending = nxt
+    finally:
+        segset.close()
+    return results
+
+
+def decay_params(data, fs):
+    """(peak_index, knee_point_index, noise_floor_dB, window_size) by the Lundeby method."""
+    return decay_params_batch([data], fs)[0]
 
 
 def decay_times(data, fs, peak_ind=None, knee_point_ind=None, noise_floor=None, window_size=None):

@@ -324,15 +324,21 @@ class HRIR(_PlotBase):
         items = self._all_irs()
         if not items:
             return 0
-        knees, lengths = [], []
-        for _, _, ir in items:
-            try:
-                knees.append(ir.decay_params()[1])
-            except (_native.NativeError, _native.NativeUnavailable):
-                raise
-            except Exception:                               # noqa: BLE001 - the reference tolerates analysis failures
-                knees.append(len(ir.data))
-            lengths.append(len(ir.data))
+        from .decay import decay_params_batch
+        lengths = [len(ir.data) for _, _, ir in items]
+        try:                                                # all knee searches in lock step on the device (K7)
+            knees = [p[1] for p in decay_params_batch([ir.data for _, _, ir in items], self.fs)]
+        except (_native.NativeError, _native.NativeUnavailable):
+            raise
+        except Exception:                                   # noqa: BLE001 - the reference tolerates analysis failures
+            knees = []
+            for _, _, ir in items:
+                try:
+                    knees.append(ir.decay_params()[1])
+                except (_native.NativeError, _native.NativeUnavailable):
+                    raise
+                except Exception:                           # noqa: BLE001
+                    knees.append(len(ir.data))
         per_octave = len(self.estimator) / self.estimator.fs / self.estimator.n_octaves
         fade = 2 * int(self.fs * per_octave * (1 / 24)) // 2
         keep = min(np.min(lengths), next_fast_len(max(knees)))

@@ -142,6 +142,23 @@ int imp_plan_debug_run_stage(imp_plan* plan, const float* x, int64_t B, int64_t 
  * db_out: host [B][ceil(n/2)].  Any n up to 2^22 (Bluestein on a power-of-two Stockham FFT). */
 int imp_magnitude_db(imp_ctx* ctx, const double* x, int64_t B, int64_t n, double* db_out);
 
+/* ---- K7: reductions of the decay analysis -------------------------------------------------------
+ * core/decay.py:44-253 (decay_params, Lundeby knee search): the analysis segment [peak, peak + 2 s) is
+ * peak-normalised and squared, then np.mean is taken over windows ((n, w) reshape, :111, :152) and over
+ * ranges (:117-118, :189) of it, between scalar decisions that stay on the host.
+ * imp_segset_create uploads B fp64 segments (x + off[b], len[b] samples), finds max|x| of each and
+ * replaces the segment by e = (x / max)^2 (x^2 when max < 1e-20, as the reference skips the division),
+ * all in fp64 on the device; maxabs_out[B] may be NULL.
+ * imp_segset_range_means answers Q queries mean(e[q_seg][q_a : q_b]) with NumPy's pairwise summation
+ * order, so each mean has the bits np.mean gives; an empty range yields NaN.
+ */
+typedef struct imp_segset imp_segset;
+int imp_segset_create(imp_ctx* ctx, const double* x, const int64_t* off, const int64_t* len, int64_t B,
+                      imp_segset** out, double* maxabs_out);
+int imp_segset_range_means(imp_segset* s, const int64_t* q_seg, const int64_t* q_a, const int64_t* q_b, int64_t Q,
+                           double* mean_out);
+void imp_segset_destroy(imp_segset* s);
+
 /* ---- K10: lag search of the ipsilateral alignment ----------------------------------------------
  * core/hrir.py:934-937 and :946-949 (HRIR.align_ipsilateral_all):
  *     corr = scipy.signal.correlate(a, b, mode="full"); lag = arange(-len(a)+1, len(a))[argmax(corr)]

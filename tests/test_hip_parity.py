@@ -994,3 +994,65 @@ def test_equalize_channels_equals_per_channel_equalize(gpu_ctx):
     for sp in data:
         for sd in ("left", "right"):
             np.testing.assert_array_equal(a.irs[sp][sd].data, b.irs[sp][sd].data)   # same kernels, same bits
+
+
+def test_k7_range_means_have_numpy_bits(gpu_ctx):
+    """K7: e = (x / max|x|)^2 and np.mean over windows / ranges of it, bit for bit (NumPy's pairwise order)."""
+    from impulse_hip._native import SegSet
+    rng = np.random.default_rng(7)
+    rows = [rng.standard_normal(n) * np.exp(-np.arange(n) / max(n / 6.0, 1.0)) for n in (96000, 12345, 130, 128, 9, 7, 1)]
+    rows.append(rng.random(50000) + 0.5)                        # no decay: every piece of a long run matters
+    rows.append(np.zeros(50))                                   # max < 1e-20: no normalisation
+    rows.append(np.full(300, 1e-25))
+    s = SegSet(gpu_ctx, rows)
+    want_e = []
+    for r, m in zip(rows, s.maxabs):
+        top = np.max(np.abs(r))
+        assert m == top
+        want_e.append((r / top) ** 2 if top >= 1e-20 else r ** 2)
+    queries = []
+    for j, e in enumerate(want_e):
+        n = len(e)
+        queries += [(j, 0, n), (j, n // 10, n), (j, 0, min(n, 8)), (j, min(3, n), min(3 + 129, n)), (j, n // 2, n // 2)]
+        for w in (1, 7, 8, 9, 127, 128, 129, 1000, 1440, 1441, 8192, 8193, 9000, 20000):
+            if w <= n:
+                k = n // w
+                queries += [(j, i * w, (i + 1) * w) for i in range(0, k, max(k // 5, 1))]
+    got = s.range_means(queries)
+    for (j, a, b), g in zip(queries, got):
+        if a == b:
+            assert np.isnan(g)
+            continue
+        ref = np.mean(want_e[j][a:b])
+        assert g == ref, (j, a, b, g, ref)
+    # the (n, w) window form the reference uses must agree with the range form
+    e, w = want_e[0], 1440
+    k = len(e) // w
+    ref = e[: k * w].reshape(k, w).mean(axis=1)
+    got = s.range_means([(0, i * w, (i + 1) * w) for i in range(k)])
+    np.testing.assert_array_equal(got, ref)
+    with pytest.raises(Exception):
+        s.range_means([(0, 5, 96001)])
+    s.close()
+
+
+def test_decay_params_batch_equals_single_and_goldens(gpu_ctx, golden):
+    """All twelve golden decays searched in lock step (one device call per round of queries) give the
+    reference's knee, window and - because the means carry NumPy's bits - its noise floor exactly."""
+    from impulse_hip.decay import decay_params, decay_params_batch
+    g = golden("decay")
+    keys, datas = [], []
+    for rt60 in (0.3, 0.6, 1.0, 1.5):
+        for seed in (0, 11, 22):
+            keys.append(f"rt{int(rt60 * 10)}_s{seed}")
+            datas.append(_decaying_sine(48000, 3.0, rt60, seed=seed).astype(np.float32).astype(np.float64))
+    datas += [np.zeros(5), np.zeros(4000), np.ones(20)]              # degenerate inputs ride along
+    batch = decay_params_batch(datas, 48000)
+    for k, d, bp in zip(keys, datas, batch):
+        want = g[k + "_params"]
+        assert (int(bp[0]), int(bp[1]), int(bp[3])) == (int(want[0]), int(want[1]), int(want[3])), k
+        assert float(bp[2]) == float(want[2]), k
+    for d, bp in zip(datas, batch):
+        one = decay_params(d, 48000)
+        assert (int(one[0]), int(one[1]), float(one[2]), int(one[3])) == (int(bp[0]), int(bp[1]), float(bp[2]), int(bp[3]))
+    assert batch[12] == (0, 5, -200.0, 5)
