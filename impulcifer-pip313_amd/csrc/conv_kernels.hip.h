@@ -323,7 +323,8 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
 template <int R2>
 struct MixCfg {
   // 64 columns = 512-byte row segments; R2 = 12 would need 96 KiB of LDS (one workgroup per CU), so it
-  // takes 32-column tiles (48 KiB, three per CU): C5 +5 %.  R2 = 10 measured 6 % slower that way (C3).
+  // takes 32-column tiles (48 KiB, three per CU): C5 +5 %.  Narrower tiles everywhere were slower
+  // (256-byte row segments: C2 327 k -> 300 k IR/s, C3 -6 %).
   static constexpr int TC = (R2 >= 12) ? 32 : 64;
   static constexpr int T = TC * R2;
   static constexpr int G = (16 + R2 - 1) / R2;
