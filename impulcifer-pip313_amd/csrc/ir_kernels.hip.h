@@ -300,4 +300,182 @@ __global__ __launch_bounds__(64) void seg_range_mean_kernel(const double* __rest
   mean_out[q] = acc / (double)n;
 }
 
+// ---------------------------------------------------------------------------------------------
+// K7b: Schroeder decay times (core/decay.py:263-340), one workgroup per response, fp64.
+//   sch[i]   = 10 log10( sum_{m=i..K} e[m] / sum_{m<K} e[m] ),  e = (x[peak+m] / max|x[peak:]|)^2,  i < K
+//   smooth   = 10 log10( running_mean((part / max|part|)^2, window) + 1e-18 ), part = x[peak-lead : peak+K+trail]
+//   offset   = mean(sch[a:b] - smooth[a-skew : b-skew]) over the 10 %..90 % stretch both cover
+//   EDT/RT20/RT30/RT60 = span / slope of the least-squares line through (t[i], sch[i]) between the first
+//   samples at or below (top, bottom) dB, when bottom >= noise_floor + offset + 10; NaN otherwise.
+// The sums are tree / blocked-scan reductions: unlike the knee search nothing here is compared against a
+// threshold bit for bit (log10 and the reference's BLAS-based covariance are not reproducible to the last
+// ulp either); the golden decay times agree to 1e-12.
+// ---------------------------------------------------------------------------------------------
+struct DecayJob {
+  long long off;       // first sample of the response in x
+  long long n;         // its length
+  long long peak;      // peak_ind
+  long long K;         // knee_point_ind - peak_ind
+  long long window;    // window_size
+  double noise_floor;  // dB
+  long long scratch;   // offset of this job's 2 (n + 2) doubles in the scratch buffer
+};
+
+__device__ inline double block_sum(double v, double* red) {
+  const int t = threadIdx.x;
+  __syncthreads();
+  red[t] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) red[t] += red[t + s];
+    __syncthreads();
+  }
+  return red[0];
+}
+__device__ inline double block_max(double v, double* red) {
+  const int t = threadIdx.x;
+  __syncthreads();
+  red[t] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) red[t] = fmax(red[t], red[t + s]);
+    __syncthreads();
+  }
+  return red[0];
+}
+__device__ inline long long block_min_ll(long long v, long long* red) {
+  const int t = threadIdx.x;
+  __syncthreads();
+  red[t] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s && red[t + s] < red[t]) red[t] = red[t + s];
+    __syncthreads();
+  }
+  return red[0];
+}
+// inclusive scan of f(0..len) into out[0..len): per-thread contiguous chunks + scan of the 256 chunk totals
+template <class F>
+__device__ inline void block_scan(F f, long long len, double* out, double* red) {
+  const int t = threadIdx.x;
+  const long long chunk = (len + 255) / 256;
+  const long long lo = (long long)t * chunk, hi = (lo + chunk < len) ? lo + chunk : len;
+  double acc = 0.0;
+  for (long long i = lo; i < hi; ++i) acc += f(i);
+  __syncthreads();
+  red[t] = acc;
+  __syncthreads();
+  if (t == 0) {
+    double run = 0.0;
+    for (int k = 0; k < 256; ++k) {
+      const double v = red[k];
+      red[k] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  acc = red[t];
+  for (long long i = lo; i < hi; ++i) {
+    acc += f(i);
+    out[i] = acc;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void decay_times_kernel(const double* __restrict__ x, const DecayJob* __restrict__ jobs,
+                                                          double* __restrict__ scratch, double fs,
+                                                          double* __restrict__ out) {
+  __shared__ double red[256];
+  __shared__ long long redl[256];
+  const DecayJob jb = jobs[blockIdx.x];
+  const double* ir = x + jb.off;
+  const long long n = jb.n, peak = jb.peak, K = jb.K;
+  const int t = threadIdx.x;
+  double* res = out + 4 * (long long)blockIdx.x;
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  if (t < 4) res[t] = nan;
+  if (K < 1 || peak < 0 || peak + K >= n + 1 || n < 2) return;          // nothing to integrate: all undefined
+  double* sch = scratch + jb.scratch;            // K + 1 values
+  double* smo = sch + (n + 2);                   // prefix sums, then the smoothed level
+
+  // ---- Schroeder backward integral
+  double m = 0.0;
+  for (long long i = peak + t; i < n; i += 256) m = fmax(m, fabs(ir[i]));
+  const double m1 = block_max(m, red);
+  auto e = [&](long long i) {                    // i relative to the peak
+    const double v = fabs(ir[peak + i] / m1);
+    return v * v;
+  };
+  double part_sum = 0.0;
+  for (long long i = t; i < K; i += 256) part_sum += e(i);
+  const double S = block_sum(part_sum, red);
+  const long long last = (peak + K < n) ? K : K - 1;                     // analytical[K] exists unless the knee is the end
+  // tmp[j] = sum_{m = last - j .. last} e[m] / S  (reversed order), stored so that sch[i] = tmp over m >= i
+  block_scan([&](long long j) { return e(last - j) / S; }, last + 1, smo, red);
+  // cumsum(...)[:0:-1] drops the first partial sum: len(schroeder) = last
+  const long long Ks = last;
+  for (long long i = t; i < Ks; i += 256) sch[i] = 10.0 * log10(smo[last - i]);
+  __syncthreads();
+
+  // ---- moving average of the squared response around the same stretch
+  const long long half = jb.window / 2;
+  const long long lead = half < peak ? half : peak;
+  long long trail = n - (peak + K);
+  if (half < trail) trail = half;
+  if (trail < 0) trail = 0;
+  const long long skew = half - lead;
+  const long long p0 = peak - lead, P = lead + K + trail, N = jb.window;
+  m = 0.0;
+  for (long long i = t; i < P; i += 256) m = fmax(m, fabs(ir[p0 + i]));
+  const double m2 = block_max(m, red);
+  const long long Ls = (N >= 1 && P >= N) ? P - N + 1 : 0;               // len(running_mean)
+  double offset = nan;
+  long long a = (long long)((double)Ks * 0.1), b = (long long)((double)Ks * 0.9);
+  if (a < skew) a = skew;
+  if (b > skew + Ls) b = skew + Ls;
+  if (Ls > 0 && a < b) {
+    // c[i + 1] = c[i] + p2[i]; smo[] holds c[1..P]
+    block_scan([&](long long i) { const double v = ir[p0 + i] / m2; return v * v; }, P, smo, red);
+    double acc = 0.0;
+    for (long long i = a + t; i < b; i += 256) {
+      const long long r = i - skew;                                      // index into the running mean
+      const double hi = smo[r + N - 1], lo = r > 0 ? smo[r - 1] : 0.0;
+      acc += sch[i] - 10.0 * log10((hi - lo) / (double)N + 1e-18);
+    }
+    offset = block_sum(acc, red) / (double)(b - a);
+  }
+
+  // ---- decay times
+  const double stop = (double)n / fs, step = stop / (double)(n - 1);
+  auto tt = [&](long long i) { return (i == n - 1) ? stop : (double)i * step; };
+  const double tops[4] = {-1.0, -5.0, -5.0, -5.0}, bots[4] = {-10.0, -25.0, -35.0, -65.0}, spans[4] = {-10.0, -20.0, -30.0, -60.0};
+  for (int k = 0; k < 4; ++k) {
+    if (bots[k] < jb.noise_floor + offset + 10.0) continue;              // < 10 dB above the floor (a NaN offset passes, as in the reference)
+    long long it = 0x7fffffffffffffffll, ib = 0x7fffffffffffffffll;
+    for (long long i = t; i < Ks; i += 256) {
+      if (sch[i] <= tops[k] && i < it) it = i;
+      if (sch[i] <= bots[k] && i < ib) ib = i;
+    }
+    it = block_min_ll(it, redl);
+    ib = block_min_ll(ib, redl);
+    if (it == 0x7fffffffffffffffll || ib == 0x7fffffffffffffffll || ib - it < 2) continue;
+    const double cnt = (double)(ib - it);
+    double sx = 0.0, sy = 0.0;
+    for (long long i = it + t; i < ib; i += 256) {
+      sx += tt(i);
+      sy += sch[i];
+    }
+    const double xm = block_sum(sx, red) / cnt;
+    const double ym = block_sum(sy, red) / cnt;
+    double sxy = 0.0, sxx = 0.0;
+    for (long long i = it + t; i < ib; i += 256) {
+      const double dx = tt(i) - xm;
+      sxy += dx * (sch[i] - ym);
+      sxx += dx * dx;
+    }
+    const double cxy = block_sum(sxy, red), cxx = block_sum(sxx, red);
+    if (t == 0) res[k] = spans[k] / (cxy / cxx);
+  }
+}
+
 }  // namespace imp

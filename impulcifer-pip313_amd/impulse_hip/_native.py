@@ -81,6 +81,7 @@ SIGNATURES = {
     "imp_segset_create": (C.c_int, [_vp, _pd, _pi64, _pi64, _i64, C.POINTER(_vp), _pd]),
     "imp_segset_range_means": (C.c_int, [_vp, _pi64, _pi64, _pi64, _i64, _pd]),
     "imp_segset_destroy": (None, [_vp]),
+    "imp_decay_times": (C.c_int, [_vp, _pd, _pi64, _pi64, _i64, _pi64, _pi64, _pd, _pi64, C.c_double, _pd]),
     "imp_xcorr_argmax": (C.c_int, [_vp, _pd, _pi64, _pi64, _pd, _pi64, _pi64, _i64, _pi64, _pd]),
     "imp_minphase_fir": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, _pd]),
     "imp_magnitude_db": (C.c_int, [_vp, _pd, _i64, _i64, _pd]),
@@ -241,6 +242,26 @@ class Context:
         _check(self._lib.imp_peak_index(self._h, _ptr_f(flat), _ptr_i64(offs), _ptr_i64(lens), B,
                                         float(peak_height), _ptr_i64(idx), _ptr_f(mx)))
         return idx, mx
+
+    def decay_times(self, rows, peaks, knees, noise_floors, windows, fs):
+        """Batched core/decay.py decay_times on the device: [B, 4] = EDT, RT20, RT30, RT60 (NaN = undefined)."""
+        rows = [np.ascontiguousarray(r, dtype=np.float64).ravel() for r in rows]
+        B = len(rows)
+        out = np.full((B, 4), np.nan)
+        if B == 0:
+            return out
+        lens = np.array([len(r) for r in rows], dtype=np.int64)
+        offs = np.zeros(B, dtype=np.int64)
+        offs[1:] = np.cumsum(lens)[:-1]
+        flat = np.concatenate(rows) if lens.sum() else np.zeros(1)
+        pk = np.ascontiguousarray(peaks, dtype=np.int64)
+        kn = np.ascontiguousarray(knees, dtype=np.int64)
+        nf = np.ascontiguousarray(noise_floors, dtype=np.float64)
+        ws = np.ascontiguousarray(windows, dtype=np.int64)
+        _check(self._lib.imp_decay_times(self._h, flat.ctypes.data_as(_pd), _ptr_i64(offs), _ptr_i64(lens), B,
+                                         _ptr_i64(pk), _ptr_i64(kn), nf.ctypes.data_as(_pd), _ptr_i64(ws),
+                                         float(fs), out.ctypes.data_as(_pd)))
+        return out
 
     def xcorr_argmax(self, a_rows, b_rows):
         """np.argmax(scipy.signal.correlate(a, b, "full")) for every pair (fp64 on the device).

@@ -3,13 +3,12 @@
 Surface of reference core/decay.py:12-403.  The Lundeby knee search is scalar control flow over at
 most ~200 window levels; the reductions it asks for - max|x|, squaring, np.mean over windows and
 ranges of <= 2 s of samples - run on the device in fp64 with NumPy's summation order (K7), the
-first-peak search (K3) and the decay window (K8) too.  decay_times (Schroeder integral, only needed
-when a decay target is set) is host float64.
+first-peak search (K3) and the decay window (K8) too; decay_times (Schroeder integral, moving average,
+line fits) is one device kernel per batch.
 """
 import numpy as np
 
 from . import _native
-from .audio_io import running_mean
 
 EPSILON = 1e-20
 
@@ -215,37 +214,12 @@ def decay_params(data, fs):
 
 def decay_times(data, fs, peak_ind=None, knee_point_ind=None, noise_floor=None, window_size=None):
     """EDT, RT20, RT30, RT60 from the Schroeder backward integral (None where the dynamic range
-    above the noise floor is insufficient)."""
+    above the noise floor is insufficient).  Integral, moving average and line fits run on the device."""
     ir = np.asarray(data, dtype=np.float64)
     if peak_ind is None or knee_point_ind is None or noise_floor is None:
         peak_ind, knee_point_ind, noise_floor, window_size = decay_params(ir, fs)
-    t = np.linspace(0, len(ir) / fs, len(ir))
-    knee = knee_point_ind - peak_ind
-    env = np.abs(ir[peak_ind:] / np.max(np.abs(ir[peak_ind:])))
-    energy = env ** 2
-    sch = 10 * np.log10(np.cumsum(energy[knee::-1] / np.sum(energy[:knee]))[:0:-1])
-
-    half = window_size // 2
-    lead = min(half, peak_ind)
-    trail = min(half, len(ir) - (peak_ind + knee))
-    skew = half - lead
-    part = ir[peak_ind - lead: peak_ind + knee + trail].copy()
-    part /= np.max(np.abs(part))
-    smooth = 10 * np.log10(running_mean(part ** 2, window_size) + 1e-18)
-    a = max(int(len(sch) * 0.1), skew)
-    b = min(int(len(sch) * 0.9), skew + len(smooth))
-    offset = np.mean(sch[a:b] - smooth[a - skew: b - skew])
-
-    result = []
-    for top, bottom, span in ((-1, -10, -10), (-5, -25, -20), (-5, -35, -30), (-5, -65, -60)):
-        value = None
-        if bottom >= noise_floor + offset + 10:
-            i_top, i_bot = _first_le(sch, top), _first_le(sch, bottom)
-            if i_top is not None and i_bot is not None and i_bot - i_top >= 2:
-                slope, _ = _fit_line(t[i_top:i_bot], sch[i_top:i_bot])
-                value = span / slope
-        result.append(value)
-    return tuple(result)
+    vals = _native.default_context().decay_times([ir], [peak_ind], [knee_point_ind], [noise_floor], [window_size], fs)[0]
+    return tuple(None if np.isnan(v) else float(v) for v in vals)
 
 
 def decay_adjustment_params(data, fs, target):

@@ -159,6 +159,15 @@ int imp_segset_range_means(imp_segset* s, const int64_t* q_seg, const int64_t* q
                            double* mean_out);
 void imp_segset_destroy(imp_segset* s);
 
+/* core/decay.py:263-340 (decay_times): Schroeder backward integral of B responses and the four decay times
+ * read from it.  x: host fp64, response b at x + off[b] (len[b] samples); peak[b], knee[b] (absolute
+ * knee_point_ind), noise_floor[b] (dB) and window[b] are decay_params' results.  out: host [B][4] =
+ * EDT, RT20, RT30, RT60 in seconds, NaN where the reference returns None.
+ */
+int imp_decay_times(imp_ctx* ctx, const double* x, const int64_t* off, const int64_t* len, int64_t B,
+                    const int64_t* peak, const int64_t* knee, const double* noise_floor, const int64_t* window,
+                    double fs, double* out);
+
 /* ---- K10: lag search of the ipsilateral alignment ----------------------------------------------
  * core/hrir.py:934-937 and :946-949 (HRIR.align_ipsilateral_all):
  *     corr = scipy.signal.correlate(a, b, mode="full"); lag = arange(-len(a)+1, len(a))[argmax(corr)]

@@ -1056,3 +1056,37 @@ def test_decay_params_batch_equals_single_and_goldens(gpu_ctx, golden):
         one = decay_params(d, 48000)
         assert (int(one[0]), int(one[1]), float(one[2]), int(one[3])) == (int(bp[0]), int(bp[1]), float(bp[2]), int(bp[3]))
     assert batch[12] == (0, 5, -200.0, 5)
+
+
+def test_decay_times_device_vs_oracle_edges(gpu_ctx):
+    """K7b against the oracle's decay_times on shapes the goldens do not reach: knee at the very end,
+    peak at sample 0, windows longer than the analysed stretch, truncated responses."""
+    from oracle import decay as odecay
+    rng = np.random.default_rng(17)
+    fs = 48000
+    cases = []
+    for rt60, n, lead in ((0.2, 30000, 0), (0.4, 48000, 500), (0.8, 96000, 2000), (0.3, 6000, 100), (0.5, 20000, 19000)):
+        t = np.arange(n) / fs
+        x = rng.standard_normal(n) * 10 ** (-3.0 * t / rt60)
+        x = np.concatenate((rng.standard_normal(lead) * 1e-4, x))[:n] if lead else x
+        x[lead if lead < n else 0] = 3.0
+        cases.append(x)
+    rows, pk, kn, nf, ws = [], [], [], [], []
+    for x in cases:
+        p = odecay.decay_params(x, fs)
+        for knee, win in ((p[1], p[3]), (len(x), p[3]), (p[1], 7), (min(p[0] + 50, len(x)), 4000), (p[1], max(len(x) * 2, 10))):
+            rows.append(x); pk.append(p[0]); kn.append(knee); nf.append(p[2]); ws.append(win)
+    got = gpu_ctx.decay_times(rows, pk, kn, nf, ws, fs)
+    import warnings
+    for x, p0, k0, f0, w0, g in zip(rows, pk, kn, nf, ws, got):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                want = odecay.decay_times(x, fs, p0, k0, f0, w0)
+            except Exception:                                    # noqa: BLE001 - the reference raises on some degenerate slices
+                continue
+        for gv, wv in zip(g, want):
+            if wv is None:
+                assert np.isnan(gv), (p0, k0, w0, g, want)
+            else:
+                assert gv == pytest.approx(wv, rel=1e-9), (p0, k0, w0, g, want)
