@@ -1090,3 +1090,45 @@ def test_decay_times_device_vs_oracle_edges(gpu_ctx):
                 assert np.isnan(gv), (p0, k0, w0, g, want)
             else:
                 assert gv == pytest.approx(wv, rel=1e-9), (p0, k0, w0, g, want)
+
+
+def test_conv_fuzz_layouts_and_sizes(gpu_ctx):
+    """Seeded fuzz over sizes (every column radix is reachable), modes, batch sizes and input layouts
+    (planar with odd pitches, interleaved float frames, PCM16 / PCM32 wire format) against the oracle."""
+    from impulse_hip import ConvPlan
+    from oracle.scipy_restated import fft_convolve
+    rng = np.random.default_rng(20261004)
+    for case in range(36):
+        L = int(rng.choice([rng.integers(1, 300), rng.integers(300, 20000), rng.integers(20000, 400000)]))
+        M = int(rng.choice([rng.integers(1, 300), rng.integers(300, 20000), rng.integers(20000, 300000)]))
+        mode = "same" if rng.random() < 0.5 else "full"
+        B = int(rng.integers(1, 6))
+        h = rng.standard_normal(M) * np.exp(-np.arange(M) / max(M / 5.0, 1.0))
+        layout = ("planar", "frames", "pcm16", "pcm32")[case % 4]
+        plan = ConvPlan(gpu_ctx, h, L, mode, ws_channels=int(rng.integers(1, B + 1)))
+        if layout == "planar":
+            x = rng.standard_normal((B, L)).astype(np.float32)
+            y = plan.execute(x)
+            ref_in = x.astype(np.float64)
+        elif layout == "frames":
+            frames = rng.standard_normal((L, B)).astype(np.float32)
+            plan.close()
+            plan = ConvPlan(gpu_ctx, h, L, mode)                  # interleaved execution uses one group
+            y = plan.execute_interleaved(frames)
+            ref_in = frames.T.astype(np.float64)
+        else:
+            bits = 16 if layout == "pcm16" else 32
+            dt = np.int16 if bits == 16 else np.int32
+            lead = int(rng.integers(0, 50))
+            frames = rng.integers(-2 ** (bits - 1), 2 ** (bits - 1), size=(lead + L + 7, B), dtype=np.int64).astype(dt)
+            plan.close()
+            plan = ConvPlan(gpu_ctx, h, L, mode, ws_channels=B)
+            y = plan.execute_pcm_columns(frames, [lead])[0]
+            ref_in = (frames[lead:lead + L].T.astype(np.float64)) / 2.0 ** (bits - 1)
+        plan.close()
+        for b in range(B):
+            ref = fft_convolve(ref_in[b], h, mode)
+            assert y[b].shape == ref.shape
+            # 32-bit PCM is rounded to fp32 on load (the device dtype): 6e-8 relative input error on top
+            tol = TIME_TOL if layout != "pcm32" else 2 * TIME_TOL
+            assert rel(y[b], ref) <= tol, (case, layout, L, M, mode, B, b)
