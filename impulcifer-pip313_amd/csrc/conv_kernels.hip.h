@@ -286,6 +286,16 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
   const __amdgpu_buffer_rsrc_t r_full = make_rsrc(tw.full, (unsigned)n1_total * kN2 * 8u);
   const __amdgpu_buffer_rsrc_t r_out = st.bind(b);
 
+  constexpr int GG = (R2 > 1) ? G : 16, KB = (R2 > 1) ? R2 : 1;
+  // pass A: four-step twiddles of this thread's outputs, fetched with the inputs (see cols_mixed_kernel)
+  cf twd[GG][KB];
+  if constexpr (DIR < 0) {
+#pragma unroll
+    for (int i = 0; i < GG; ++i)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+        twd[i][kb] = bload_cf(r_full, ((unsigned)((R2 > 1 ? g * G : 0) + i) * kN2 + n2) * 8u, (unsigned)(kb * 16 * kN2) * 8u);
+  }
   cf v[16];
   cols_first_stage<R2, TC, DIR>(ld, tw, r_full, b, g, (unsigned)g * kN2 + n2, v);
 
@@ -300,14 +310,13 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
       for (int gp = 0; gp < R2; ++gp) v[i * R2 + gp] = buf[(g * G + i) * T + gp * TC + c];
     fft_groups<DIR, R2>(v);
   }
-  constexpr int GG = (R2 > 1) ? G : 16, KB = (R2 > 1) ? R2 : 1;
 #pragma unroll
   for (int i = 0; i < GG; ++i) {
     const unsigned e = (unsigned)((R2 > 1 ? g * G : 0) + i) * kN2 + n2;      // row a = g*G + i (R2 = 1: a = i)
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       cf z = v[i * KB + kb];
-      if constexpr (DIR < 0) z = cmul(z, bload_cf(r_full, e * 8u, (unsigned)(kb * 16 * kN2) * 8u));
+      if constexpr (DIR < 0) z = cmul(z, twd[i][kb]);
       st.put(r_out, e, (unsigned)(kb * 16 * kN2), z);
     }
   }
@@ -348,6 +357,20 @@ __global__ __launch_bounds__(MixCfg<R2>::T) void cols_mixed_kernel(Load ld, Stor
   const __amdgpu_buffer_rsrc_t r_full = make_rsrc(tw.full, (unsigned)n1_total * kN2 * 8u);
   const __amdgpu_buffer_rsrc_t r_out = st.bind(b);
 
+  // pass A: the four-step twiddles of this thread's outputs are fetched with the inputs, not after the
+  // exchange where their latency would sit in front of the stores
+  cf twd[G][R2];
+  if constexpr (DIR < 0) {
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int ka = g + R2 * i;
+      if (ka < 16) {
+#pragma unroll
+        for (int kb = 0; kb < R2; ++kb)
+          twd[i][kb] = bload_cf(r_full, ((unsigned)ka * kN2 + n2) * 8u, (unsigned)(kb * 16 * kN2) * 8u);
+      }
+    }
+  }
   cf v[16];
   cols_first_stage<R2, TC, DIR>(ld, tw, r_full, b, g, (unsigned)g * kN2 + n2, v);
 #pragma unroll
@@ -365,7 +388,7 @@ __global__ __launch_bounds__(MixCfg<R2>::T) void cols_mixed_kernel(Load ld, Stor
 #pragma unroll
       for (int kb = 0; kb < R2; ++kb) {
         cf z = y[kb];
-        if constexpr (DIR < 0) z = cmul(z, bload_cf(r_full, e * 8u, (unsigned)(kb * 16 * kN2) * 8u));
+        if constexpr (DIR < 0) z = cmul(z, twd[i][kb]);
         st.put(r_out, e, (unsigned)(kb * 16 * kN2), z);
       }
     }
