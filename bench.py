@@ -178,6 +178,18 @@ def load_traffic_profile(workload):
         return None
 
 
+def load_path_traffic(workload):
+    """Bytes all three kernels of one launch group move across the L2 boundary (rocprofv3 FETCH_SIZE / WRITE_SIZE,
+    profiles/pmc_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh).get(workload, {})
+        return sum(t[k] for k in ("rows_kernel_bytes_per_launch", "cols_fwd_bytes_per_launch", "cols_inv_bytes_per_launch"))
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -351,6 +363,15 @@ def main():
                         launch_groups_per_step=groups,
                         path_achieved=value / world * 8.0 * L / 1e9,
                         path_frac=value / world * 8.0 * L / 1e9 / HBM_PEAK_GBS)
+            moved = load_path_traffic(args.workload)
+            if moved is not None:
+                # north_star's "achieved HBM GB/s against the chip's peak": bytes the counters saw per launch
+                # group (profiled at this workload's default group size) over this run's time per group
+                rate = moved * groups / (elapsed / args.steps) / 1e9
+                roof["measured_traffic"] = dict(bytes_per_launch_group=moved, achieved=rate, unit="GB/s",
+                                                frac_of_peak=rate / HBM_PEAK_GBS,
+                                                note="rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE bytes of passes A+B+C "
+                                                     "(profiles/pmc_traffic.json) / measured time per launch group")
         cpu = None
         parity = dict(peak_indices_exact=bool(peaks_ok))
         if world == 1 and not args.no_cpu_baseline:
