@@ -105,13 +105,13 @@ struct LoadRealPacked {
   long long chan_stride;            // elements between channels
   long long elem_stride;            // elements between consecutive samples of a channel
   long long len;                    // valid samples per channel
-  template <int STEP>
-  __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[16]) const {
+  template <int STEP, int F>
+  __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[F]) const {
     const float* p = base + (long long)b * chan_stride;
     if (elem_stride == 1) {
       const __amdgpu_buffer_rsrc_t r = make_rsrc(p, (unsigned)len * 4u);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < F; ++j) {
         const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, e0 * 8u, (unsigned)(j * STEP) * 8u, kStreamAux);
         v[j] = make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
       }
@@ -120,7 +120,7 @@ struct LoadRealPacked {
       const __amdgpu_buffer_rsrc_t r = make_rsrc(p, ((unsigned)(len - 1) * (unsigned)elem_stride + 1u) * 4u);
       const unsigned vo = 2u * e0 * es;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < F; ++j) {
         const unsigned so = 2u * (unsigned)(j * STEP) * es;
         v[j].x = bload_f(r, vo, so);
         v[j].y = bload_f(r, vo, so + es);
@@ -144,15 +144,15 @@ struct LoadPcmPacked {
     if constexpr (sizeof(Sample) == 2) return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(r, vo, so, 0) * scale;
     else return (float)(int)__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0) * scale;
   }
-  template <int STEP>
-  __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[16]) const {
+  template <int STEP, int F>
+  __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[F]) const {
     const Sample* p = base + (long long)b * chan_stride;
     const unsigned es = (unsigned)elem_stride * (unsigned)sizeof(Sample);
     const __amdgpu_buffer_rsrc_t r =
         make_rsrc(p, ((unsigned)(len - 1) * (unsigned)elem_stride + 1u) * (unsigned)sizeof(Sample));
     const unsigned vo = 2u * e0 * es;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < F; ++j) {
       const unsigned so = 2u * (unsigned)(j * STEP) * es;
       v[j].x = sample(r, vo, so);
       v[j].y = sample(r, vo, so + es);
@@ -163,11 +163,11 @@ struct LoadPcmPacked {
 struct LoadWorkspace {
   const cf* __restrict__ ws;   // [B][N1][4096]
   int n1_total;
-  template <int STEP>
-  __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[16]) const {
+  template <int STEP, int F>
+  __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[F]) const {
     const __amdgpu_buffer_rsrc_t r = make_rsrc(ws + (long long)b * n1_total * kN2, (unsigned)n1_total * kN2 * 8u);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = bload_cf(r, e0 * 8u, (unsigned)(j * STEP) * 8u);
+    for (int j = 0; j < F; ++j) v[j] = bload_cf(r, e0 * 8u, (unsigned)(j * STEP) * 8u);
   }
 };
 
@@ -247,25 +247,26 @@ struct ColsCfg {
   static constexpr size_t lds_bytes = (R2 > 1) ? sizeof(cf) * 16 * T : 0;
 };
 
-// first stage shared by both column kernels: fetch, (inverse: conj four-step twiddle,) FFT16, w_N1^(g a)
-template <int R2, int TC, int DIR, class Load>
+// first stage shared by both column kernels: fetch F rows (i = g + R2 j), (inverse: conj four-step twiddle,)
+// F-point FFT over j -> a, x w_N1^(g a)
+template <int F, int R2, int TC, int DIR, class Load>
 __device__ __forceinline__ void cols_first_stage(const Load& ld, const Twiddles& tw, __amdgpu_buffer_rsrc_t r_full,
-                                                 int b, int g, unsigned e0, cf (&v)[16]) {
-  ld.template column<R2 * kN2>(b, e0, v);
+                                                 int b, int g, unsigned e0, cf (&v)[F]) {
+  ld.template column<R2 * kN2, F>(b, e0, v);
   if constexpr (DIR > 0) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = cmulc(v[j], bload_cf(r_full, e0 * 8u, (unsigned)(j * R2 * kN2) * 8u));
+    for (int j = 0; j < F; ++j) v[j] = cmulc(v[j], bload_cf(r_full, e0 * 8u, (unsigned)(j * R2 * kN2) * 8u));
   }
-  fft16<DIR>(v);   // index a
+  fft_first<DIR, F>(v);   // index a
   if constexpr (R2 > 1) {
     // w_N1^(g a) = hi[4 g a]  (Nc/1024 = 4 N1 entries); g is wave-uniform for 64-column tiles
     if constexpr (TC == 64) {
       const int gu = __builtin_amdgcn_readfirstlane(g);
 #pragma unroll
-      for (int a = 1; a < 16; ++a) v[a] = ctw_uniform<DIR>(v[a], tw.hi[4 * gu * a]);
+      for (int a = 1; a < F; ++a) v[a] = ctw_uniform<DIR>(v[a], tw.hi[4 * gu * a]);
     } else {
 #pragma unroll
-      for (int a = 1; a < 16; ++a) v[a] = ctw<DIR>(v[a], tw.hi[4 * g * a]);
+      for (int a = 1; a < F; ++a) v[a] = ctw<DIR>(v[a], tw.hi[4 * g * a]);
     }
   }
 }
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
         twd[i][kb] = bload_cf(r_full, ((unsigned)((R2 > 1 ? g * G : 0) + i) * kN2 + n2) * 8u, (unsigned)(kb * 16 * kN2) * 8u);
   }
   cf v[16];
-  cols_first_stage<R2, TC, DIR>(ld, tw, r_full, b, g, (unsigned)g * kN2 + n2, v);
+  cols_first_stage<16, R2, TC, DIR>(ld, tw, r_full, b, g, (unsigned)g * kN2 + n2, v);
 
   if constexpr (R2 > 1) {
 #pragma unroll
@@ -323,27 +324,29 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Column pass for N1 = 16*R2 with an odd factor, R2 in {3, 5, 6, 10, 12}.  Same first stage as
-// cols_kernel (FFT16 over j); the second stage is 16 DFTs of R2 points per column, dealt to the R2
-// threads of the column as ka = g, g + R2, ... (< 16), so a thread holds up to G = ceil(16/R2)
-// butterflies.  These sizes exist because the circular length only has to cover
-// L + ceil((M-1)/2) in 'same' mode: 5*2^17 instead of 2^20 for the 7.1 / 6.15 s case.
+// Column pass for N1 = F*R2 with an odd factor: F = 16 rows per thread and R2 in {3, 5, 6, 9, 10, 12}, or
+// F = 8 and R2 in {3, 5, 9} (N1 = 24, 40, 72).  Same first stage as cols_kernel (F-point FFT over j); the
+// second stage is F DFTs of R2 points per column, dealt to the R2 threads of the column as
+// ka = g, g + R2, ... (< F), so a thread holds up to G = ceil(F/R2) butterflies.  These sizes exist
+// because the circular length only has to cover L + ceil((M-1)/2) in 'same' mode: 72 rows of 4096
+// complex points (589 824 samples) instead of 128 for the 7.1 / 6.15 s case, and every row not
+// transformed is 32 KiB less workspace traffic in each of the four trips.
 // ---------------------------------------------------------------------------------------------
-template <int R2>
+template <int F, int R2>
 struct MixCfg {
-  // 64 columns = 512-byte row segments; R2 = 12 would need 96 KiB of LDS (one workgroup per CU), so it
-  // takes 32-column tiles (48 KiB, three per CU): C5 +5 %.  Narrower tiles everywhere were slower
+  // 64 columns = 512-byte row segments; F = 16 with R2 = 12 would need 96 KiB of LDS (one workgroup per CU),
+  // so it takes 32-column tiles (48 KiB, three per CU): C5 +5 %.  Narrower tiles everywhere were slower
   // (256-byte row segments: C2 327 k -> 300 k IR/s, C3 -6 %).
-  static constexpr int TC = (R2 >= 12) ? 32 : 64;
+  static constexpr int TC = (F * R2 >= 192) ? 32 : 64;
   static constexpr int T = TC * R2;
-  static constexpr int G = (16 + R2 - 1) / R2;
-  static constexpr size_t lds_bytes = sizeof(cf) * 16 * T;
+  static constexpr int G = (F + R2 - 1) / R2;
+  static constexpr size_t lds_bytes = sizeof(cf) * F * T;
 };
 
-template <int R2, int DIR, class Load, class Store>
-__global__ __launch_bounds__(MixCfg<R2>::T) void cols_mixed_kernel(Load ld, Store st, Twiddles tw, int nchan,
-                                                                    int n1_total) {
-  using Cfg = MixCfg<R2>;
+template <int F, int R2, int DIR, class Load, class Store>
+__global__ __launch_bounds__((MixCfg<F, R2>::T)) void cols_mixed_kernel(Load ld, Store st, Twiddles tw, int nchan,
+                                                                       int n1_total) {
+  using Cfg = MixCfg<F, R2>;
   constexpr int TC = Cfg::TC, T = Cfg::T, G = Cfg::G;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cf* buf = reinterpret_cast<cf*>(smem_raw);
@@ -364,32 +367,32 @@ __global__ __launch_bounds__(MixCfg<R2>::T) void cols_mixed_kernel(Load ld, Stor
 #pragma unroll
     for (int i = 0; i < G; ++i) {
       const int ka = g + R2 * i;
-      if (ka < 16) {
+      if (ka < F) {
 #pragma unroll
         for (int kb = 0; kb < R2; ++kb)
-          twd[i][kb] = bload_cf(r_full, ((unsigned)ka * kN2 + n2) * 8u, (unsigned)(kb * 16 * kN2) * 8u);
+          twd[i][kb] = bload_cf(r_full, ((unsigned)ka * kN2 + n2) * 8u, (unsigned)(kb * F * kN2) * 8u);
       }
     }
   }
-  cf v[16];
-  cols_first_stage<R2, TC, DIR>(ld, tw, r_full, b, g, (unsigned)g * kN2 + n2, v);
+  cf v[F];
+  cols_first_stage<F, R2, TC, DIR>(ld, tw, r_full, b, g, (unsigned)g * kN2 + n2, v);
 #pragma unroll
-  for (int a = 0; a < 16; ++a) buf[a * T + tid] = v[a];
+  for (int a = 0; a < F; ++a) buf[a * T + tid] = v[a];
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < G; ++i) {
     const int ka = g + R2 * i;
-    if (ka < 16) {
+    if (ka < F) {
       cf y[R2];
 #pragma unroll
       for (int gp = 0; gp < R2; ++gp) y[gp] = buf[ka * T + gp * TC + c];
       fft_small<DIR, R2>(y);
       const unsigned e = (unsigned)ka * kN2 + n2;
 #pragma unroll
-      for (int kb = 0; kb < R2; ++kb) {
+      for (int kb = 0; kb < R2; ++kb) {                    // output row k1 = ka + F kb
         cf z = y[kb];
         if constexpr (DIR < 0) z = cmul(z, twd[i][kb]);
-        st.put(r_out, e, (unsigned)(kb * 16 * kN2), z);
+        st.put(r_out, e, (unsigned)(kb * F * kN2), z);
       }
     }
   }
@@ -468,6 +471,7 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   const int N1 = args.n1_total;
   int b, pair;
   xcd_work_item(args.nchan, pair, b);
+  if (pair >= args.npairs) return;              // the grid is padded to a multiple of 8 pairs (whole workgroup exits)
   const int rowA = pair;
   const int rowB = (pair == 0) ? (N1 >> 1) : (N1 - pair);
   const int k1 = half ? rowB : rowA;

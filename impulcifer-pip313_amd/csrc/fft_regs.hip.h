@@ -181,6 +181,14 @@ __host__ __device__ __forceinline__ void fft8(cf& x0, cf& x1, cf& x2, cf& x3, cf
   x1 = t2; x2 = t4; x3 = t6; x4 = t1; x5 = t3; x6 = t5;
 }
 
+// first stage of the column passes: F-point DFT of the thread's F rows
+template <int DIR, int F>
+__host__ __device__ __forceinline__ void fft_first(cf (&v)[F]) {
+  static_assert(F == 16 || F == 8, "first stage holds 16 or 8 rows per thread");
+  if constexpr (F == 16) fft16<DIR>(v);
+  else fft8<DIR>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+}
+
 // R-point DFT applied to the G = 16/R independent groups v[i*R .. i*R+R-1].
 template <int DIR, int R>
 __host__ __device__ __forceinline__ void fft_groups(cf (&v)[16]) {
@@ -234,11 +242,28 @@ __host__ __device__ __forceinline__ void bfly5(cf& a, cf& b, cf& c, cf& d, cf& e
   d = csub_rot<DIR>(m2, n2);
 }
 
-// R-point DFT of x[0..R-1] in place, natural order in and out, R in {3, 5, 6, 10, 12}.
+// R-point DFT of x[0..R-1] in place, natural order in and out, R in {3, 5, 6, 9, 10, 12}.
 template <int DIR, int R>
 __host__ __device__ __forceinline__ void fft_small(cf* x) {
   if constexpr (R == 3) {
     bfly3<DIR>(x[0], x[1], x[2]);
+  } else if constexpr (R == 9) {
+    // n = 3 n1 + n2 ; k = k1 + 3 k2 : three radix-3 over n1, twiddle w9^(n2 k1), three radix-3 over n2
+    constexpr float C1 = 0.76604444311897803520f, S1 = 0.64278760968653932632f;    // 2 pi / 9
+    constexpr float C2 = 0.17364817766693034885f, S2 = 0.98480775301220805937f;    // 4 pi / 9
+    constexpr float C4 = -0.93969262078590838405f, S4 = 0.34202014332566873304f;   // 8 pi / 9
+#pragma unroll
+    for (int n2 = 0; n2 < 3; ++n2) bfly3<DIR>(x[n2], x[3 + n2], x[6 + n2]);         // x[3 k1 + n2] = A[n2][k1]
+    x[3 * 1 + 1] = ctw<DIR>(x[3 * 1 + 1], make_float2(C1, -S1));
+    x[3 * 1 + 2] = ctw<DIR>(x[3 * 1 + 2], make_float2(C2, -S2));
+    x[3 * 2 + 1] = ctw<DIR>(x[3 * 2 + 1], make_float2(C2, -S2));
+    x[3 * 2 + 2] = ctw<DIR>(x[3 * 2 + 2], make_float2(C4, -S4));
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) bfly3<DIR>(x[3 * k1], x[3 * k1 + 1], x[3 * k1 + 2]);   // x[3 k1 + k2] = X[k1 + 3 k2]
+    cf t;
+    t = x[1]; x[1] = x[3]; x[3] = t;
+    t = x[2]; x[2] = x[6]; x[6] = t;
+    t = x[5]; x[5] = x[7]; x[7] = t;
   } else if constexpr (R == 5) {
     bfly5<DIR>(x[0], x[1], x[2], x[3], x[4]);
   } else if constexpr (R == 6) {

@@ -363,7 +363,7 @@ struct imp_plan {
   int mode = IMP_MODE_SAME;
   int64_t out_start = 0, out_len = 0;
   int64_t nfft = 0, Nc = 0;
-  int N1 = 0, R2 = 0;
+  int N1 = 0, R2 = 0, F = 16;       // N1 = F * R2 rows; F = rows per thread in the column passes
   int64_t ws_channels = 0;           // channels the workspace holds in total
   int lanes = 1;                     // launch groups in flight (imp_plan_set_overlap)
   int64_t group_counter_lane = 0;    // round-robin lane assignment of launch groups
@@ -404,10 +404,10 @@ static int launch_cols(imp_plan* p, int64_t nchan, Load ld, Store st) {
   return IMP_OK;
 }
 
-template <int R2, int DIR, class Load, class Store>
+template <int F, int R2, int DIR, class Load, class Store>
 static int launch_cols_mixed(imp_plan* p, int64_t nchan, Load ld, Store st) {
-  using Cfg = imp::MixCfg<R2>;
-  auto kern = imp::cols_mixed_kernel<R2, DIR, Load, Store>;
+  using Cfg = imp::MixCfg<F, R2>;
+  auto kern = imp::cols_mixed_kernel<F, R2, DIR, Load, Store>;
   static bool attr_set = false;   // per instantiation
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -424,17 +424,26 @@ static int launch_cols_mixed(imp_plan* p, int64_t nchan, Load ld, Store st) {
 
 template <int DIR, class Load, class Store>
 static int launch_cols_any(imp_plan* p, int64_t nchan, Load ld, Store st) {
+  if (p->F == 8) {
+    switch (p->R2) {
+      case 3: return launch_cols_mixed<8, 3, DIR>(p, nchan, ld, st);
+      case 5: return launch_cols_mixed<8, 5, DIR>(p, nchan, ld, st);
+      case 9: return launch_cols_mixed<8, 9, DIR>(p, nchan, ld, st);
+    }
+    return fail(IMP_ERR_UNSUPPORTED, "unsupported column factorisation 8 x %d", p->R2);
+  }
   switch (p->R2) {
     case 1: return launch_cols<1, DIR>(p, nchan, ld, st);
     case 2: return launch_cols<2, DIR>(p, nchan, ld, st);
     case 4: return launch_cols<4, DIR>(p, nchan, ld, st);
     case 8: return launch_cols<8, DIR>(p, nchan, ld, st);
     case 16: return launch_cols<16, DIR>(p, nchan, ld, st);
-    case 3: return launch_cols_mixed<3, DIR>(p, nchan, ld, st);
-    case 5: return launch_cols_mixed<5, DIR>(p, nchan, ld, st);
-    case 6: return launch_cols_mixed<6, DIR>(p, nchan, ld, st);
-    case 10: return launch_cols_mixed<10, DIR>(p, nchan, ld, st);
-    case 12: return launch_cols_mixed<12, DIR>(p, nchan, ld, st);
+    case 3: return launch_cols_mixed<16, 3, DIR>(p, nchan, ld, st);
+    case 5: return launch_cols_mixed<16, 5, DIR>(p, nchan, ld, st);
+    case 6: return launch_cols_mixed<16, 6, DIR>(p, nchan, ld, st);
+    case 9: return launch_cols_mixed<16, 9, DIR>(p, nchan, ld, st);
+    case 10: return launch_cols_mixed<16, 10, DIR>(p, nchan, ld, st);
+    case 12: return launch_cols_mixed<16, 12, DIR>(p, nchan, ld, st);
   }
   return fail(IMP_ERR_UNSUPPORTED, "unsupported column radix %d", p->R2);
 }
@@ -457,7 +466,8 @@ static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan) {
   a.npairs = p->N1 / 2;
   a.nchan = (int)nchan;
   imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
-  dim3 grid((unsigned)(nchan * a.npairs)), block(512);
+  // the XCD-aware work mapping deals pairs in eights: pad, the surplus workgroups exit at once
+  dim3 grid((unsigned)(nchan * ((a.npairs + 7) / 8 * 8))), block(512);
   hipLaunchKernelGGL(imp::rows_kernel, grid, block, kRowsLds, p->cur_stream, a, tw);
   HIP_TRY(hipGetLastError());
   return IMP_OK;
@@ -472,16 +482,21 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   // the discarded part: P >= L + ceil((M-1)/2) = L + M/2 is enough (and P >= M so the filter fits).
   const int64_t full = L + M - 1;
   const int64_t need = (mode == IMP_MODE_SAME) ? std::max(L + M / 2, M) : full;
-  static const int kR2[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};      // N1 = 16*R2 rows of 4096
-  int r2 = 0;
+  // N1 = F * R2 rows of 4096 complex points, ascending; F = rows per thread in the column passes
+  static const struct { int f, r2; } kShapes[] = {{16, 1}, {8, 3},  {16, 2}, {8, 5},  {16, 3},  {16, 4},  {8, 9},
+                                                  {16, 5}, {16, 6}, {16, 8}, {16, 9}, {16, 10}, {16, 12}, {16, 16}};
+  int r2 = 0, f1 = 16;
   const bool pow2_only = std::getenv("IMPULSE_HIP_POW2_ONLY") != nullptr;     // debug/experiments
   const bool no_wrap = std::getenv("IMPULSE_HIP_NO_WRAP") != nullptr;
   const int64_t need_eff = no_wrap ? full : need;
-  for (int cand : kR2)
-    if ((!pow2_only || (cand & (cand - 1)) == 0) && (int64_t)cand * 2 * 16 * imp::kN2 >= need_eff) {
-      r2 = cand;
+  for (const auto& sh : kShapes) {
+    const int n1 = sh.f * sh.r2;
+    if ((!pow2_only || (n1 & (n1 - 1)) == 0) && (int64_t)n1 * 2 * imp::kN2 >= need_eff) {
+      r2 = sh.r2;
+      f1 = sh.f;
       break;
     }
+  }
   if (!r2)
     return fail(IMP_ERR_UNSUPPORTED, "needs a transform of %lld points, beyond 2^21 (two-level plan)", (long long)need);
   p->L = L;
@@ -489,7 +504,8 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   p->n_filters = n_filters;
   p->mode = mode;
   p->R2 = r2;
-  p->N1 = 16 * r2;
+  p->F = f1;
+  p->N1 = f1 * r2;
   p->Nc = (int64_t)p->N1 * imp::kN2;
   p->nfft = 2 * p->Nc;
   if (mode == IMP_MODE_SAME) {
@@ -602,7 +618,7 @@ extern "C" int imp_debug_plan_geometry(int64_t M, int64_t L, int mode, int64_t* 
 }
 
 extern "C" int imp_debug_host_spectrum(const double* filter, int64_t M, int n1_rows, float* ab_out) {
-  if (!filter || !ab_out || M < 1 || n1_rows < 16 || n1_rows % 16) return fail(IMP_ERR_INVALID, "imp_debug_host_spectrum: bad argument");
+  if (!filter || !ab_out || M < 1 || n1_rows < 16 || n1_rows % 8) return fail(IMP_ERR_INVALID, "imp_debug_host_spectrum: bad argument");
   const int64_t Nc = (int64_t)n1_rows * imp::kN2;
   if (M > 2 * Nc) return fail(IMP_ERR_INVALID, "filter longer than the transform");
   std::vector<cd> H;

@@ -7,7 +7,7 @@ algebra can be unit-tested on a CPU-only box.  All arithmetic is float64 here;
 the kernels do the same steps in fp32.
 
 Layout conventions (identical to the kernels):
-  nfft = 2*Nc, Nc = N1*N2, N2 = 4096 (row length), N1 = 16*R2 (column length)
+  nfft = 2*Nc, Nc = N1*N2, N2 = 4096 (row length), N1 = F*R2 (column length, F = 16 or 8)
   z[n] = x[2n] + i x[2n+1]            (even/odd packing of one real channel)
   n  = N2*n1 + n2   -> workspace[k1][n2] after pass A   (k1 = ka + 16*kb)
   k  = k1 + N1*k2   -> workspace[k1][k2] inside pass B  (transposed spectrum order)
@@ -163,16 +163,17 @@ def pass_c(ws, nfft, start, length):
     return full[start:start + length]
 
 
-SUPPORTED_R2 = (1, 2, 3, 4, 5, 6, 8, 10, 12, 16)     # N1 = 16*R2 rows of 4096 -> nfft = 131072*R2
+# N1 = F*R2 rows of 4096 complex points (F = rows per thread in the column passes) -> nfft = 8192*N1
+SUPPORTED_N1 = (16, 24, 32, 40, 48, 64, 72, 80, 96, 128, 144, 160, 192, 256)
 
 
 def pick_nfft(L, M, mode="same"):
     """Same rule as plan_geometry() in csrc/impulse_hip.hip: 'same' only needs L + M/2 points
     because wrap-around may fall into the part of the linear convolution the window discards."""
     need = max(L + M // 2, M) if mode == "same" else L + M - 1
-    for r2 in SUPPORTED_R2:
-        if 131072 * r2 >= need:
-            return 131072 * r2
+    for n1 in SUPPORTED_N1:
+        if 8192 * n1 >= need:
+            return 8192 * n1
     raise ValueError("too long")
 
 

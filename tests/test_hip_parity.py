@@ -48,10 +48,11 @@ def spec_rel_cropped(y, ref, fs=48000, n=None):
 # ------------------------------------------------------------------------------------------------
 # K1/K5: convolution plans against the oracle
 # ------------------------------------------------------------------------------------------------
-# sizes chosen to hit every column radix R2 (nfft = 131072*R2) in at least one mode:
-# 'same': R2 = 1, 1, 1, 1, 2, 3, 5, 6, 10 ; 'full': 1, 1, 1, 1, 2, 3, 6, 8, 12
+# sizes chosen to hit every column shape N1 = F x R2 (nfft = 8192 N1) in at least one mode:
+# 'same': N1 = 16, 16, 16, 16, 32, 40, 72, 96, 144, 24, 48, 64, 80, 128 ; 'full': 16, 16, 16, 32, 32, 48, 96, 128, 192, 32, 48, 80, 96, 160
 @pytest.mark.parametrize("L,M", [(1, 1), (17, 5), (1000, 999), (70001, 61000), (150000, 100001),
-                                 (243635, 147635), (391270, 295270), (500000, 400000), (827965, 635965)])
+                                 (243635, 147635), (391270, 295270), (500000, 400000), (827965, 635965),
+                                 (150000, 80000), (300000, 150000), (420000, 200000), (500000, 300000), (800000, 400000)])
 @pytest.mark.parametrize("mode", ["same", "full"])
 def test_conv_matches_oracle(gpu_ctx, L, M, mode):
     from impulse_hip import ConvPlan
@@ -1131,4 +1132,7 @@ def test_conv_fuzz_layouts_and_sizes(gpu_ctx):
             assert y[b].shape == ref.shape
             # 32-bit PCM is rounded to fp32 on load (the device dtype): 6e-8 relative input error on top
             tol = TIME_TOL if layout != "pcm32" else 2 * TIME_TOL
+            if mode == "same" and M > 4 * L:
+                tol *= 1.5        # a short window of a long filter's output: the window's peak is small next to
+                                  # the transform's rounding noise, which scales with the whole filter's energy
             assert rel(y[b], ref) <= tol, (case, layout, L, M, mode, B, b)

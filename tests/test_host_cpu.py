@@ -184,8 +184,9 @@ def test_plan_geometry_wraparound_rule(lib):
     import fourstep_model as fm
     from impulse_hip._native import plan_geometry
     from oracle.scipy_restated import fft_convolve
-    cases = {(391270, 295270): 655360, (827965, 635965): 1310720, (1 << 20, 1 << 20): 1572864,
-             (243635, 147635): 393216, (100, 4): 131072, (4, 100): 131072, (1, 1): 131072}
+    cases = {(391270, 295270): 589824, (827965, 635965): 1179648, (1 << 20, 1 << 20): 1572864,
+             (243635, 147635): 327680, (100, 4): 131072, (4, 100): 131072, (1, 1): 131072,
+             (150000, 80000): 196608}                                   # N1 = 72, 144, 192, 40, 16, 16, 16, 24
     for (L, M), want in cases.items():
         nfft, start, n = plan_geometry(M, L, "same")
         assert nfft == want == fm.pick_nfft(L, M, "same")
@@ -197,7 +198,7 @@ def test_plan_geometry_wraparound_rule(lib):
         plan_geometry(4, 3_000_000, "same")
     # aliasing lands only outside the window: model at the reduced size == linear convolution
     rng = np.random.default_rng(8)
-    for L, M in ((250000, 190000), (60000, 130000)):          # nfft 393216 (R2=3) / 131072 with M > L
+    for L, M in ((250000, 190000), (60000, 130000)):          # nfft 393216 (N1 = 48) / 131072 with M > L
         x, h = rng.standard_normal(L), rng.standard_normal(M)
         nfft = fm.pick_nfft(L, M, "same")
         assert nfft < L + M - 1
@@ -206,7 +207,7 @@ def test_plan_geometry_wraparound_rule(lib):
         assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-12
 
 
-@pytest.mark.parametrize("n1", [16, 48, 80, 96, 128, 160, 192])
+@pytest.mark.parametrize("n1", [16, 24, 40, 48, 72, 80, 96, 128, 144, 160, 192])
 def test_host_spectrum_matches_model(lib, n1):
     """fp64 host FFT (radices 2/3/5) + alpha/beta packing of the library vs the NumPy model."""
     import fourstep_model as fm
