@@ -5,7 +5,7 @@
 //   core/impulse_response.py:119,135        (equalize / convolve: 'full')
 //
 // One real channel x[L] is packed even/odd into z[n] = x[2n] + i x[2n+1] (Nc = nfft/2 complex
-// points, Nc = N1*N2, N2 = 4096, N1 = 16*R2, R2 in {1,2,3,4,5,6,8,10,12,16}) and transformed with a
+// points, Nc = N1*N2, N2 = 4096, N1 = F*R2 in {16,24,32,40,48,64,72,80,96,128,144,160,192,256}) and transformed with a
 // four-step FFT:
 //   pass A  cols_kernel<fwd>   : length-N1 column FFTs (stride N2), x w_Nc^(n2 k1)     -> ws[k1][n2]
 //   pass B  rows_kernel        : length-4096 row FFT -> real-FFT unpack * H * repack
