@@ -105,6 +105,11 @@ struct LoadRealPacked {
   long long chan_stride;            // elements between channels
   long long elem_stride;            // elements between consecutive samples of a channel
   long long len;                    // valid samples per channel
+  // the block [first, first + maxlen) of every channel (overlap-add over long inputs)
+  __host__ __device__ LoadRealPacked shifted(long long first, long long maxlen) const {
+    const long long rest = len - first;
+    return LoadRealPacked{base + first * elem_stride, chan_stride, elem_stride, rest < maxlen ? rest : maxlen};
+  }
   template <int STEP, int F>
   __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[F]) const {
     const float* p = base + (long long)b * chan_stride;
@@ -140,6 +145,10 @@ struct LoadPcmPacked {
   long long elem_stride;
   long long len;
   float scale;
+  __host__ __device__ LoadPcmPacked shifted(long long first, long long maxlen) const {
+    const long long rest = len - first;
+    return LoadPcmPacked{base + first * elem_stride, chan_stride, elem_stride, rest < maxlen ? rest : maxlen, scale};
+  }
   __device__ __forceinline__ float sample(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) const {
     if constexpr (sizeof(Sample) == 2) return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(r, vo, so, 0) * scale;
     else return (float)(int)__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0) * scale;
@@ -212,6 +221,27 @@ struct StoreRealCrop {
       x.y = __float_as_uint(v.y);
       __builtin_amdgcn_raw_buffer_store_b64(x, r, off, 0u, kStreamAux);
     }
+  }
+};
+
+// Overlap-add: the piece's full convolution is ADDED into the window [start, start+len) of the long result
+// (start may be negative: the piece then begins inside the window).  Pieces of one output run in stream
+// order, so the read-modify-write needs no atomics; the range check clips as in StoreRealCrop.
+struct StoreRealCropAdd {
+  float* __restrict__ base;
+  long long chan_stride;
+  long long start;
+  long long len;
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind(int b) const {
+    return make_rsrc(base + (long long)b * chan_stride, (unsigned)len * 4u);
+  }
+  __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, unsigned e, unsigned step_elems, cf v) const {
+    const unsigned off = (2u * (e + step_elems) - (unsigned)start) * 4u;
+    unsigned off_im = off + 4u;
+    asm volatile("" : "+v"(off_im));            // two dword accesses: the straddling point splits at either edge
+    const float re = bload_f(r, off, 0u), im = bload_f(r, off_im, 0u);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(re + v.x), r, off, 0u, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(im + v.y), r, off_im, 0u, 0);
   }
 };
 

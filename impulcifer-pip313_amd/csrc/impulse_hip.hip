@@ -363,6 +363,9 @@ struct imp_plan {
   int mode = IMP_MODE_SAME;
   int64_t out_start = 0, out_len = 0;
   int64_t nfft = 0, Nc = 0;
+  // overlap-add (need > 2^21 points): pieces of ola_lb input samples x ola_mp filter taps, each a 'full' transform
+  bool ola = false;
+  int64_t ola_lb = 0, ola_mp = 0, ola_blocks = 1, ola_parts = 1;
   int N1 = 0, R2 = 0, F = 16;       // N1 = F * R2 rows; F = rows per thread in the column passes
   int64_t ws_channels = 0;           // channels the workspace holds in total
   int lanes = 1;                     // launch groups in flight (imp_plan_set_overlap)
@@ -450,7 +453,7 @@ static int launch_cols_any(imp_plan* p, int64_t nchan, Load ld, Store st) {
 
 static constexpr size_t kRowsLds = sizeof(cf) * 2 * 16 * imp::kRowPad;
 
-static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan) {
+static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan, int64_t part = 0) {
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(imp::rows_kernel),
@@ -460,8 +463,8 @@ static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan) {
   imp::RowsArgs a;
   a.ws = p->cur_ws;
   const int64_t plane = (int64_t)p->N1 * imp::kN2;
-  a.ab = p->ab + (p->n_filters > 1 ? first_chan * plane : 0);
-  a.ab_chan_stride = p->n_filters > 1 ? plane : 0;
+  a.ab = p->ab + (p->n_filters > 1 ? first_chan * p->ola_parts * plane : 0) + part * plane;
+  a.ab_chan_stride = p->n_filters > 1 ? p->ola_parts * plane : 0;
   a.n1_total = p->N1;
   a.npairs = p->N1 / 2;
   a.nchan = (int)nchan;
@@ -497,8 +500,23 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
       break;
     }
   }
-  if (!r2)
-    return fail(IMP_ERR_UNSUPPORTED, "needs a transform of %lld points, beyond 2^21 (two-level plan)", (long long)need);
+  p->ola = false;
+  if (!r2) {
+    // Longer than one two-level transform (2^21 points): overlap-add.  The input is cut into blocks and, when
+    // the filter itself is longer than 2^20 taps, the filter into partitions; every (block, partition) piece is
+    // a 'full' convolution of at most 2^21 points through the same three passes, added into the result.
+    if (L >= ((int64_t)1 << 29) || M >= ((int64_t)1 << 29))
+      return fail(IMP_ERR_UNSUPPORTED, "L = %lld / M = %lld beyond the 2^29 samples one channel's buffer range covers",
+                  (long long)L, (long long)M);
+    const int64_t cap = (int64_t)1 << 21;
+    p->ola = true;
+    p->ola_mp = std::min<int64_t>(M, cap / 2);
+    p->ola_lb = cap - p->ola_mp + 1;                       // Lb + Mp - 1 = 2^21
+    p->ola_parts = (M + p->ola_mp - 1) / p->ola_mp;
+    p->ola_blocks = (L + p->ola_lb - 1) / p->ola_lb;
+    r2 = 16;
+    f1 = 16;
+  }
   p->L = L;
   p->M = M;
   p->n_filters = n_filters;
@@ -530,7 +548,7 @@ static int plan_alloc(imp_plan* p) {
   if (rc) return rc;
   if ((rc = ctx_twiddles(p->ctx, p->N1, &p->tw))) return rc;
   const size_t plane = (size_t)p->N1 * imp::kN2;
-  hipError_t e = hipMalloc((void**)&p->ab, plane * (size_t)p->n_filters * sizeof(float4));
+  hipError_t e = hipMalloc((void**)&p->ab, plane * (size_t)(p->n_filters * p->ola_parts) * sizeof(float4));
   if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(spectrum): %s", hipGetErrorString(e));
   e = hipMalloc((void**)&p->ws, plane * (size_t)p->ws_channels * sizeof(cf));
   if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(workspace): %s", hipGetErrorString(e));
@@ -582,7 +600,7 @@ extern "C" int imp_conv_plan_create(imp_ctx* ctx, const double* filter, int64_t 
   if (rc) return rc;
   // IMPULSE_HIP_HOST_SPECTRUM=1 keeps the fp64 host preparation (the cross-check path of the tests)
   const char* host_env = std::getenv("IMPULSE_HIP_HOST_SPECTRUM");
-  if (host_env && host_env[0] == '1') {
+  if (host_env && host_env[0] == '1' && !p->ola) {
     const size_t plane = (size_t)p->N1 * imp::kN2;
     std::vector<float4> ab(plane);
     std::vector<cd> H;
@@ -596,6 +614,19 @@ extern "C" int imp_conv_plan_create(imp_ctx* ctx, const double* filter, int64_t 
         imp_plan_destroy(p);
         return fail(IMP_ERR_HIP, "spectrum upload: %s", hipGetErrorString(e));
       }
+    }
+  } else if (p->ola) {
+    // plane (f, j) = partition j of filter f
+    const size_t plane = (size_t)p->N1 * imp::kN2;
+    for (int64_t j = 0; j < p->ola_parts && !rc; ++j) {
+      const int64_t m0 = j * p->ola_mp, mj = std::min(p->ola_mp, M - m0);
+      for (int64_t f = 0; f < n_filters && !rc; ++f)
+        rc = spectrum_alpha_beta_device(ctx, filter + f * (n_filters > 1 ? filter_ld : M) + m0, mj, 1, mj, p->Nc, p->N1,
+                                        p->ab + (size_t)(f * p->ola_parts + j) * plane);
+    }
+    if (rc) {
+      imp_plan_destroy(p);
+      return rc;
     }
   } else if ((rc = spectrum_alpha_beta_device(ctx, filter, M, n_filters, n_filters > 1 ? filter_ld : M, p->Nc, p->N1,
                                                p->ab))) {
@@ -741,6 +772,23 @@ static int run_group_with(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64
     return fail(IMP_ERR_INVALID, "channel %lld has no filter: the plan holds %lld per-channel filters",
                 (long long)(first_chan + nchan - 1), (long long)p->n_filters);
   imp::StoreWorkspace stw{p->cur_ws, p->N1};
+  if (p->ola) {
+    if (last_stage < 2) return fail(IMP_ERR_UNSUPPORTED, "debug stages are not available on overlap-add plans");
+    HIP_TRY(hipMemset2DAsync(d_y, (size_t)chan_stride_out * sizeof(float), 0, (size_t)p->out_len * sizeof(float),
+                             (size_t)nchan, p->cur_stream));
+    imp::LoadWorkspace ldw{p->cur_ws, p->N1};
+    for (int64_t i = 0; i < p->ola_blocks; ++i) {
+      const Load ldi = ld.shifted(i * p->ola_lb, p->ola_lb);
+      for (int64_t j = 0; j < p->ola_parts; ++j) {
+        // pass B is in place, so every partition starts from a fresh forward transform of the block
+        if ((rc = launch_cols_any<-1>(p, nchan, ldi, stw))) return rc;
+        if ((rc = launch_rows(p, nchan, first_chan, j))) return rc;
+        imp::StoreRealCropAdd sta{d_y, chan_stride_out, p->out_start - i * p->ola_lb - j * p->ola_mp, p->out_len};
+        if ((rc = launch_cols_any<+1>(p, nchan, ldw, sta))) return rc;
+      }
+    }
+    return IMP_OK;
+  }
   if ((rc = timing_event(p, 0))) return rc;
   if ((rc = launch_cols_any<-1>(p, nchan, ld, stw))) return rc;
   if ((rc = timing_event(p, 1))) return rc;

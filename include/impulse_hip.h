@@ -67,9 +67,11 @@ int imp_memset(imp_ctx* ctx, void* dptr, int value, size_t bytes);
  *   core/impulse_response.py:110-119, 126-135    ImpulseResponse.equalize / convolve (mode 'full')
  *   core/parallel_workers.py:9-21                process_plot_worker (mode 'full')
  *
- * A plan fixes (filter, M, L, mode).  The circular length is nfft = 131072*R2 with
- * R2 in {1,2,3,4,5,6,8,10,12,16}: the smallest that covers L+M-1 ('full') or L + M/2 ('same':
- * wrap-around may fall into the part of the linear convolution that the window discards).
+ * A plan fixes (filter, M, L, mode).  The circular length is nfft = 8192*N1 with
+ * N1 in {16,24,32,40,48,64,72,80,96,128,144,160,192,256}: the smallest that covers L+M-1 ('full') or
+ * L + M/2 ('same': wrap-around may fall into the part of the linear convolution that the window
+ * discards).  Beyond 2^21 points the plan runs overlap-add: input blocks x filter partitions of at most
+ * 2^21 points each through the same kernels, accumulated on the device (L, M < 2^29).
  * ws_channels = channels processed per launch group (0 = choose so that the workspace stays
  * resident in the 256 MiB Infinity Cache).
  */

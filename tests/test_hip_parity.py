@@ -1230,3 +1230,28 @@ def test_c3_slice_13ch_96k_against_oracle(gpu_ctx):
         got = hrir.irs[sp][sd].data
         assert got.shape == want.shape
         assert rel(got, want) <= 1e-6, (sp, sd)
+
+
+@pytest.mark.parametrize("L,M,mode", [(3_000_000, 5, "same"), (2_300_000, 700_001, "same"), (2_600_000, 1_500_000, "full"),
+                                      (100, 2_500_000, "same"), (1_200_000, 1_200_000, "full")])
+def test_overlap_add_beyond_one_transform(gpu_ctx, L, M, mode):
+    """Convolutions longer than one two-level transform (2^21 points) run as overlap-add pieces through the
+    same three passes (input blocks x filter partitions, accumulated on the device) - the reference's
+    scipy.signal.convolve has no length limit."""
+    from impulse_hip import ConvPlan
+    from impulse_hip._native import plan_geometry
+    from oracle.scipy_restated import fft_convolve
+    rng = np.random.default_rng(L % 1000 + M % 1000)
+    x = rng.standard_normal((2, L)).astype(np.float32)
+    h = rng.standard_normal(M) * np.exp(-np.arange(M) / max(M / 6.0, 1.0))
+    assert plan_geometry(M, L, mode)[0] == 1 << 21
+    plan = ConvPlan(gpu_ctx, h, L, mode)
+    y = plan.execute(x)
+    yi = plan.execute_interleaved(np.ascontiguousarray(x.T)) if L < 2_500_000 else None
+    plan.close()
+    for b in range(2):
+        ref = fft_convolve(x[b].astype(np.float64), h, mode)
+        assert y[b].shape == ref.shape
+        assert rel(y[b], ref) <= 2 * TIME_TOL, (L, M, mode)           # sums of up to four fp32 pieces
+    if yi is not None:
+        assert np.array_equal(yi, y)

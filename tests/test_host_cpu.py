@@ -194,8 +194,11 @@ def test_plan_geometry_wraparound_rule(lib):
         nfft_f, start_f, n_f = plan_geometry(M, L, "full")
         assert nfft_f == fm.pick_nfft(L, M, "full") >= L + M - 1 and (start_f, n_f) == (0, L + M - 1)
     from impulse_hip import NativeError
+    # beyond one two-level transform: overlap-add pieces of 2^21 points
+    assert plan_geometry(4, 3_000_000, "same") == (1 << 21, 1, 3_000_000)
+    assert plan_geometry(1_500_000, 2_600_000, "full") == (1 << 21, 0, 4_099_999)
     with pytest.raises(NativeError):
-        plan_geometry(4, 3_000_000, "same")
+        plan_geometry(4, 1 << 29, "same")
     # aliasing lands only outside the window: model at the reduced size == linear convolution
     rng = np.random.default_rng(8)
     for L, M in ((250000, 190000), (60000, 130000)):          # nfft 393216 (N1 = 48) / 131072 with M > L
