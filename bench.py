@@ -193,8 +193,8 @@ def load_path_traffic(workload):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ws-channels", type=int, default=0,
@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=3,
                     help="independent launch groups in flight (imp_plan_set_overlap); 1 = strictly serial kernels")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--no-ramp", action="store_true", help="skip the 0.25 s clock ramp before the warm-up (profiling runs)")
     ap.add_argument("--event-stride", type=int, default=8,
                     help="bracket the three passes of every n-th step with HIP events (sampling keeps the "
                          "event records from perturbing the throughput being measured)")
@@ -294,6 +295,14 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # Set-up, before the W warm-up steps the contract counts: the chip needs ~10-20 ms of sustained work to
+    # reach its steady clocks (a 9 ms run of 200 steps measured 349 k IR/s, the same 200 steps after 500 more
+    # 396 k), so the first 0.25 s of steps are spent before the warm-up proper.
+    t_ramp = time.perf_counter()
+    while not args.no_ramp and time.perf_counter() - t_ramp < 0.25:
+        for _ in range(16):
+            step()
+        ctx.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()

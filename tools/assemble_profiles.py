@@ -18,11 +18,12 @@ GROUPS = {"c2": "16 channels at circular length 589824", "c3": "9 channels at ci
 
 def main(out, tag="r01"):
     prof = os.path.join(ROOT, "profiles")
-    kt = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 100 --warmup 10 "
+    kt = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 400 --warmup 20 "
                      "--no-cpu-baseline  (tools/run_profiles.sh)",
-          "note": "bench.py runs 110 overlapped steps (3 launch groups in flight) and then 40 strictly serial ones for the "
-                  "isolated roofline; the kernel_stats.csv averages over all 150 launches of each kernel, this file splits them",
-          "kernels": profile_summary.main(os.path.join(out, "trace"), 110)}
+          "note": "bench.py spends 0.25 s ramping the clocks, then warm-up, 400 timed overlapped steps (3 launch groups in "
+                  "flight) and 40 strictly serial ones for the isolated roofline; the kernel_stats.csv averages over ALL launches "
+                  "of each kernel (ramp included), this file splits out the timed region and the serial tail",
+          "kernels": profile_summary.main(os.path.join(out, "trace"), 400)}
     json.dump(kt, open(os.path.join(prof, f"{tag}_kernel_trace_summary.json"), "w"), indent=1)
     for root, _, files in os.walk(os.path.join(out, "trace")):
         for f in files:
@@ -48,7 +49,7 @@ def main(out, tag="r01"):
                               + what}
     json.dump(traffic, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py "
-                          "--workload W --lanes 1 --no-events --no-cpu-baseline  (tools/run_profiles.sh)",
+                          "--workload W --lanes 1 --no-events --no-ramp --no-cpu-baseline  (tools/run_profiles.sh)",
                "unit": "KB per launch, raw counter values (FETCH_SIZE needs the x2 gfx950 correction)", "workloads": pmc_all},
               open(os.path.join(prof, f"{tag}_pmc_summary.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))

@@ -3,7 +3,7 @@
 summary committed under profiles/: per kernel, mean duration over the overlapped timed region and over
 the strictly serial launches bench.py makes afterwards for the isolated roofline.
 
-    python tools/profile_summary.py <dir with *_kernel_trace.csv> <steps+warmup> > profiles/rNN_kernel_trace_summary.json
+    python tools/profile_summary.py <dir with *_kernel_trace.csv> <steps> > profiles/rNN_kernel_trace_summary.json
 """
 import csv
 import glob
@@ -21,7 +21,7 @@ def short(name):
     return None
 
 
-def main(root, n_overlapped):
+def main(root, n_timed, n_iso=40):
     files = glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)
     rows = defaultdict(list)
     for f in files:
@@ -33,8 +33,12 @@ def main(root, n_overlapped):
     for k, v in rows.items():
         v.sort()
         d = [(e - s) / 1e3 for s, e in v]
-        ov, iso = d[:n_overlapped], d[n_overlapped:]
+        # bench.py ends with n_iso strictly serial launch groups; the n_timed groups before them are the timed
+        # region; everything earlier is clock ramp and warm-up
+        iso = d[-n_iso:] if n_iso else []
+        ov = d[-(n_iso + n_timed):-n_iso] if n_iso else d[-n_timed:]
         out[k] = {"launches": len(d),
+                  "timed_region_launches": len(ov),
                   "overlapped_avg_us": sum(ov) / max(len(ov), 1),
                   "isolated_avg_us": (sum(iso) / len(iso)) if iso else None,
                   "isolated_min_us": min(iso) if iso else None}

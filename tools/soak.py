@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Leak / stability soak: plans, segment sets and the auxiliary kernels created and destroyed in a loop;
+device memory before and after must agree.  python tools/soak.py [iterations]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "impulcifer-pip313_amd"))
+from impulse_hip import _native  # noqa: E402
+
+
+def free_bytes():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipDeviceSynchronize()
+    free, total = C.c_size_t(), C.c_size_t()
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    ctx = _native.default_context()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((4, 60000)).astype(np.float32)
+    h = rng.standard_normal((4, 9600))
+    gain = np.abs(1 + 0.1 * rng.standard_normal((4, 2400)))
+    gain[:, -1] = 0
+    rows = [rng.standard_normal(30000) * np.exp(-np.arange(30000) / 4000.0) for _ in range(4)]
+
+    def once():
+        p = _native.ConvPlan(ctx, h, 60000, "full")
+        y = p.execute(x)
+        p.close()
+        p = _native.ConvPlan(ctx, h[0], 60000, "same")
+        p.execute_interleaved(np.ascontiguousarray(x.T))
+        p.close()
+        s = _native.SegSet(ctx, rows)
+        s.range_means([(i, 0, 1000) for i in range(4)])
+        s.close()
+        ctx.minphase_fir(gain, 48000)
+        ctx.magnitude_db(np.stack(rows))
+        ctx.peak_index(rows)
+        ctx.xcorr_argmax([r[:1440] for r in rows[:2]], [r[:1440] for r in rows[2:]])
+        ctx.decay_times(rows, [0] * 4, [20000] * 4, [-80.0] * 4, [1440] * 4, 48000)
+        return float(y[0, 0])
+
+    for _ in range(10):
+        once()
+    before = free_bytes()
+    for _ in range(iters):
+        once()
+    after = free_bytes()
+    print(f"{iters} iterations: free device memory {before / 2**20:.1f} MiB -> {after / 2**20:.1f} MiB (delta {(before - after) / 2**20:.2f} MiB)")
+    assert before - after < 8 * 2 ** 20, "device memory leak"
+    print("soak ok")
+
+
+if __name__ == "__main__":
+    main()
