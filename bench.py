@@ -203,7 +203,7 @@ def main():
                     help="independent launch groups in flight (imp_plan_set_overlap); 1 = strictly serial kernels")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-ramp", action="store_true", help="skip the 0.25 s clock ramp before the warm-up (profiling runs)")
-    ap.add_argument("--event-stride", type=int, default=8,
+    ap.add_argument("--event-stride", type=int, default=32,
                     help="bracket the three passes of every n-th step with HIP events (sampling keeps the "
                          "event records from perturbing the throughput being measured)")
     args = ap.parse_args()
