@@ -306,7 +306,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    plan.set_timing(0 if args.no_events else args.event_stride)
+    # at least ~8 sampled launch groups however short the run
+    plan.set_timing(0 if args.no_events else max(1, min(args.event_stride, args.steps // 8)))
     plan.get_timing(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
