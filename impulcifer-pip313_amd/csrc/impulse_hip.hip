@@ -1218,6 +1218,49 @@ extern "C" int imp_decay_times(imp_ctx* ctx, const double* x, const int64_t* off
   return IMP_OK;
 }
 
+extern "C" int imp_sosfilt(imp_ctx* ctx, const double* sos, int64_t n_sections, const double* x, const int64_t* off,
+                           const int64_t* len, int64_t B, double* y) {
+  if (!ctx || !sos || (B && (!x || !off || !len || !y))) return fail(IMP_ERR_INVALID, "imp_sosfilt: null argument");
+  IMP_CTX_LOCK(ctx);
+  if (n_sections < 1 || n_sections > 4096) return fail(IMP_ERR_INVALID, "imp_sosfilt: n_sections must be in [1, 4096]");
+  for (int64_t s = 0; s < n_sections; ++s)
+    if (sos[6 * s + 3] != 1.0) return fail(IMP_ERR_INVALID, "imp_sosfilt: section %lld is not normalised (a0 != 1)", (long long)s);
+  if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
+  if (B == 0) return IMP_OK;
+  int64_t total = 0;
+  for (int64_t b = 0; b < B; ++b) {
+    if (off[b] < 0 || len[b] < 0) return fail(IMP_ERR_INVALID, "negative offset/length in row %lld", (long long)b);
+    total = std::max(total, off[b] + len[b]);
+  }
+  if (total == 0) return IMP_OK;
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  hipStream_t st = ctx->stream;
+  const size_t bytes = (size_t)(2 * total + 6 * n_sections) * sizeof(double) + (size_t)(2 * B) * sizeof(int64_t);
+  void* buf = nullptr;
+  if ((rc = ctx_scratch(ctx, bytes, &buf))) return rc;
+  double* d_x = (double*)buf;
+  double* d_y = d_x + total;
+  double* d_sos = d_y + total;
+  int64_t* d_off = (int64_t*)(d_sos + 6 * n_sections);
+  int64_t* d_len = d_off + B;
+  HIP_TRY(hipMemcpyAsync(d_x, x, (size_t)total * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_sos, sos, (size_t)(6 * n_sections) * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_off, off, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_len, len, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, st));
+  // a cascade is its sections applied one after the other: chunks of kMaxSections ping-pong between the buffers
+  for (int64_t s0 = 0; s0 < n_sections; s0 += imp::kMaxSections) {
+    const int ns = (int)std::min<int64_t>(imp::kMaxSections, n_sections - s0);
+    hipLaunchKernelGGL(imp::sosfilt_kernel, dim3((unsigned)B), dim3(64), 0, st, d_sos + 6 * s0, ns, d_x, d_y, d_off, d_len);
+    HIP_TRY(hipGetLastError());
+    std::swap(d_x, d_y);
+  }
+  std::swap(d_x, d_y);                                     // d_y = output of the last chunk
+  HIP_TRY(hipMemcpyAsync(y, d_y, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return IMP_OK;
+}
+
 extern "C" int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_off, const int64_t* a_len,
                                 const double* b, const int64_t* b_off, const int64_t* b_len, int64_t B,
                                 int64_t* arg_out, double* val_out) {

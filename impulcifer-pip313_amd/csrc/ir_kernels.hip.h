@@ -478,4 +478,59 @@ __global__ __launch_bounds__(256) void decay_times_kernel(const double* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K11: cascaded second-order sections, scipy.signal.sosfilt(sos, x) with zero initial state
+// (core/virtual_bass.py:121-176: Butterworth crossover / shelf filters over every response), fp64.
+// SciPy's loop (scipy/signal/_sosfilt.pyx), per sample and section, direct form II transposed:
+//     y  = b0 x + z0 ;  z0 = (b1 x - a1 y) + z1 ;  z1 = b2 x - a2 y ;  x <- y
+// with separately rounded products and sums (the wheels' scalar code has no FMA), reproduced here with
+// contraction switched off for the kernel (the _rn intrinsics alone still fuse under -ffp-contract=fast):
+// results are bit-identical.
+// One wave per row: the lanes load 64 samples at a time, every lane runs the (scalar) recurrence on the
+// broadcast samples, lane i keeps output i, and the block is stored coalesced.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxSections = 8;       // per launch; longer cascades run as consecutive launches (same arithmetic)
+
+__global__ __launch_bounds__(64) void sosfilt_kernel(const double* __restrict__ sos, int n_sections,
+                                                     const double* __restrict__ x, double* __restrict__ y,
+                                                     const int64_t* __restrict__ off, const int64_t* __restrict__ len) {
+#pragma clang fp contract(off)          // products and sums round separately, as in SciPy's scalar loop
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const int64_t n = len[row];
+  const double* xr = x + off[row];
+  double* yr = y + off[row];
+  double b0[kMaxSections], b1[kMaxSections], b2[kMaxSections], a1[kMaxSections], a2[kMaxSections];
+  double z0[kMaxSections], z1[kMaxSections];
+#pragma unroll
+  for (int s = 0; s < kMaxSections; ++s) {
+    const bool on = s < n_sections;
+    b0[s] = on ? sos[6 * s + 0] : 1.0;
+    b1[s] = on ? sos[6 * s + 1] : 0.0;
+    b2[s] = on ? sos[6 * s + 2] : 0.0;
+    a1[s] = on ? sos[6 * s + 4] : 0.0;
+    a2[s] = on ? sos[6 * s + 5] : 0.0;
+    z0[s] = 0.0;
+    z1[s] = 0.0;
+  }
+  for (int64_t base = 0; base < n; base += 64) {
+    const double xv = (base + lane < n) ? xr[base + lane] : 0.0;
+    double yv = 0.0;
+    const int cnt = (n - base < 64) ? (int)(n - base) : 64;
+    for (int i = 0; i < cnt; ++i) {
+      double cur = __shfl(xv, i, 64);
+#pragma unroll
+      for (int s = 0; s < kMaxSections; ++s) {          // compile-time indices keep the state in registers
+        if (s < n_sections) {
+          const double out = b0[s] * cur + z0[s];
+          z0[s] = (b1[s] * cur - a1[s] * out) + z1[s];
+          z1[s] = b2[s] * cur - a2[s] * out;
+          cur = out;
+        }
+      }
+      if (lane == i) yv = cur;
+    }
+    if (base + lane < n) yr[base + lane] = yv;
+  }
+}
+
 }  // namespace imp

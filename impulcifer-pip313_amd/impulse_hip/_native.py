@@ -82,6 +82,7 @@ SIGNATURES = {
     "imp_segset_range_means": (C.c_int, [_vp, _pi64, _pi64, _pi64, _i64, _pd]),
     "imp_segset_destroy": (None, [_vp]),
     "imp_decay_times": (C.c_int, [_vp, _pd, _pi64, _pi64, _i64, _pi64, _pi64, _pd, _pi64, C.c_double, _pd]),
+    "imp_sosfilt": (C.c_int, [_vp, _pd, _i64, _pd, _pi64, _pi64, _i64, _pd]),
     "imp_xcorr_argmax": (C.c_int, [_vp, _pd, _pi64, _pi64, _pd, _pi64, _pi64, _i64, _pi64, _pd]),
     "imp_minphase_fir": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, _pd]),
     "imp_magnitude_db": (C.c_int, [_vp, _pd, _i64, _i64, _pd]),
@@ -262,6 +263,22 @@ class Context:
                                          _ptr_i64(pk), _ptr_i64(kn), nf.ctypes.data_as(_pd), _ptr_i64(ws),
                                          float(fs), out.ctypes.data_as(_pd)))
         return out
+
+    def sosfilt(self, sos, rows):
+        """scipy.signal.sosfilt(sos, row) for every row (fp64 on the device, bit-identical). Returns a list."""
+        sos = np.ascontiguousarray(sos, dtype=np.float64).reshape(-1, 6)
+        rows = [np.ascontiguousarray(r, dtype=np.float64).ravel() for r in rows]
+        B = len(rows)
+        if B == 0:
+            return []
+        lens = np.array([len(r) for r in rows], dtype=np.int64)
+        offs = np.zeros(B, dtype=np.int64)
+        offs[1:] = np.cumsum(lens)[:-1]
+        flat = np.concatenate(rows) if lens.sum() else np.zeros(1)
+        out = np.zeros_like(flat)
+        _check(self._lib.imp_sosfilt(self._h, sos.ctypes.data_as(_pd), len(sos), flat.ctypes.data_as(_pd), _ptr_i64(offs),
+                                     _ptr_i64(lens), B, out.ctypes.data_as(_pd)))
+        return [out[o:o + n].copy() for o, n in zip(offs, lens)]
 
     def xcorr_argmax(self, a_rows, b_rows):
         """np.argmax(scipy.signal.correlate(a, b, "full")) for every pair (fp64 on the device).

@@ -170,6 +170,15 @@ int imp_decay_times(imp_ctx* ctx, const double* x, const int64_t* off, const int
                     const int64_t* peak, const int64_t* knee, const double* noise_floor, const int64_t* window,
                     double fs, double* out);
 
+/* ---- K11: cascaded second-order sections -------------------------------------------------------
+ * core/virtual_bass.py:121-176: scipy.signal.sosfilt(sos, x) (zero initial state) over every response.
+ * sos: host [n_sections][6] = b0 b1 b2 a0 a1 a2 with a0 = 1 (SciPy's layout);
+ * x: host fp64, B rows at x + off[b] (len[b] samples); y: host, same layout (may alias x).
+ * fp64 with SciPy's operation order and no fused multiply-adds: bit-identical to scipy.signal.sosfilt.
+ */
+int imp_sosfilt(imp_ctx* ctx, const double* sos, int64_t n_sections, const double* x, const int64_t* off,
+                const int64_t* len, int64_t B, double* y);
+
 /* ---- K10: lag search of the ipsilateral alignment ----------------------------------------------
  * core/hrir.py:934-937 and :946-949 (HRIR.align_ipsilateral_all):
  *     corr = scipy.signal.correlate(a, b, mode="full"); lag = arange(-len(a)+1, len(a))[argmax(corr)]

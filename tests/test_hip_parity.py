@@ -1255,3 +1255,36 @@ def test_overlap_add_beyond_one_transform(gpu_ctx, L, M, mode):
         assert rel(y[b], ref) <= 2 * TIME_TOL, (L, M, mode)           # sums of up to four fp32 pieces
     if yi is not None:
         assert np.array_equal(yi, y)
+
+
+def test_k11_sosfilt_bits_and_virtual_bass(gpu_ctx, golden):
+    """K11 (imp_sosfilt) reproduces scipy.signal.sosfilt bit for bit (golden outputs from the reference run,
+    SciPy itself on ragged rows and long cascades), and the virtual-bass synthesis built on it matches the
+    reference's synthesize_virtual_bass on the seeded FL/FR/FC set."""
+    from scipy import signal
+    from make_goldens import balance_inputs
+    from impulse_hip.impulse_response import ImpulseResponse
+    from impulse_hip.virtual_bass import synthesize_virtual_bass
+    g = golden("virtual_bass")
+    x = g["sosfilt_in"]
+    got = gpu_ctx.sosfilt(g["sos_hp8_250"], list(x))
+    np.testing.assert_array_equal(np.stack(got), g["sosfilt_hp8"])
+    got = gpu_ctx.sosfilt(g["sos_lp8_250"], gpu_ctx.sosfilt(g["sos_hp4_15"], list(x)))
+    np.testing.assert_array_equal(np.stack(got), g["sosfilt_lp8_of_hp4"])
+    rng = np.random.default_rng(11)
+    rows = [rng.standard_normal(n) for n in (1, 63, 64, 65, 1000, 33000)]
+    for order in (2, 6, 22):                                        # 1, 3 and 11 sections (two launches)
+        sos = signal.butter(order, 0.2, btype="low", output="sos")
+        got = gpu_ctx.sosfilt(sos, rows)
+        for r, y in zip(rows, got):
+            np.testing.assert_array_equal(y, signal.sosfilt(sos, r))
+    with pytest.raises(Exception):
+        gpu_ctx.sosfilt(np.array([[1.0, 0, 0, 2.0, 0, 0]]), rows[:1])       # a0 != 1
+    for name, kw in (("default", {}), ("inverted_300", dict(crossover_freq=300, invert_polarity=True, head_ms=1.5))):
+        irs = {sp: {sd: ImpulseResponse(v.astype(np.float64), 48000) for sd, v in pair.items()}
+               for sp, pair in balance_inputs(4096).items()}
+        synthesize_virtual_bass(irs, 48000, **kw)
+        for sp in irs:
+            for sd in ("left", "right"):
+                want = g[f"vb_{name}_{sp}_{sd}"]
+                np.testing.assert_allclose(irs[sp][sd].data, want, rtol=0, atol=1e-13 * np.max(np.abs(want)))

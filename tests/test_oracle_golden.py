@@ -346,3 +346,13 @@ def test_ipsilateral_alignment(golden):
     a[60] = 1.0
     b[67] = 1.0
     assert abs(ohrir.ipsilateral_lag(a, b, 1440)) == 7
+
+
+def test_sosfilt_restatement(golden):
+    """oracle.virtual_bass.sosfilt against scipy.signal.sosfilt outputs captured in the reference run
+    (fixture section 12): the same separately rounded operations, so the same bits."""
+    from oracle import virtual_bass as ovb
+    g = golden("virtual_bass")
+    x = g["sosfilt_in"]
+    np.testing.assert_array_equal(ovb.sosfilt(g["sos_hp8_250"], x), g["sosfilt_hp8"])
+    np.testing.assert_array_equal(ovb.sosfilt(g["sos_lp8_250"], ovb.sosfilt(g["sos_hp4_15"], x)), g["sosfilt_lp8_of_hp4"])
