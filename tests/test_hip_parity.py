@@ -145,7 +145,7 @@ def test_conv_many_channels_cross_workspace_groups(gpu_ctx):
 def test_conv_error_paths(gpu_ctx):
     from impulse_hip import ConvPlan, NativeError
     with pytest.raises(NativeError):
-        ConvPlan(gpu_ctx, np.ones(4), 3_000_000, "same")         # nfft > 2^21: unsupported, loud
+        ConvPlan(gpu_ctx, np.ones(4), 1 << 29, "same")           # beyond one channel's 32-bit buffer range: loud
     p = ConvPlan(gpu_ctx, np.ones(4), 100, "same")
     with pytest.raises(ValueError):
         p.execute(np.zeros((2, 99), np.float32))
