@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "impulcifer-pip313_amd"))
 sys.path.insert(0, ROOT)
 
+PITCH_ALIGN = int(os.environ.get("IMPULSE_BENCH_PITCH_ALIGN", "64"))     # samples
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 METRIC = "impulse responses/sec (sweep deconv+FIR), 7.1×2-ear @48kHz, 1/2/4/8 GPU"
 
@@ -64,10 +65,12 @@ def make_estimator(workload):
 
 def synth_recordings(est, n_channels, seed0, column=None):
     """SURVEY 8(d) recipe: per channel a sparse-tap room (direct sound at 64+37c, three later
-    taps) excited by the sweep, plus -70 dBFS noise; fp32, pitch padded to an even length."""
+    taps) excited by the sweep, plus -70 dBFS noise; fp32, row pitch padded to a multiple of 64 samples (256 B:
+    every channel then starts on a cache-line boundary; an odd pitch makes each 512-byte wave access straddle
+    an extra 128-byte line, +25 % input lines fetched)."""
     N, fs = len(est), est.fs
     L = N + 2 * fs if column is None else column
-    pitch = (L + 1) & ~1
+    pitch = (L + PITCH_ALIGN - 1) // PITCH_ALIGN * PITCH_ALIGN
     sweep = est.test_signal.astype(np.float32)
     rec = np.zeros((n_channels, pitch), dtype=np.float32)
     delays = []
@@ -279,7 +282,11 @@ def main():
     lanes = max(1, min(args.lanes, 4, plan.ws_channels))
     plan.set_overlap(lanes)
     n_out = lanes
-    d_ys = [torch.empty((B, pitch), dtype=torch.float32, device=device) for _ in range(n_out)]
+    # output rows: same pitch; the first sample of a row is placed so that the crop offset of the 'same' window
+    # lands the stores on 128-byte lines (the caller chooses where results go: here (M-1)/2 mod 32 samples in)
+    skew = ((M - 1) // 2) % 32 if os.environ.get("IMPULSE_BENCH_OUT_SKEW", "1") == "1" else 0
+    d_ybufs = [torch.empty(B * pitch + 64, dtype=torch.float32, device=device) for _ in range(n_out)]
+    d_ys = [b[skew: skew + B * pitch].view(B, pitch) for b in d_ybufs]
     d_y = d_ys[0]
     torch.cuda.synchronize(device)
     step_no = [0]
@@ -414,6 +421,8 @@ def main():
             "config": {"workload": desc, "stage": "K1 batched sweep deconvolution incl. 'same' crop "
                        "(inverse-filter spectrum prepared once, outside the timed region)",
                        "channels_per_gpu_per_step": B, "sweep_samples": M, "column_samples": L,
+                       "layout": f"planar fp32, row pitch {pitch} samples (multiple of {PITCH_ALIGN}); output rows start "
+                                 f"{skew} samples into 256-byte aligned buffers so the cropped stores fall on cache lines",
                        "nfft": plan.nfft, "launch_groups_in_flight": lanes, "sharding": f"channels x{world}, no data-path collective; "
                        f"one {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} broadcast of "
                        f"{bcast_bytes} B spectrum at plan creation"},
@@ -422,7 +431,7 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
     plan.close()
-    del d_x, d_y, d_ys
+    del d_x, d_y, d_ys, d_ybufs
     ctx.close()
     if dist is not None:
         dist.barrier()
