@@ -12,7 +12,7 @@
 //                                (W = alpha Z[k] + beta conj Z[Nc-k]) -> row IFFT, in place
 //   pass C  cols_kernel<inv>   : x conj w_Nc^(n2 k1), column IFFTs, unpack + crop     -> out
 // The spectrum never leaves the transposed [k1][k2] order, so there is no transpose pass.
-// No MFMA: the work is butterflies (VALU) + LDS exchanges; the bound is HBM/MALL traffic.
+// No MFMA: the work is butterflies (VALU) + LDS exchanges; the bound is the bytes moved across the L2 boundary.
 #pragma once
 #include "fft_regs.hip.h"
 

@@ -208,7 +208,7 @@ __host__ __device__ __forceinline__ void fft_groups(cf (&v)[16]) {
 
 
 // ---------------------------------------------------------------------------------------------
-// Odd radices for the mixed column lengths N1 = 16*R2, R2 in {3, 5, 6, 10, 12}.
+// Odd radices for the mixed column lengths N1 = F*R2, R2 in {3, 5, 6, 9, 10, 12}.
 // 6, 10 and 12 use the prime-factor (Good-Thomas) mapping: no twiddles between the two factors.
 // ---------------------------------------------------------------------------------------------
 template <int DIR>

@@ -1,7 +1,7 @@
 """NumPy model of the device dataflow used by the HIP deconvolution kernels.
 
 This is NOT the oracle and NOT a product path: it mirrors, thread for thread,
-the index/twiddle algebra of csrc/deconv_kernels.hip (pass A column FFT,
+the index/twiddle algebra of csrc/conv_kernels.hip.h (pass A column FFT,
 pass B fused row FFT * spectrum * row IFFT, pass C column IFFT + crop) so the
 algebra can be unit-tested on a CPU-only box.  All arithmetic is float64 here;
 the kernels do the same steps in fp32.
