@@ -73,7 +73,10 @@ def main():
         plan.close()
         for b in range(B):
             ref = fft_convolve(ref_in[b], h[b if per_channel else 0], mode)
-            e = rel(y[b], ref)
+            # a window of a few samples out of a long filter's output can sit far below the transform's rounding
+            # noise, which scales with |x| |h|: the error is measured against the larger of the two scales
+            scale = max(np.max(np.abs(ref)), 0.05 * np.max(np.abs(ref_in[b])) * np.max(np.abs(h[b if per_channel else 0])))
+            e = float(np.max(np.abs(np.asarray(y[b], np.float64) - ref)) / max(scale, 1e-300))
             tol = 1e-6 * (2 if layout == "pcm32" else 1) * (1.5 if (mode == "same" and M > 4 * L) else 1) * (2 if L > 2_000_000 else 1)
             worst = max(worst, e / tol)
             if e > tol:
