@@ -36,11 +36,12 @@ WORKLOADS = {
     # c5: channels in TOTAL, sharded over the ranks (strong scaling)
     "c2": (48000, 5.0, 16, "C2: 7.1 layout (8 spk x 2 ear = 16 IRs), 6.15 s ESS sweep @48 kHz"),
     "c3": (96000, 5.0, 26, "C3: 13-ch TrueHD layout x 2 ear @96 kHz (deconvolution stage only)"),
+    "c4": (48000, None, 256, "C4: synthetic 256-channel batch, 2^20-sample sweeps @48 kHz, channel-sharded"),
     "c5": (48000, None, 1024, "C5: synthetic 1024-channel batch, 2^20-sample sweeps @48 kHz, channel-sharded"),
 }
 # channels per launch group when groups overlap on 3 lanes (measured sweeps): the
 # groups in flight together must still fit the 256 MiB Infinity Cache with their inputs and outputs
-GROUP_CHANNELS = {"c2": 16, "c3": 9, "c5": 8}
+GROUP_CHANNELS = {"c2": 16, "c3": 9, "c4": 8, "c5": 8}
 
 
 def make_estimator(workload):
@@ -251,7 +252,7 @@ def main():
 
     fs, dur, B, desc = WORKLOADS[args.workload]
     est = make_estimator(args.workload)
-    strong = args.workload == "c5"
+    strong = args.workload in ("c4", "c5")
     if strong:
         lo, hi = shard_channels(B, world, rank)
         total_channels, B = B, hi - lo
