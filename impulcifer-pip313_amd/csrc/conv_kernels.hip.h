@@ -130,8 +130,8 @@ struct LoadRealPacked {
 #pragma unroll
       for (int j = 0; j < F; ++j) {
         const unsigned so = 2u * (unsigned)(j * STEP) * es;
-        v[j].x = bload_f(r, vo, so);
-        v[j].y = bload_f(r, vo, so + es);
+        v[j].x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, kStreamAux));
+        v[j].y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vo, so + es, kStreamAux));
       }
     }
   }
@@ -153,8 +153,8 @@ struct LoadPcmPacked {
     return LoadPcmPacked{base + first * elem_stride, chan_stride, elem_stride, rest < maxlen ? rest : maxlen, scale};
   }
   __device__ __forceinline__ float sample(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) const {
-    if constexpr (sizeof(Sample) == 2) return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(r, vo, so, 0) * scale;
-    else return (float)(int)__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0) * scale;
+    if constexpr (sizeof(Sample) == 2) return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(r, vo, so, kStreamAux) * scale;
+    else return (float)(int)__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, kStreamAux) * scale;
   }
   template <int STEP, int F>
   __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[F]) const {
