@@ -53,6 +53,11 @@ def pass_a(x, nfft):
     xp = np.zeros(nfft)
     xp[: len(x)] = x
     z = (xp[0::2] + 1j * xp[1::2]).reshape(N1, N2)          # [n1][n2]
+    if N1 % 16:
+        # N1 = 8*R2 shapes (24, 40, 72): the staging differs (8 rows per thread) but the result is the same
+        # column DFT times the four-step twiddle, whatever the factorisation
+        k1 = np.arange(N1)[:, None]
+        return np.fft.fft(z, axis=0) * w(np.arange(N2)[None, :], k1, Nc)
     ws = np.zeros((N1, N2), complex)
     g = np.arange(R2)
     for c in range(0, N2, 1024):                              # model a few columns vectorised

@@ -1292,21 +1292,22 @@ def test_k11_sosfilt_bits_and_virtual_bass(gpu_ctx, golden):
 
 def test_workspace_after_each_pass_matches_the_dataflow_model(gpu_ctx):
     """imp_plan_debug_run_stage: the workspace after pass A and after pass B against the NumPy dataflow model
-    (tests/model/fourstep_model.py, the thread-for-thread algebra of the kernels) at N1 = 48."""
+    (tests/model/fourstep_model.py, the thread-for-thread algebra of the kernels) at N1 = 48 (16 rows per
+    thread, radix 3) and N1 = 72 (8 rows per thread, radix 9: the C2 plan)."""
     import fourstep_model as fm
     from impulse_hip import ConvPlan
     rng = np.random.default_rng(48)
-    L, M = 300000, 150000
-    x = rng.standard_normal((2, L)).astype(np.float32)
-    h = rng.standard_normal(M) * np.exp(-np.arange(M) / 30000.0)
-    plan = ConvPlan(gpu_ctx, h, L, "same")
-    assert plan.n1 == 48
-    ws_a = plan.debug_stage(x, 0)
-    ws_b = plan.debug_stage(x, 1)
-    plan.close()
-    alpha, beta = fm.plan_alpha_beta(h, plan.nfft)
-    for b in range(2):
-        want_a = fm.pass_a(x[b].astype(np.float64), plan.nfft)
-        assert np.max(np.abs(ws_a[b] - want_a)) / np.max(np.abs(want_a)) <= 2e-6
-        want_b = fm.pass_b(want_a, alpha, beta)
-        assert np.max(np.abs(ws_b[b] - want_b)) / np.max(np.abs(want_b)) <= 3e-6
+    for L, M, n1 in ((300000, 150000, 48), (391270, 295270, 72)):
+        x = rng.standard_normal((2, L)).astype(np.float32)
+        h = rng.standard_normal(M) * np.exp(-np.arange(M) / 30000.0)
+        plan = ConvPlan(gpu_ctx, h, L, "same")
+        assert plan.n1 == n1
+        ws_a = plan.debug_stage(x, 0)
+        ws_b = plan.debug_stage(x, 1)
+        plan.close()
+        alpha, beta = fm.plan_alpha_beta(h, plan.nfft)
+        for b in range(2):
+            want_a = fm.pass_a(x[b].astype(np.float64), plan.nfft)
+            assert np.max(np.abs(ws_a[b] - want_a)) / np.max(np.abs(want_a)) <= 2e-6
+            want_b = fm.pass_b(want_a, alpha, beta)
+            assert np.max(np.abs(ws_b[b] - want_b)) / np.max(np.abs(want_b)) <= 3e-6
