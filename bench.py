@@ -433,9 +433,10 @@ def main():
                        "input_sets_in_rotation": n_sets,
                        "layout": f"planar fp32, row pitch {pitch} samples (multiple of {PITCH_ALIGN}); output rows start "
                                  f"{skew} samples into 256-byte aligned buffers so the cropped stores fall on cache lines",
-                       "nfft": plan.nfft, "launch_groups_in_flight": lanes, "sharding": f"channels x{world}, no data-path collective; "
-                       f"one {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} broadcast of "
-                       f"{bcast_bytes} B spectrum at plan creation"},
+                       "nfft": plan.nfft, "launch_groups_in_flight": lanes, "sharding": (f"channels x{world}, no data-path collective; "
+                                    f"one {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} broadcast of "
+                                    f"{bcast_bytes} B spectrum at plan creation") if dist is not None else
+                                   "single rank: no collective"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "slice": whole_slice,
         }
         sys.stdout.flush()
