@@ -1311,3 +1311,32 @@ def test_workspace_after_each_pass_matches_the_dataflow_model(gpu_ctx):
             assert np.max(np.abs(ws_a[b] - want_a)) / np.max(np.abs(want_a)) <= 2e-6
             want_b = fm.pass_b(want_a, alpha, beta)
             assert np.max(np.abs(ws_b[b] - want_b)) / np.max(np.abs(want_b)) <= 3e-6
+
+
+def test_bench_contract_line(gpu_ctx):
+    """bench.py prints exactly one JSON line on stdout with the contract's keys, BASELINE.json's metric, a
+    roofline block and (at N = 1) a cpu_baseline block; everything else goes to stderr."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "40", "--warmup", "4"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    base = json.load(open(os.path.join(root, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["unit"] == "IR/s"
+    for key in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"], d["higher_is_better"]) == (1, 40, 4, "weak", True)
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["sample"]
+    assert d["parity"]["peak_indices_exact"] and d["parity"]["spectrum_max_rel_err"] <= 1e-6
+    assert d["value"] > 100 * c["value"]
