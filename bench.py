@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
 """bench.py - IRs/s of the batched ESS deconvolution on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N ranks (child torchrun)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path over one batch: every rank deconvolves one 7.1 x 2-ear
-measurement (BASELINE.json configs[1], "C2": 16 channels, 6.15 s sweep @48 kHz, column
-L = N + 2 fs = 391 270) that is already resident in HBM.  Channels shard across ranks with no
-data-path collective ("weak" scaling: one measurement per GPU per step); the only collective is
-the one-off RCCL broadcast of the prepared inverse-sweep spectrum from rank 0.
+One STEP = one pass of the hot path (K1: deconvolution incl. the 'same' crop) over every input set in
+rotation: at the default workload (BASELINE.json configs[1], "C2": 7.1 x 2 ears = 16 channels, 6.15 s sweep
+@48 kHz, column L = N + 2 fs = 391 270) that is 40 measurements = 640 IRs per GPU per step, all resident in
+HBM before the clock starts (1 GiB of inputs, so no input line survives in the 256 MiB Infinity Cache between
+two uses).  Channels shard across ranks with no data-path collective ("weak": one such stream of measurements
+per GPU); the only collective is the one-off RCCL broadcast of the prepared inverse-sweep spectrum.
 
-The JSON line carries `roofline` (HIP-event time of the dominant kernel over the timed steps,
-priced in ALGORITHMIC bytes 8*L per IR) and `cpu_baseline` (the NumPy oracle of the reference's
+With N > 1 (or --strong) the line also carries `strong_c5`: BASELINE.json configs[4] (1024 channels x 2^20
+samples) sharded over the ranks, its IR/s, and the speed-up over rank 0 doing all 1024 channels alone in the
+same run (north_star's strong-scaling figure).
+
+The JSON line carries `roofline` (HIP-event time of the dominant kernel over the timed steps, priced in
+ALGORITHMIC bytes 8*L per IR) and `cpu_baseline` (the NumPy oracle of the reference's
 scipy.signal.convolve(x, inverse_filter, 'same') timed on this box's host cores, rank 0, N=1).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,8 +38,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 METRIC = "impulse responses/sec (sweep deconv+FIR), 7.1×2-ear @48kHz, 1/2/4/8 GPU"
 
 WORKLOADS = {
-    # name: (fs, min_duration, channels, description); c2/c3: channels PER RANK per step (weak scaling),
-    # c5: channels in TOTAL, sharded over the ranks (strong scaling)
+    # name: (fs, min_duration, channels, description); c2/c3: channels PER RANK per measurement (weak scaling),
+    # c4/c5: channels in TOTAL, sharded over the ranks (strong scaling)
     "c2": (48000, 5.0, 16, "C2: 7.1 layout (8 spk x 2 ear = 16 IRs), 6.15 s ESS sweep @48 kHz"),
     "c3": (96000, 5.0, 26, "C3: 13-ch TrueHD layout x 2 ear @96 kHz (deconvolution stage only)"),
     "c4": (48000, None, 256, "C4: synthetic 256-channel batch, 2^20-sample sweeps @48 kHz, channel-sharded"),
@@ -42,6 +48,66 @@ WORKLOADS = {
 # channels per launch group when groups overlap on 3 lanes (measured sweeps): the
 # groups in flight together must still fit the 256 MiB Infinity Cache with their inputs and outputs
 GROUP_CHANNELS = {"c2": 16, "c3": 9, "c4": 8, "c5": 8}
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ws-channels", type=int, default=0,
+                    help="workspace size in channels (0 = lanes x the per-workload group size)")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="independent launch groups in flight (imp_plan_set_overlap); 1 = strictly serial kernels")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--event-stride", type=int, default=32,
+                    help="bracket the passes of every n-th launch group with HIP events (sampling keeps the "
+                         "event records from perturbing the throughput being measured)")
+    ap.add_argument("--input-sets", type=int, default=0,
+                    help="input batches in rotation = measurements per step (0: enough for 1 GiB, at most 40)")
+    ap.add_argument("--strong", action="store_true", help="add the strong_c5 block at N = 1 too")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong_c5 block at N > 1")
+    ap.add_argument("--strong-channels", type=int, default=1024)
+    ap.add_argument("--strong-passes", type=int, default=4)
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launcher/collective rehearsal WITHOUT a GPU: ranks rendezvous over gloo, shard, broadcast "
+                         "a dummy spectrum and reduce a clock; no compute, value = null (CPU test of the N > 1 plumbing)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------
+# N > 1 invoked plainly: start the ranks as a CHILD torchrun before this process touches HIP or torch.cuda
+# (a process that has initialised the GPU must never exec/replace itself on this pool).
+# ------------------------------------------------------------------------------------------------------
+def spawn_ranks(args, argv):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in proc.stdout.decode("utf-8", "replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            line = ln
+        elif ln:
+            sys.stderr.write(ln + "\n")
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    if proc.returncode != 0:
+        raise SystemExit(proc.returncode)
+    if line is None:
+        raise SystemExit("the ranks exited 0 but rank 0 printed no JSON line")
+    return 0
 
 
 def make_estimator(workload):
@@ -171,46 +237,225 @@ def fp32_fft_floor(est, x, L):
     return float(np.max(np.abs(A - R)) / np.max(R))
 
 
-def load_traffic_profile(workload):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary
-    (profiles/), or None.  bench.py cannot collect PMC counters itself."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh).get(workload, {}).get("rows_kernel_bytes_per_launch")
-    except (OSError, ValueError):
+def demo_column_error():
+    """Whole-column magnitude-spectrum error of THIS path on the one real recording column that ships as a
+    fixture (tests/golden/demo_fc.npz: the reference's data/demo/FC.wav, left track, after the 2 s lead) against the
+    oracle in float64.  Peak normalised, like every spectrum figure here."""
+    path = os.path.join(ROOT, "tests", "golden", "demo_fc.npz")
+    if not os.path.exists(path):
         return None
-
-
-def load_path_traffic(workload):
-    """Bytes all three kernels of one launch group move across the L2 boundary (rocprofv3 FETCH_SIZE / WRITE_SIZE,
-    profiles/pmc_traffic.json), or None."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            t = json.load(fh).get(workload, {})
-        return sum(t[k] for k in ("rows_kernel_bytes_per_launch", "cols_fwd_bytes_per_launch", "cols_inv_bytes_per_launch"))
-    except (OSError, ValueError, KeyError):
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from oracle.estimator import estimate
+    z = np.load(path)
+    key = "column_i32" if "column_i32" in z.files else None
+    if key is None:
         return None
+    col = z[key].astype(np.float64) / 2.0 ** 31
+    est = ImpulseResponseEstimator(min_duration=5.0, fs=48000)
+    y = est.estimate_batch(col[None, :].astype(np.float32))[0].astype(np.float64)
+    ref = estimate(col.astype(np.float32).astype(np.float64), np.asarray(est.inverse_filter, dtype=np.float64))
+    A, R = np.abs(np.fft.rfft(y)), np.abs(np.fft.rfft(ref))
+    pk = int(np.argmax(np.abs(ref)))
+    sl = slice(pk - 48, pk - 48 + int(0.68 * 48000))
+    Ac, Rc = np.abs(np.fft.rfft(y[sl])), np.abs(np.fft.rfft(ref[sl]))
+    return dict(whole_column_spectrum_max_rel_err=float(np.max(np.abs(A - R)) / np.max(R)),
+                cropped_spectrum_max_rel_err=float(np.max(np.abs(Ac - Rc)) / np.max(Rc)),
+                peak_index_equal=bool(int(np.argmax(np.abs(y))) == pk), samples=int(len(col)),
+                source="tests/golden/demo_fc.npz (reference data/demo/FC.wav, left track, column 0)")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ws-channels", type=int, default=0,
-                    help="workspace size in channels (0 = lanes x the per-workload group size)")
-    ap.add_argument("--lanes", type=int, default=3,
-                    help="independent launch groups in flight (imp_plan_set_overlap); 1 = strictly serial kernels")
-    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
-    ap.add_argument("--no-ramp", action="store_true", help="skip the 0.25 s clock ramp before the warm-up (profiling runs)")
-    ap.add_argument("--event-stride", type=int, default=32,
-                    help="bracket the three passes of every n-th step with HIP events (sampling keeps the "
-                         "event records from perturbing the throughput being measured)")
-    args = ap.parse_args()
+def load_profile_traffic(workload):
+    """L2<->fabric bytes per launch from the committed rocprofv3 --pmc summary of this command (profiles/), or
+    None.  bench.py cannot collect PMC counters itself; the figure is from an EARLIER profiled run and says so."""
+    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as fh:
+                t = json.load(fh).get(workload)
+        except (OSError, ValueError):
+            continue
+        if t:
+            return t, "profiles/" + name
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+def rehearse_launch(args, rank, world):
+    """CPU rehearsal of the N > 1 plumbing (no GPU, no compute): rendezvous, sharding, the spectrum broadcast
+    helper on dummy bytes, the MAX clock reduction, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    from impulse_hip.sharding import broadcast_bytes, shard_channels
+    dist.init_process_group("gloo")
+    want = torch.from_numpy(np.random.default_rng(7).integers(0, 255, 1 << 16, dtype=np.uint8))
+    buf = want.clone() if rank == 0 else torch.zeros_like(want)
+    broadcast_bytes(buf, dist, src=0)
+    ok = bool(torch.equal(buf, want))
+    lo, hi = shard_channels(args.strong_channels, world, rank)
+    spans = [None] * world
+    dist.all_gather_object(spans, (lo, hi))
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    dist.barrier()
+    if rank == 0:
+        tiled = spans[0][0] == 0 and spans[-1][1] == args.strong_channels and all(
+            spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        line = {"metric": METRIC, "value": None, "unit": "IR/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "rehearsal": "launcher + collectives over gloo, no GPU, no compute",
+                "ranks_seen": dist.get_world_size(), "broadcast_ok": bool(flag.item()), "shards_tile": bool(tiled),
+                "max_clock_s": float(t.item()), "strong_c5": {"channels": args.strong_channels, "shards": spans}}
+        sys.stdout.write(json.dumps(line) + "\n")
+        sys.stdout.flush()
+    dist.destroy_process_group()
+    return 0
+
+
+class DeviceBatch:
+    """A workload resident in HBM: plan, rotating input sets, per-lane output buffers (torch = device memory
+    plumbing only)."""
+
+    def __init__(self, torch, device, ctx, plan, rec, L, pitch, M, lanes, n_sets):
+        self.torch, self.device, self.ctx, self.plan = torch, device, ctx, plan
+        self.B, self.L, self.pitch, self.M = rec.shape[0], L, pitch, M
+        self.lanes = max(1, min(lanes, 4, plan.ws_channels))
+        plan.set_overlap(self.lanes)
+        d_x = torch.from_numpy(rec).to(device)
+        self.d_xs = [d_x] + [d_x.clone() for _ in range(n_sets - 1)]
+        # output rows: same pitch; the first sample of a row is placed so that the crop offset of the 'same' window
+        # lands the stores on 128-byte lines (the caller chooses where results go: here (M-1)/2 mod 32 samples in)
+        self.skew = ((M - 1) // 2) % 32 if os.environ.get("IMPULSE_BENCH_OUT_SKEW", "1") == "1" else 0
+        # overlapped launch groups must not write the same memory: one output buffer per lane, used round robin
+        self.d_ybufs = [torch.empty(self.B * pitch + 64, dtype=torch.float32, device=device) for _ in range(self.lanes)]
+        self.d_ys = [b[self.skew: self.skew + self.B * pitch].view(self.B, pitch) for b in self.d_ybufs]
+        self.n = 0
+        torch.cuda.synchronize(device)
+
+    def measurement(self):
+        """one launch-group sequence over one input set (B channels)"""
+        out = self.d_ys[self.n % len(self.d_ys)]
+        src = self.d_xs[self.n % len(self.d_xs)]
+        self.n += 1
+        self.plan.execute_device(src.data_ptr(), self.B, self.pitch, out.data_ptr(), self.pitch)
+
+    def step(self):
+        for _ in range(len(self.d_xs)):
+            self.measurement()
+
+    def sync(self):
+        self.ctx.synchronize()
+        self.torch.cuda.synchronize(self.device)
+
+    def outputs(self):
+        return [b.cpu().numpy()[:, :self.L] for b in self.d_ys]
+
+    def release(self):
+        self.plan.close()
+        self.d_xs = self.d_ys = self.d_ybufs = None
+
+
+def strong_block(args, torch, dist, device, comm_device, ctx, rank, world, backend):
+    """BASELINE.json configs[4]: 1024 channels x 2^20 samples sharded over the ranks (strong scaling), then rank 0
+    alone over all of them for the single-GPU figure of the same run."""
+    from impulse_hip import ConvPlan
+    from impulse_hip.sharding import broadcast_plan_spectrum, shard_channels
+    total = args.strong_channels
+    est = make_estimator("c5")
+    M = len(est)
+    grp = GROUP_CHANNELS["c5"]
+    lanes = max(1, min(args.lanes, 4))
+    if rank == 0:
+        plan = ConvPlan(ctx, np.asarray(est.inverse_filter, dtype=np.float64), M, "same", ws_channels=lanes * grp)
+    else:
+        plan = ConvPlan(ctx, None, M, "same", ws_channels=lanes * grp, empty_M=M, n_filters=1)
+    bcast = 0
+    if dist is not None:
+        bcast = broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0, via_host=(backend != "nccl"))
+    base, L, pitch, dl = synth_recordings(est, 64, seed0=0xC5, column=M)
+    d_base = torch.from_numpy(base).to(device)
+
+    def timed(lo, hi, everyone):
+        n = hi - lo
+        reps = -(-n // 64)
+        # channel c of the 1024-channel batch is recording c % 64 (tiled on the device)
+        d_x = torch.roll(d_base, -(lo % 64), 0).repeat(reps, 1)[:n].contiguous()
+        skew = ((M - 1) // 2) % 32
+        d_ybuf = torch.empty(n * pitch + 64, dtype=torch.float32, device=device)
+        d_y = d_ybuf[skew: skew + n * pitch].view(n, pitch)
+
+        def one_pass():
+            plan.execute_device(d_x.data_ptr(), n, pitch, d_y.data_ptr(), pitch)
+
+        one_pass()
+        ctx.synchronize()
+        torch.cuda.synchronize(device)
+        if everyone and dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.strong_passes):
+            one_pass()
+        ctx.synchronize()
+        torch.cuda.synchronize(device)
+        el = time.perf_counter() - t0
+        if everyone and dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        # parity: every channel's peak where the analytic truth puts it (sampled rows come to the host)
+        rows = sorted(set(list(range(0, n, max(1, n // 16))) + [n - 1]))
+        y = d_y[rows].cpu().numpy()[:, :L]
+        ok = all(int(np.argmax(np.abs(y[i]))) == M // 2 + dl[(lo + r) % 64] for i, r in enumerate(rows))
+        # tiles bit-equal their twins (same recording 64 channels apart -> same bits whatever launch group / lane)
+        if n > 64:
+            ok &= bool(torch.equal(d_y[:n - 64, :L], d_y[64:n, :L]))
+        del d_x, d_y, d_ybuf
+        return el, ok
+
+    lo, hi = shard_channels(total, world, rank)
+    el_n, ok = timed(lo, hi, True)
+    el_1, ok1 = (None, True)
+    if world > 1:
+        if rank == 0:
+            el_1, ok1 = timed(0, total, False)
+        dist.barrier()
+    flag_ok = ok and ok1
+    if dist is not None:
+        flag = torch.tensor([1 if flag_ok else 0], dtype=torch.int32, device=comm_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        flag_ok = bool(flag.item())
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    nfft = plan.nfft
+    plan.close()
+    out = None
+    if rank == 0:
+        rate = total * args.strong_passes / el_n
+        out = dict(workload=WORKLOADS["c5"][3], channels=total, scaling="strong", n_gpus=world, ranks_seen=ranks_seen,
+                   channels_per_rank=hi - lo, passes=args.strong_passes, value=rate, unit="IR/s",
+                   ms_per_pass=el_n / args.strong_passes * 1e3, nfft=nfft,
+                   path_frac=rate / world * 8.0 * L / 1e9 / HBM_PEAK_GBS,
+                   broadcast_bytes=bcast, peaks_exact_and_tiles_bit_equal=bool(flag_ok))
+        if el_1 is not None:
+            r1 = total * args.strong_passes / el_1
+            out["single_gpu_same_run"] = dict(value=r1, unit="IR/s", ms_per_pass=el_1 / args.strong_passes * 1e3,
+                                              note="rank 0 alone over all channels while the other ranks wait")
+            out["speedup_vs_single_gpu"] = rate / r1
+    return out, flag_ok
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse_launch:
+        return rehearse_launch(args, rank, world)
 
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to fd 1 at communicator
     # creation, so everything the run writes to stdout is sent to stderr and the JSON line goes to the
@@ -218,12 +463,6 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
 
     import torch
     dist = None
@@ -277,59 +516,32 @@ def main():
         bcast_bytes = broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0,
                                               via_host=(backend != "nccl"))   # RCCL over xGMI
 
-    # inputs/outputs resident in HBM before the clock starts (torch = device memory plumbing only)
-    d_x = torch.from_numpy(rec).to(device)
-    # overlapped steps must not write the same memory: one output buffer per lane, used round robin
-    lanes = max(1, min(args.lanes, 4, plan.ws_channels))
-    plan.set_overlap(lanes)
-    n_out = lanes
-    # output rows: same pitch; the first sample of a row is placed so that the crop offset of the 'same' window
-    # lands the stores on 128-byte lines (the caller chooses where results go: here (M-1)/2 mod 32 samples in)
-    skew = ((M - 1) // 2) % 32 if os.environ.get("IMPULSE_BENCH_OUT_SKEW", "1") == "1" else 0
-    d_ybufs = [torch.empty(B * pitch + 64, dtype=torch.float32, device=device) for _ in range(n_out)]
-    d_ys = [b[skew: skew + B * pitch].view(B, pitch) for b in d_ybufs]
-    d_y = d_ys[0]
-    torch.cuda.synchronize(device)
-    step_no = [0]
-
-    # Successive steps read DIFFERENT copies of the batch, 1 GiB in rotation, so that no input line survives in the
-    # 256 MiB Infinity Cache from one use to the next: inputs come from HBM, as a stream of new measurements would.
-    # (Re-reading one 25 MB batch every step measured 9 % higher at C2: 429 k vs 391-395 k IR/s.)
-    batch_bytes = d_x.numel() * 4
-    n_sets = int(os.environ.get("IMPULSE_BENCH_INPUT_SETS", "0")) or max(1, min(40, -(-(1 << 30) // batch_bytes)))
-    d_xs = [d_x] + [d_x.clone() for _ in range(n_sets - 1)]
-
-    def step():
-        out = d_ys[step_no[0] % n_out]
-        src = d_xs[step_no[0] % n_sets]
-        step_no[0] += 1
-        plan.execute_device(src.data_ptr(), B, pitch, out.data_ptr(), pitch)
+    # Successive measurements read DIFFERENT copies of the batch, 1 GiB in rotation, so that no input line survives in
+    # the 256 MiB Infinity Cache from one use to the next: inputs come from HBM, as a stream of new measurements would.
+    # (Re-reading one 25 MB batch every time measured 9 % higher at C2: 429 k vs 391-395 k IR/s.)
+    batch_bytes = rec.size * 4
+    n_sets = args.input_sets or int(os.environ.get("IMPULSE_BENCH_INPUT_SETS", "0")) or \
+        max(1, min(40, -(-(1 << 30) // batch_bytes)))
+    wl = DeviceBatch(torch, device, ctx, plan, rec, L, pitch, M, args.lanes, n_sets)
+    lanes = wl.lanes
 
     def barrier():
-        ctx.synchronize()
-        torch.cuda.synchronize(device)
+        wl.sync()
         if dist is not None:
             dist.barrier()
 
-    # Set-up, before the W warm-up steps the contract counts: the chip needs ~10-20 ms of sustained work to
-    # reach its steady clocks (a 9 ms run of 200 steps measured 349 k IR/s, the same 200 steps after 500 more
-    # 396 k), so the first 0.25 s of steps are spent before the warm-up proper.
-    t_ramp = time.perf_counter()
-    while not args.no_ramp and time.perf_counter() - t_ramp < 0.25:
-        for _ in range(16):
-            step()
-        ctx.synchronize()
     for _ in range(args.warmup):
-        step()
+        wl.step()
     barrier()
+    groups_per_measurement = -(-B // (plan.ws_channels // lanes))
+    groups_timed = args.steps * n_sets * groups_per_measurement
     # at least ~8 sampled launch groups however short the run
-    plan.set_timing(0 if args.no_events else max(1, min(args.event_stride, args.steps // 8)))
+    plan.set_timing(0 if args.no_events else max(1, min(args.event_stride, groups_timed // 8)))
     plan.get_timing(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize(device)
+        wl.step()
+    wl.sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
@@ -346,8 +558,8 @@ def main():
         barrier()
         plan.set_overlap(1)
         plan.set_timing(1)
-        for _ in range(max(4, min(40, args.steps))):
-            step()
+        for _ in range(max(4, min(40, n_sets))):
+            wl.measurement()
         ctx.synchronize()
         iso_ms, iso_n = plan.get_timing(reset=True)
         plan.set_timing(0)
@@ -355,20 +567,29 @@ def main():
 
     # parity gate on what the timed loop produced (outside the timed region)
     peaks_ok = True
-    for buf in d_ys:
-        y = buf.cpu().numpy()[:, :L]
+    ys = wl.outputs()
+    for y in ys:
         peaks_ok &= all(int(np.argmax(np.abs(y[c]))) == M // 2 + delays[c] for c in range(B))
+    y = ys[-1]
     if dist is not None:                      # rank 0 reports the verdict of every rank
         flag = torch.tensor([1 if peaks_ok else 0], dtype=torch.int32, device=comm_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         peaks_ok = bool(flag.item())
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    nfft = plan.nfft
+    plan_ws = plan.ws_channels
+    wl.release()
+
+    strong_c5 = None
+    if (world > 1 and not args.no_strong) or args.strong:
+        strong_c5, s_ok = strong_block(args, torch, dist, device, comm_device, ctx, rank, world, backend)
+        peaks_ok &= s_ok
 
     result = None
     if rank == 0:
-        irs_per_step = total_channels
+        irs_per_step = total_channels * n_sets
         value = irs_per_step * args.steps / elapsed
-        groups = -(-B // (plan.ws_channels // lanes))
-        alg_bytes_per_launch = 8.0 * L * B / groups          # average over this rank's launch groups
+        alg_bytes_per_launch = 8.0 * L * B / groups_per_measurement          # average over this rank's launch groups
         names = ("cols_kernel<fwd> (pass A)", "rows_kernel (pass B)", "cols_kernel<inv> (pass C)")
         roof = None
         if launches > 0:
@@ -377,27 +598,37 @@ def main():
             achieved = alg_bytes_per_launch / (avg_ms[dom] * 1e-3) / 1e9
             iso_avg = [m / max(iso_n, 1) for m in iso_ms]
             iso_achieved = alg_bytes_per_launch / (iso_avg[dom] * 1e-3) / 1e9
+            prof, prof_src = load_profile_traffic(args.workload)
             roof = dict(bound="hbm", kernel=names[dom], achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=load_traffic_profile(args.workload),
+                        frac=achieved / HBM_PEAK_GBS,
+                        traffic=(prof or {}).get("rows_kernel_bytes_per_launch"),
+                        traffic_note=(f"L2<->fabric bytes per launch of the dominant kernel (FETCH_SIZE x2 + WRITE_SIZE, "
+                                      f"Infinity-Cache hits INCLUDED, so not HBM bytes) from an earlier rocprofv3 --pmc run of "
+                                      f"this command: {prof_src}") if prof else None,
                         avg_kernel_ms=dict(zip(("pass_a", "pass_b", "pass_c"), avg_ms)),
-                        launch_groups_in_flight=lanes,
+                        events_sampled=int(launches), launch_groups_in_flight=lanes,
+                        note="achieved/frac: algorithmic bytes of one launch group / HIP-event time of the dominant kernel "
+                             "over the timed region; with several launch groups in flight that time includes the share of "
+                             "the chip the kernel cedes to the others, so `isolated` (strictly serial groups) and "
+                             "`path_frac` (whole path, all kernels) are the cleaner figures",
                         isolated=dict(note="same kernel, launch groups strictly serial (nothing else on the chip), "
                                            "measured after the timed region", achieved=iso_achieved,
                                       frac=iso_achieved / HBM_PEAK_GBS,
                                       avg_kernel_ms=dict(zip(("pass_a", "pass_b", "pass_c"), iso_avg))),
                         algorithmic_bytes_per_launch=alg_bytes_per_launch,
-                        launch_groups_per_step=groups,
+                        launch_groups_per_step=groups_per_measurement * n_sets,
                         path_achieved=value / world * 8.0 * L / 1e9,
                         path_frac=value / world * 8.0 * L / 1e9 / HBM_PEAK_GBS)
-            moved = load_path_traffic(args.workload)
-            if moved is not None:
-                # north_star's "achieved HBM GB/s against the chip's peak": bytes the counters saw per launch
-                # group (profiled at this workload's default group size) over this run's time per group
-                rate = moved * groups / (elapsed / args.steps) / 1e9
-                roof["measured_traffic"] = dict(bytes_per_launch_group=moved, achieved=rate, unit="GB/s",
-                                                frac_of_peak=rate / HBM_PEAK_GBS,
-                                                note="rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE bytes of passes A+B+C "
-                                                     "(profiles/pmc_traffic.json) / measured time per launch group")
+            if prof and all(k in prof for k in ("rows_kernel_bytes_per_launch", "cols_fwd_bytes_per_launch",
+                                                "cols_inv_bytes_per_launch")):
+                moved = sum(prof[k] for k in ("rows_kernel_bytes_per_launch", "cols_fwd_bytes_per_launch",
+                                              "cols_inv_bytes_per_launch"))
+                rate = moved * groups_per_measurement * n_sets / (elapsed / args.steps) / 1e9
+                roof["l2_fabric_traffic"] = dict(
+                    bytes_per_launch_group=moved, rate=rate, unit="GB/s", source=prof_src,
+                    note="bytes passes A+B+C move across the L2<->fabric boundary per launch group (earlier rocprofv3 --pmc "
+                         "run) / this run's time per launch group.  Infinity-Cache hits are counted, so this is a FABRIC "
+                         "rate, not achieved HBM bandwidth; it is not compared with the HBM peak")
         cpu = None
         parity = dict(peak_indices_exact=bool(peaks_ok))
         if world == 1 and not args.no_cpu_baseline:
@@ -410,12 +641,20 @@ def main():
                     A, R = np.abs(np.fft.rfft(y[c][sl].astype(np.float64))), np.abs(np.fft.rfft(ref[sl]))
                     acc.append(float(np.max(np.abs(A - R)) / np.max(R)))
             floor = fp32_fft_floor(est, rec[0], L)
-            bound = max(3e-6, 2.0 * floor) if floor else 3e-6
             parity = dict(peak_indices_exact=bool(peaks_ok), spectrum_max_rel_err=max(errs), tolerance=1e-6,
-                          spectrum_window="IR cropped as the pipeline does: peak - 1 ms, 0.68 s long",
-                          whole_column_spectrum_max_rel_err=max(errs_full), whole_column_bound=bound,
-                          whole_column_pocketfft_fp32_err=floor, channels_checked=len(errs))
-            peaks_ok &= max(errs) <= 1e-6 and max(errs_full) <= bound
+                          spectrum_window="IR cropped as the pipeline does before any magnitude_response: peak - 1 ms, 0.68 s long",
+                          whole_column_spectrum_max_rel_err=max(errs_full),
+                          whole_column_meets_1e_6=bool(max(errs_full) <= 1e-6),
+                          whole_column_pocketfft_fp32_err=floor,
+                          whole_column_note="un-cropped 391 270-sample column: above 1e-6 for every fp32 transform (the "
+                                            "reference's own pocketfft in single precision is listed beside it); reported, "
+                                            "not gated",
+                          channels_checked=len(errs))
+            try:
+                parity["real_demo_column"] = demo_column_error()
+            except Exception as exc:                          # noqa: BLE001 - reported figure only
+                parity["real_demo_column"] = dict(error=repr(exc))
+            peaks_ok &= max(errs) <= 1e-6
             cpu["pooled"] = cpu_pooled(est, rec, L)
         whole_slice = None
         if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
@@ -427,29 +666,32 @@ def main():
             "metric": METRIC, "value": value, "unit": "IR/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "stage": "K1 batched sweep deconvolution incl. 'same' crop "
-                       "(inverse-filter spectrum prepared once, outside the timed region)",
-                       "channels_per_gpu_per_step": B, "sweep_samples": M, "column_samples": L,
-                       "input_sets_in_rotation": n_sets,
+            "timed_region_s": elapsed, "irs_per_step": irs_per_step, "ranks_seen": ranks_seen,
+            "config": {"workload": desc, "stage": "K1 ONLY: batched sweep deconvolution incl. 'same' crop "
+                       "(inverse-filter spectrum prepared once, outside the timed region); the FIR stages are not in the "
+                       "timed region (see `slice` / deconv_fir for figures that include them)",
+                       "step": f"one pass over {n_sets} resident measurements of {B} channels per GPU",
+                       "channels_per_gpu_per_measurement": B, "measurements_per_step": n_sets,
+                       "sweep_samples": M, "column_samples": L,
                        "layout": f"planar fp32, row pitch {pitch} samples (multiple of {PITCH_ALIGN}); output rows start "
-                                 f"{skew} samples into 256-byte aligned buffers so the cropped stores fall on cache lines",
-                       "nfft": plan.nfft, "launch_groups_in_flight": lanes, "sharding": (f"channels x{world}, no data-path collective; "
+                                 f"{wl.skew} samples into 256-byte aligned buffers so the cropped stores fall on cache lines",
+                       "nfft": nfft, "launch_groups_in_flight": lanes, "workspace_channels": plan_ws,
+                       "sharding": (f"channels x{world}, no data-path collective; "
                                     f"one {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} broadcast of "
                                     f"{bcast_bytes} B spectrum at plan creation") if dist is not None else
                                    "single rank: no collective"},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "slice": whole_slice,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "slice": whole_slice, "strong_c5": strong_c5,
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
-    plan.close()
-    del d_x, d_xs, d_y, d_ys, d_ybufs
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and not peaks_ok:
-        raise SystemExit("parity gate failed: deconvolved peak indices do not match the analytic truth")
+        raise SystemExit("parity gate failed: deconvolved peak indices / cropped spectra do not match the truth")
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -41,6 +41,13 @@ int ctx_bind(imp_ctx* ctx) {
   return IMP_OK;
 }
 
+int ctx_kernel_lds(imp_ctx* ctx, const void* kernel, size_t bytes) {
+  if (bytes == 0 || ctx->lds_opt_in.count(kernel)) return IMP_OK;
+  HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  ctx->lds_opt_in.insert(kernel);
+  return IMP_OK;
+}
+
 static int upload_table(cf** dptr, const std::vector<cf>& h, hipStream_t s) {
   HIP_TRY(hipMalloc((void**)dptr, h.size() * sizeof(cf)));
   HIP_TRY(hipMemcpyAsync(*dptr, h.data(), h.size() * sizeof(cf), hipMemcpyHostToDevice, s));
@@ -393,12 +400,8 @@ template <int R2, int DIR, class Load, class Store>
 static int launch_cols(imp_plan* p, int64_t nchan, Load ld, Store st) {
   using Cfg = imp::ColsCfg<R2>;
   auto kern = imp::cols_kernel<R2, DIR, Load, Store>;
-  static bool attr_set = false;   // per instantiation
-  if (!attr_set && Cfg::lds_bytes > 0) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes));
-    attr_set = true;
-  }
+  int rc_attr = ctx_kernel_lds(p->ctx, reinterpret_cast<const void*>(kern), Cfg::lds_bytes);
+  if (rc_attr) return rc_attr;
   const int tiles = imp::kN2 / Cfg::TC;
   imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
   dim3 grid((unsigned)(nchan * tiles)), block(Cfg::T);
@@ -411,12 +414,8 @@ template <int F, int R2, int DIR, class Load, class Store>
 static int launch_cols_mixed(imp_plan* p, int64_t nchan, Load ld, Store st) {
   using Cfg = imp::MixCfg<F, R2>;
   auto kern = imp::cols_mixed_kernel<F, R2, DIR, Load, Store>;
-  static bool attr_set = false;   // per instantiation
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::lds_bytes));
-    attr_set = true;
-  }
+  int rc_attr = ctx_kernel_lds(p->ctx, reinterpret_cast<const void*>(kern), Cfg::lds_bytes);
+  if (rc_attr) return rc_attr;
   const int tiles = imp::kN2 / Cfg::TC;
   imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
   dim3 grid((unsigned)(nchan * tiles)), block(Cfg::T);
@@ -454,12 +453,8 @@ static int launch_cols_any(imp_plan* p, int64_t nchan, Load ld, Store st) {
 static constexpr size_t kRowsLds = sizeof(cf) * 2 * 16 * imp::kRowPad;
 
 static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan, int64_t part = 0) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(imp::rows_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowsLds));
-    attr_set = true;
-  }
+  int rc_attr = ctx_kernel_lds(p->ctx, reinterpret_cast<const void*>(imp::rows_kernel), kRowsLds);
+  if (rc_attr) return rc_attr;
   imp::RowsArgs a;
   a.ws = p->cur_ws;
   const int64_t plane = (int64_t)p->N1 * imp::kN2;
@@ -672,7 +667,8 @@ extern "C" int imp_plan_spectrum(imp_plan* p, void** dptr, size_t* bytes) {
   if (!p || !dptr || !bytes) return fail(IMP_ERR_INVALID, "imp_plan_spectrum: null argument");
   IMP_CTX_LOCK(p->ctx);
   *dptr = p->ab;
-  *bytes = (size_t)p->N1 * imp::kN2 * (size_t)p->n_filters * sizeof(float4);
+  // every plane the row pass can read: per-channel filters x overlap-add filter partitions
+  *bytes = (size_t)p->N1 * imp::kN2 * (size_t)(p->n_filters * p->ola_parts) * sizeof(float4);
   return IMP_OK;
 }
 
@@ -803,15 +799,26 @@ static int run_group_with(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64
   return IMP_OK;
 }
 
+// One channel is addressed through a 32-bit buffer range, and the loaders form byte offsets up to the END OF THE
+// TRANSFORM (nfft samples: the zero padding is the hardware range check), not just up to L: the whole span
+// nfft * elem_stride * sizeof(sample) must stay below 4 GiB or a padded offset would wrap back into range.
+static int check_input_span(const imp_plan* p, int64_t elem_stride, size_t sample_bytes) {
+  const int64_t reach = p->ola ? ((int64_t)1 << 21) : p->nfft;
+  if ((double)reach * (double)elem_stride * (double)sample_bytes >= 4294967296.0)
+    return fail(IMP_ERR_INVALID,
+                "transform length %lld x elem_stride %lld x %zu B exceeds the 4 GiB buffer range of one channel",
+                (long long)reach, (long long)elem_stride, sample_bytes);
+  return IMP_OK;
+}
+
 extern "C" int imp_conv_execute_device(imp_plan* p, const float* d_x, int64_t B, int64_t chan_stride_in,
                                        int64_t elem_stride_in, float* d_y, int64_t chan_stride_out) {
   if (!p || !d_x || !d_y) return fail(IMP_ERR_INVALID, "imp_conv_execute_device: null argument");
   IMP_CTX_LOCK(p->ctx);
   if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
   if (elem_stride_in < 1) return fail(IMP_ERR_INVALID, "elem_stride_in must be >= 1");
-  // one channel is addressed through a 32-bit buffer range
-  if ((double)p->L * (double)elem_stride_in * 4.0 >= 4294967296.0)
-    return fail(IMP_ERR_INVALID, "L * elem_stride_in exceeds the 4 GiB buffer range of one channel");
+  int rc_span = check_input_span(p, elem_stride_in, sizeof(float));
+  if (rc_span) return rc_span;
   if (chan_stride_out < p->out_len) return fail(IMP_ERR_INVALID, "chan_stride_out %lld < out_len %lld",
                                                 (long long)chan_stride_out, (long long)p->out_len);
   if (p->n_filters > 1 && B > p->n_filters)
@@ -835,8 +842,8 @@ extern "C" int imp_conv_execute_device_pcm(imp_plan* p, const void* d_pcm, int b
   IMP_CTX_LOCK(p->ctx);
   if (bits != 16 && bits != 32) return fail(IMP_ERR_INVALID, "PCM width must be 16 or 32 bits");
   if (B < 0 || elem_stride_in < 1) return fail(IMP_ERR_INVALID, "bad B or elem_stride_in");
-  if ((double)p->L * (double)elem_stride_in * 4.0 >= 4294967296.0)
-    return fail(IMP_ERR_INVALID, "L * elem_stride_in exceeds the 4 GiB buffer range of one channel");
+  int rc_span = check_input_span(p, elem_stride_in, (size_t)(bits / 8));
+  if (rc_span) return rc_span;
   if (chan_stride_out < p->out_len) return fail(IMP_ERR_INVALID, "chan_stride_out < out_len");
   int rc = ctx_bind(p->ctx);
   if (rc) return rc;
@@ -928,7 +935,9 @@ extern "C" int imp_conv_execute_interleaved(imp_plan* p, const float* frames, in
   IMP_CTX_LOCK(p->ctx);
   if (C < 1) return fail(IMP_ERR_INVALID, "C < 1");
   if (ld_out < p->out_len) return fail(IMP_ERR_INVALID, "ld_out < out_len");
-  int rc = ctx_bind(p->ctx);
+  int rc = check_input_span(p, C, sizeof(float));
+  if (rc) return rc;
+  rc = ctx_bind(p->ctx);
   if (rc) return rc;
   if (p->lanes > 1) return fail(IMP_ERR_INVALID, "host-buffer execution needs imp_plan_set_overlap(plan, 1)");
   const int64_t pout = (p->out_len + 1) & ~(int64_t)1;
@@ -1299,12 +1308,7 @@ extern "C" int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_
   HIP_TRY(hipMemcpyAsync(d_meta + B, a_len, meta, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_meta + 2 * B, b_off, meta, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_meta + 3 * B, b_len, meta, hipMemcpyHostToDevice, s));
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(imp::xcorr_argmax_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(double)));
-    attr_set = true;
-  }
+  if ((rc = ctx_kernel_lds(ctx, reinterpret_cast<const void*>(imp::xcorr_argmax_kernel), 16384 * sizeof(double)))) return rc;
   hipLaunchKernelGGL(imp::xcorr_argmax_kernel, dim3((unsigned)B), dim3(256), (size_t)lds * sizeof(double), s, d_a, d_meta,
                      d_meta + B, d_b, d_meta + 2 * B, d_meta + 3 * B, d_arg, d_val);
   HIP_TRY(hipGetLastError());

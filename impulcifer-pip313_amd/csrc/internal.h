@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -52,7 +53,13 @@ struct imp_ctx {
   std::map<long long, struct MagPlan*> magnitude_plans;
   // fp64 roots of unity on the device, keyed by transform length (filter-spectrum preparation)
   std::map<long long, void*> fft_roots;
+  // kernels whose dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) has been made ON THIS DEVICE:
+  // the attribute is per device, so it is tracked per context, under the context lock
+  std::set<const void*> lds_opt_in;
 };
+
+// opt a kernel into `bytes` of dynamic LDS on the context's device, once per context
+int ctx_kernel_lds(imp_ctx* ctx, const void* kernel, size_t bytes);
 
 // Every compute entry point holds the context's lock from argument check to return: the Python host
 // shares one context between threads (reference: ThreadPoolExecutor workers, core/hrir.py:529-537,

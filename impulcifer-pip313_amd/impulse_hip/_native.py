@@ -204,6 +204,9 @@ class Context:
     def d2d(self, dst, src, nbytes):
         _check(self._lib.imp_memcpy_d2d(self._h, _vp(int(dst)), _vp(int(src)), int(nbytes)))
 
+    def memset(self, dptr, value, nbytes):
+        _check(self._lib.imp_memset(self._h, _vp(int(dptr)), int(value), int(nbytes)))
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             for plan in list(getattr(self, "_plans", ())):

@@ -319,3 +319,27 @@ def test_product_curve_logic_matches_reference(golden, tmp_path):
             np.testing.assert_allclose(cur.equalization, mp[f"fs{fs}_{nm}_eq"], rtol=0, atol=1e-12)
     with pytest.raises(ValueError):
         FrequencyResponse("dup", frequency=[10, 20, 20], raw=[0, 0, 0])
+
+
+def test_bench_starts_its_own_ranks_when_invoked_plainly():
+    """`python bench.py --gpus 2 ...` without torchrun (no WORLD_SIZE): the parent starts two ranks as a child
+    torch.distributed.run before touching any GPU API, relays rank 0's single JSON line and its exit code.
+    --rehearse-launch keeps the ranks off the GPU (rendezvous, sharding, broadcast helper, MAX reduction over gloo)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--rehearse-launch"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert (d["n_gpus"], d["ranks_seen"], d["steps"], d["warmup"]) == (2, 2, 20, 5)
+    assert d["broadcast_ok"] and d["shards_tile"] and d["value"] is None and "rehearsal" in d
+    assert d["strong_c5"]["shards"] == [[0, 512], [512, 1024]]
+
+
+def test_bench_rank_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         timeout=120, env=env, cwd=ROOT)
+    assert res.returncode != 0 and "WORLD_SIZE=3" in res.stderr
