@@ -77,22 +77,27 @@ constexpr int kStreamAux = IMP_STREAM_AUX;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
+// AUX = cache policy bits of the instruction: 0 default, 1 sc0, 2 nt, 16 sc1 (agent scope: bypasses this CU's L1 and is
+// served by the XCD's L2), 18 nt sc1
+template <int AUX = 0>
 __device__ __forceinline__ cf bload_cf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
   return make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
 }
 __device__ __forceinline__ float bload_f(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+template <int AUX = 0>
 __device__ __forceinline__ float4 bload_f4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
   return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void bstore_cf(cf v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   u32x2 x;
   x.x = __float_as_uint(v.x);
   x.y = __float_as_uint(v.y);
-  __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(x, r, voff, soff, AUX);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -491,9 +496,11 @@ __device__ unsigned long long g_phase_trace[8192 * 16];
 #define IMP_MARK_WALL(i)
 #endif
 
-__global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  cf* lds = reinterpret_cast<cf*>(smem_raw);
+// One row pair of channel b (workspace slot b), 512 threads, 68 KiB of LDS at `lds`.  WS_AUX / AB_AUX: cache policy of
+// the workspace loads and of the alpha/beta loads (the three-launch path uses the defaults; the XCD-resident path reads
+// the workspace with sc1 because other CUs of the XCD wrote it, and streams alpha/beta with nt).
+template <int WS_AUX, int AB_AUX>
+__device__ __forceinline__ void rows_pair(const RowsArgs& args, const Twiddles& tw, int b, int pair, cf* lds) {
   IMP_MARK_WALL(12);
   IMP_MARK(0);
 
@@ -502,9 +509,6 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
   const int t = tid & 255;
   const int N1 = args.n1_total;
-  int b, pair;
-  xcd_work_item(args.nchan, pair, b);
-  if (pair >= args.npairs) return;              // the grid is padded to a multiple of 8 pairs (whole workgroup exits)
   const int rowA = pair;
   const int rowB = (pair == 0) ? (N1 >> 1) : (N1 - pair);
   const int k1 = half ? rowB : rowA;
@@ -528,27 +532,10 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   // (phase trace: the four twiddle fetches were ~1 us of exposed latency each).
   cf v[16], u[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) v[j] = bload_cf(r_row, vo8, j * 256 * 8);
+  for (int j = 0; j < 16; ++j) v[j] = bload_cf<WS_AUX>(r_row, vo8, j * 256 * 8);
 #pragma unroll
   for (int a = 1; a < 16; ++a) u[a] = bload_cf(r_t1, vo8, a * 256 * 8);      // stage-1 twiddles
   IMP_MARK_MEM(1);
-#ifdef IMP_EXPERIMENT_ROWS_COPY
-  // ceiling probe: the row pass as a pure copy (alpha/beta still fetched), no butterflies, no LDS
-  {
-    float acc = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const float4 ab = bload_f4(r_ab, vo16, q * 256 * 16);
-      acc += ab.x + ab.w;
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      v[j].x += acc * 1e-30f;
-      bstore_cf(v[j], r_row, vo8, j * 256 * 8);
-    }
-    return;
-  }
-#endif
 
   // ---- forward FFT4096 ----
   fft16<-1>(v);                                            // over j -> a
@@ -579,7 +566,7 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   for (int t2 = 0; t2 < 16; ++t2) v[t2] = buf[hi4 * kRowPad + t2 * 17 + lo4];
   float4 ab_pre[kAbPrefetch];                              // first half of this thread's alpha/beta, a phase early
 #pragma unroll
-  for (int q = 0; q < kAbPrefetch; ++q) ab_pre[q] = bload_f4(r_ab, vo16, q * 256 * 16);
+  for (int q = 0; q < kAbPrefetch; ++q) ab_pre[q] = bload_f4<AB_AUX>(r_ab, vo16, q * 256 * 16);
   fft16<-1>(v);                                            // over t2 -> kb2
   __syncthreads();
   IMP_MARK(3);
@@ -613,14 +600,14 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   const bool dc_lane = (k1 == 0) && (t == 0);
   cf w_dc = make_float2(0.f, 0.f);
   if (dc_lane) {
-    const float4 ab = bload_f4(r_ab, 0u, 0u);
+    const float4 ab = bload_f4<AB_AUX>(r_ab, 0u, 0u);
     const float x0 = v[0].x + v[0].y, xn = v[0].x - v[0].y;
     w_dc = make_float2(0.5f * (x0 * ab.x + xn * ab.z), 0.5f * (x0 * ab.x - xn * ab.z));
   }
   // W = alpha Z + beta conj(Z[Nc-k]), in place
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    v[q] = filter_bin(q < kAbPrefetch ? ab_pre[q] : bload_f4(r_ab, vo16, q * 256 * 16), v[q], u[q]);
+    v[q] = filter_bin(q < kAbPrefetch ? ab_pre[q] : bload_f4<AB_AUX>(r_ab, vo16, q * 256 * 16), v[q], u[q]);
   }
   if (dc_lane) v[0] = w_dc;
   IMP_MARK_MEM(5);
@@ -660,6 +647,14 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
 #ifdef IMP_PHASE_TRACE
   if (threadIdx.x == 0 && blockIdx.x < 8192) g_phase_trace[blockIdx.x * 16 + 14] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
 #endif
+}
+
+__global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int b, pair;
+  xcd_work_item(args.nchan, pair, b);
+  if (pair >= args.npairs) return;              // the grid is padded to a multiple of 8 pairs (whole workgroup exits)
+  rows_pair<0, 0>(args, tw, b, pair, reinterpret_cast<cf*>(smem_raw));
 }
 
 }  // namespace imp

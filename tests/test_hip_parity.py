@@ -155,13 +155,13 @@ def test_conv_error_paths(gpu_ctx):
     # the loaders reach to the END of the transform (zero padding = range check), so the guard is on
     # nfft x elem_stride x 4 B, not L x elem_stride x 4 B: 600 interleaved tracks of 2^20 samples would wrap
     p = ConvPlan(gpu_ctx, np.ones(1 << 19), 1 << 20, "same")
-    assert p.nfft == 3 << 19
+    assert p.nfft == 5 << 18
     d = gpu_ctx.malloc(1 << 20)
     try:
         with pytest.raises(NativeError, match="4 GiB buffer range"):
-            p.execute_device(d, 1, 1, d, 1 << 20, elem_stride_in=700)      # L x 700 x 4 < 4 GiB <= nfft x 700 x 4
+            p.execute_device(d, 1, 1, d, 1 << 20, elem_stride_in=900)      # L x 900 x 4 < 4 GiB <= nfft x 900 x 4
         with pytest.raises(NativeError, match="4 GiB buffer range"):
-            p.execute_device_pcm(d, 32, 1, 1, 700, d, 1 << 20)
+            p.execute_device_pcm(d, 32, 1, 1, 900, d, 1 << 20)
     finally:
         gpu_ctx.free(d)
         p.close()
