@@ -496,15 +496,15 @@ __device__ unsigned long long g_phase_trace[8192 * 16];
 #define IMP_MARK_WALL(i)
 #endif
 
-// One row pair of channel b (workspace slot b), 512 threads, 68 KiB of LDS at `lds`.  WS_AUX / AB_AUX: cache policy of
+// One row pair: workspace slot ws_b, spectrum of channel `chan`; 512 threads, 68 KiB of LDS at `lds`.  WS_AUX / AB_AUX: cache policy of
 // the workspace loads and of the alpha/beta loads (the three-launch path uses the defaults; the XCD-resident path reads
 // the workspace with sc1 because other CUs of the XCD wrote it, and streams alpha/beta with nt).
 template <int WS_AUX, int AB_AUX>
-__device__ __forceinline__ void rows_pair(const RowsArgs& args, const Twiddles& tw, int b, int pair, cf* lds) {
+__device__ __forceinline__ void rows_pair(const RowsArgs& args, const Twiddles& tw, int ws_b, int chan, int pair, cf* lds,
+                                          const int tid) {
   IMP_MARK_WALL(12);
   IMP_MARK(0);
 
-  const int tid = threadIdx.x;
   // a wave never straddles the two rows: everything derived from `half` is wave-uniform (SGPRs)
   const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
   const int t = tid & 255;
@@ -514,9 +514,9 @@ __device__ __forceinline__ void rows_pair(const RowsArgs& args, const Twiddles& 
   const int k1 = half ? rowB : rowA;
   cf* buf = lds + half * (16 * kRowPad);
 
-  const __amdgpu_buffer_rsrc_t r_row = make_rsrc(args.ws + ((long long)b * N1 + k1) * kN2, kN2 * sizeof(cf));
+  const __amdgpu_buffer_rsrc_t r_row = make_rsrc(args.ws + ((long long)ws_b * N1 + k1) * kN2, kN2 * sizeof(cf));
   const __amdgpu_buffer_rsrc_t r_ab =
-      make_rsrc(args.ab + (long long)b * args.ab_chan_stride + (long long)k1 * kN2, kN2 * sizeof(float4));
+      make_rsrc(args.ab + (long long)chan * args.ab_chan_stride + (long long)k1 * kN2, kN2 * sizeof(float4));
   const __amdgpu_buffer_rsrc_t r_t1 = make_rsrc(tw.t1, 16 * 256 * sizeof(cf));
   const __amdgpu_buffer_rsrc_t r_t2 = make_rsrc(tw.t2, 16 * 16 * sizeof(cf));
   const __amdgpu_buffer_rsrc_t r_t4 = make_rsrc(tw.t4, 16 * 256 * sizeof(cf));
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   int b, pair;
   xcd_work_item(args.nchan, pair, b);
   if (pair >= args.npairs) return;              // the grid is padded to a multiple of 8 pairs (whole workgroup exits)
-  rows_pair<0, 0>(args, tw, b, pair, reinterpret_cast<cf*>(smem_raw));
+  rows_pair<0, 0>(args, tw, b, b, pair, reinterpret_cast<cf*>(smem_raw), (int)threadIdx.x);
 }
 
 }  // namespace imp

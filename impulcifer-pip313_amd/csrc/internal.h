@@ -56,6 +56,8 @@ struct imp_ctx {
   // kernels whose dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) has been made ON THIS DEVICE:
   // the attribute is per device, so it is tracked per context, under the context lock
   std::set<const void*> lds_opt_in;
+  // plans with XCD-resident launches whose abort word has not been looked at since (imp_ctx_synchronize does)
+  std::set<struct imp_plan*> resident_plans;
 };
 
 // opt a kernel into `bytes` of dynamic LDS on the context's device, once per context

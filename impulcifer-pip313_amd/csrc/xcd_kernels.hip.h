@@ -60,6 +60,7 @@ struct XcdArgs {
   int nx;                        // XCDs that share the channels (8)
   XcdCtl* ctl;
   XcdCtl* ctl_next;              // zeroed by this launch for the next one
+  unsigned* sticky;              // [0] set on abort and never cleared by the device
   unsigned timeout_ticks;        // s_memrealtime ticks (100 MHz) a single wait may take
 };
 
@@ -69,7 +70,8 @@ __device__ __forceinline__ unsigned xcd_poll(const unsigned* p) {
 
 // lane 0 of wave 0 polls until *counter >= want (or abort); returns false on abort/timeout.  Result is broadcast
 // to the workgroup through `flag` (LDS) by the caller.
-__device__ __forceinline__ bool xcd_wait(XcdCtl* ctl, const unsigned* counter, unsigned want, unsigned timeout_ticks) {
+__device__ __forceinline__ bool xcd_wait(XcdCtl* ctl, unsigned* sticky, const unsigned* counter, unsigned want,
+                                         unsigned timeout_ticks) {
   if (xcd_poll(counter) >= want) return true;
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   unsigned spins = 0;
@@ -81,6 +83,7 @@ __device__ __forceinline__ bool xcd_wait(XcdCtl* ctl, const unsigned* counter, u
       if (xcd_poll(&ctl->abort.v) != 0u) { ok = false; break; }
       if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)timeout_ticks) {
         __hip_atomic_store(&ctl->abort.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = false;
         break;
       }
@@ -134,10 +137,10 @@ __device__ __forceinline__ void xcd_first_twiddle(const Twiddles& tw, int g, cf 
 // pass C of one tile: ws slot -> output channel `chan`
 template <int F, int R2>
 __device__ __forceinline__ void xcd_tile_inverse(const StoreRealCrop& st, const cf* ws_slot, const Twiddles& tw,
-                                                 const DigitTwiddles& dt, int n1_total, int chan, int tile, cf* buf) {
+                                                 const DigitTwiddles& dt, int n1_total, int chan, int tile, cf* buf,
+                                                 const int tid) {
   using Cfg = XcdCfg<F, R2>;
   constexpr int TC = Cfg::TC, T = Cfg::T, G = Cfg::G;
-  const int tid = threadIdx.x;
   const int c = tid % TC, g = tid / TC;
   const unsigned n2 = (unsigned)(tile * TC + c);
   const __amdgpu_buffer_rsrc_t r_ws = make_rsrc(ws_slot, (unsigned)n1_total * kN2 * 8u);
@@ -199,30 +202,26 @@ __device__ __forceinline__ void xcd_tile_inverse(const StoreRealCrop& st, const 
 // pass A of one tile: prefetched input rows (v) -> ws slot
 template <int F, int R2>
 __device__ __forceinline__ void xcd_tile_forward(cf (&v)[F], cf* ws_slot, const Twiddles& tw, const DigitTwiddles& dt,
-                                                 int n1_total, int tile, cf* buf) {
+                                                 int n1_total, int tile, cf* buf, const int tid) {
   using Cfg = XcdCfg<F, R2>;
   constexpr int TC = Cfg::TC, T = Cfg::T, G = Cfg::G;
-  const int tid = threadIdx.x;
   const int c = tid % TC, g = tid / TC;
   const unsigned n2 = (unsigned)(tile * TC + c);
   const __amdgpu_buffer_rsrc_t r_ws = make_rsrc(ws_slot, (unsigned)n1_total * kN2 * 8u);
   const __amdgpu_buffer_rsrc_t r_p = make_rsrc(dt.P, 8u * kN2 * 8u);
   const __amdgpu_buffer_rsrc_t r_q = make_rsrc(dt.Q, (unsigned)(n1_total / 8) * kN2 * 8u);
-  // four-step twiddles of this thread's outputs k1 = ka + F kb, fetched before the exchange
-  cf twd[G][R2];
+  // four-step twiddles of this thread's outputs k1 = ka + F kb (first batch: ka = g), fetched before the exchange
+  auto fetch_twd = [&](int ka, cf (&twd)[R2]) {
 #pragma unroll
-  for (int i = 0; i < G; ++i) {
-    const int ka = g + R2 * i;
-    if (ka < F) {
-#pragma unroll
-      for (int kb = 0; kb < R2; ++kb) {
-        const unsigned k1 = (unsigned)ka + (unsigned)(F * kb);
-        const cf pd = bload_cf(r_p, ((k1 & 7u) * kN2 + n2) * 8u, 0u);
-        const cf qe = bload_cf(r_q, ((k1 >> 3) * kN2 + n2) * 8u, 0u);
-        twd[i][kb] = cmul(pd, qe);
-      }
+    for (int kb = 0; kb < R2; ++kb) {
+      const unsigned k1 = (unsigned)ka + (unsigned)(F * kb);
+      const cf pd = bload_cf(r_p, ((k1 & 7u) * kN2 + n2) * 8u, 0u);
+      const cf qe = bload_cf(r_q, ((k1 >> 3) * kN2 + n2) * 8u, 0u);
+      twd[kb] = cmul(pd, qe);
     }
-  }
+  };
+  cf twd[R2];
+  fetch_twd(g, twd);
   fft_first_any<-1, F>(v);
   xcd_first_twiddle<F, R2, -1>(tw, g, v);
   if constexpr (R2 > 1) {
@@ -233,7 +232,8 @@ __device__ __forceinline__ void xcd_tile_forward(cf (&v)[F], cf* ws_slot, const 
 #pragma unroll
   for (int i = 0; i < G; ++i) {
     const int ka = g + R2 * i;
-    if (ka < F) {
+    if (ka < F) {                                            // i > 0: a few leftover rows, one wave (g is wave-uniform)
+      if (i > 0) fetch_twd(ka, twd);
       cf y[R2];
       if constexpr (R2 > 1) {
 #pragma unroll
@@ -244,7 +244,7 @@ __device__ __forceinline__ void xcd_tile_forward(cf (&v)[F], cf* ws_slot, const 
       }
       const unsigned e = (unsigned)ka * kN2 + n2;
 #pragma unroll
-      for (int kb = 0; kb < R2; ++kb) bstore_cf(cmul(y[kb], twd[i][kb]), r_ws, e * 8u, (unsigned)(kb * F * kN2) * 8u);
+      for (int kb = 0; kb < R2; ++kb) bstore_cf(cmul(y[kb], twd[kb]), r_ws, e * 8u, (unsigned)(kb * F * kN2) * 8u);
     }
   }
 }
@@ -259,14 +259,14 @@ __global__ __launch_bounds__(512, 4) void xcd_conv_kernel(XcdArgs<Load> args, Tw
   cf* lds = reinterpret_cast<cf*>(smem_raw);
   __shared__ int s_word[2];                                  // [0] ticket, [1] wait verdict
 
-  const int tid = threadIdx.x;
+  const int tid0 = threadIdx.x;
   const int xcc = (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u);   // HW_REG_XCC_ID[3:0]
   XcdCtl* ctl = args.ctl;
   if (blockIdx.x == 0) {                                     // zero the NEXT launch's control block
     unsigned* z = reinterpret_cast<unsigned*>(args.ctl_next);
-    for (unsigned i = tid; i < sizeof(XcdCtl) / 4; i += 512) z[i] = 0u;
+    for (unsigned i = tid0; i < sizeof(XcdCtl) / 4; i += 512) z[i] = 0u;
   }
-  if (tid == 0) atomicOr(&ctl->xcc_seen.v, 1u << xcc);
+  if (tid0 == 0) atomicOr(&ctl->xcc_seen.v, 1u << xcc);
   if (xcc >= args.nx) return;                                // not a team of this launch (never on an SPX device)
 
   constexpr int tiles = kN2 / Cfg::TC;                       // 64
@@ -284,6 +284,11 @@ __global__ __launch_bounds__(512, 4) void xcd_conv_kernel(XcdArgs<Load> args, Tw
   ra.nchan = args.nchan;
 
   for (;;) {
+    // the thread index is made opaque once per item: everything derived from it (row / column offsets of either
+    // phase) is then recomputed per item instead of being hoisted out of the loop and kept live - and spilled -
+    // across both phases
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
     if (tid == 0) s_word[0] = (int)atomicAdd(&ctl->ticket[xcc].v, 1u);
     __syncthreads();
     const int ticket = s_word[0];
@@ -300,15 +305,15 @@ __global__ __launch_bounds__(512, 4) void xcd_conv_kernel(XcdArgs<Load> args, Tw
         args.ld.template column<R2 * kN2, F>(chan_a, e0, v);          // in flight while we wait for B(r-1)
       }
       if (has_c) {
-        if (tid == 0) s_word[1] = xcd_wait(ctl, &ctl->done_b[xcc].v, (unsigned)(pairs * r), args.timeout_ticks) ? 1 : 0;
+        if (tid == 0) s_word[1] = xcd_wait(ctl, args.sticky, &ctl->done_b[xcc].v, (unsigned)(pairs * r), args.timeout_ticks) ? 1 : 0;
         __syncthreads();
         if (!s_word[1]) break;
-        if (tid < Cfg::T) xcd_tile_inverse<F, R2>(args.st, ws_slot, tw, dt, args.n1_total, chan_c, i, lds);
+        if (tid < Cfg::T) xcd_tile_inverse<F, R2>(args.st, ws_slot, tw, dt, args.n1_total, chan_c, i, lds, tid);
         else if constexpr (R2 > 1) __syncthreads();
         __syncthreads();                                     // C's LDS reads done before A writes the plane
       }
       if (has_a) {
-        if (tid < Cfg::T) xcd_tile_forward<F, R2>(v, ws_slot, tw, dt, args.n1_total, i, lds);
+        if (tid < Cfg::T) xcd_tile_forward<F, R2>(v, ws_slot, tw, dt, args.n1_total, i, lds, tid);
         else if constexpr (R2 > 1) __syncthreads();
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave: its stores have reached the L2
@@ -317,10 +322,10 @@ __global__ __launch_bounds__(512, 4) void xcd_conv_kernel(XcdArgs<Load> args, Tw
     } else {
       const int pair = i - tiles;
       const int chan = xcc + r * args.nx;
-      if (tid == 0) s_word[1] = xcd_wait(ctl, &ctl->done_ca[xcc].v, (unsigned)(tiles * (r + 1)), args.timeout_ticks) ? 1 : 0;
+      if (tid == 0) s_word[1] = xcd_wait(ctl, args.sticky, &ctl->done_ca[xcc].v, (unsigned)(tiles * (r + 1)), args.timeout_ticks) ? 1 : 0;
       __syncthreads();
       if (!s_word[1]) break;
-      rows_pair<16, 2>(ra, tw, 0, chan, pair, lds);
+      rows_pair<16, 2>(ra, tw, 0, chan, pair, lds, tid);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(&ctl->done_b[xcc].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

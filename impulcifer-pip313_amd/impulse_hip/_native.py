@@ -73,6 +73,8 @@ SIGNATURES = {
     "imp_conv_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64]),
     "imp_conv_execute_device_pcm": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _i64]),
     "imp_plan_set_overlap": (C.c_int, [_vp, C.c_int]),
+    "imp_plan_set_resident": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
+    "imp_plan_resident_status": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong)]),
     "imp_plan_set_timing": (C.c_int, [_vp, C.c_int]),
     "imp_plan_get_timing": (C.c_int, [_vp, _pd, _pi64, C.c_int]),
     "imp_debug_plan_geometry": (C.c_int, [_i64, _i64, C.c_int, _pi64, _pi64, _pi64]),
@@ -501,6 +503,23 @@ class ConvPlan:
         """lanes > 1: successive launch groups of execute_device overlap on that many streams (inputs must
         be ready before each call; outputs are complete after ctx.synchronize())."""
         _check(self._lib.imp_plan_set_overlap(self._h, int(lanes)))
+
+    def resident_available(self):
+        """True if this plan qualifies for the XCD-resident path (one channel's workspace fits an XCD's L2)."""
+        a = C.c_int(0)
+        _check(self._lib.imp_plan_set_resident(self._h, 0, C.byref(a)))
+        return bool(a.value)
+
+    def set_resident(self, on=True):
+        """Route execute_device / execute_device_pcm through the XCD-resident persistent kernel (one launch per call,
+        channel c on XCD c mod 8, workspace kept in that XCD's L2).  Raises NativeError if the plan does not qualify."""
+        _check(self._lib.imp_plan_set_resident(self._h, 1 if on else 0, None))
+
+    def resident_status(self):
+        """Synchronises; (aborted, xcc_seen mask, wait ticks @100 MHz) of the resident launches since the last call."""
+        a, m, w = C.c_int(0), C.c_uint(0), C.c_ulonglong(0)
+        _check(self._lib.imp_plan_resident_status(self._h, C.byref(a), C.byref(m), C.byref(w)))
+        return bool(a.value), int(m.value), int(w.value)
 
     def set_timing(self, every_n):
         """0/False = off; n = bracket the three passes of every n-th launch group with HIP events."""

@@ -120,6 +120,19 @@ int imp_conv_execute_device_pcm(imp_plan* plan, const void* d_pcm, int bits, int
  * in flight must not write the same output memory.  lanes = 1 restores strict stream order. */
 int imp_plan_set_overlap(imp_plan* plan, int lanes);
 
+/* XCD-resident execution (one persistent launch per call instead of three launches per group): available when one
+ * channel's workspace (nfft * 4 bytes) fits an XCD's 4 MiB L2 beside the tables, i.e. nfft <= 589 824 (the 7.1 x
+ * 6.15 s configuration), on a device that exposes all 8 XCDs.  Channel c is processed on XCD c mod 8 and its
+ * workspace never leaves that XCD's L2.  on = 1 enables it for imp_conv_execute_device(_pcm) (launches go to the
+ * context stream in order; imp_plan_set_overlap does not apply to them); on = 0 restores the three-launch path.
+ * *available (may be NULL) says whether the plan qualifies; enabling an unqualified plan is an error. */
+int imp_plan_set_resident(imp_plan* plan, int on, int* available);
+/* Synchronises and reports the resident launches since the last call: *aborted != 0 if a bounded in-kernel wait
+ * expired (the outputs of that call are invalid; imp_ctx_synchronize returns an error too), *xcc_seen = OR of
+ * 1 << XCC_ID over the workgroups of the last launch, *wait_ticks = 100 MHz ticks workgroups spent waiting for a
+ * phase of their XCD to complete in the last launch.  Any pointer may be NULL. */
+int imp_plan_resident_status(imp_plan* plan, int* aborted, unsigned* xcc_seen, unsigned long long* wait_ticks);
+
 /* per-kernel timing with HIP events on the plan's stream (for bench.py's roofline block):
  * every_n = 0 switches it off, n >= 1 brackets the three passes of every n-th launch group. */
 int imp_plan_set_timing(imp_plan* plan, int every_n);
