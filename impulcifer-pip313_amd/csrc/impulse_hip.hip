@@ -982,6 +982,10 @@ extern "C" int imp_plan_resident_status(imp_plan* p, int* aborted, unsigned* xcc
   if (aborted) *aborted = (sticky || last.abort.v) ? 1 : 0;
   if (xcc_seen) *xcc_seen = last.xcc_seen.v;
   if (wait_ticks) *wait_ticks = last.wait_ticks.v;
+  if (std::getenv("IMPULSE_HIP_RESIDENT_DIAG")) {
+    static const char* names[8] = {"ticket", "ca_wait", "c_part", "a_part", "ca_drain", "b_wait", "b_work", "b_drain"};
+    for (int k = 0; k < 8; ++k) fprintf(stderr, "  xcd diag %-9s %10.1f us (sum over workgroups)\n", names[k], last.diag[k].v * 0.01);
+  }
   return IMP_OK;
 }
 

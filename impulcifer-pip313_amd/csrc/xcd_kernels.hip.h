@@ -38,6 +38,8 @@ struct XcdCtl {
   XcdLine abort;              // set when a wait expired: outputs are invalid
   XcdLine xcc_seen;           // OR of 1 << XCC_ID over the workgroups that ran (census for the host)
   XcdLine wait_ticks;         // diagnostics: total s_memrealtime ticks lane 0 of every workgroup spent polling
+  XcdLine diag[8];            // IMP_XCD_DIAG builds: ticks in [0] ticket fetch [1] CA prefetch+wait [2] C part [3] A part
+                              // [4] CA drain [5] B wait [6] B work [7] B drain, summed over workgroups
 };
 
 // four-step twiddle w_Nc^(k1 n2) as the product of two small tables (the Nc-entry table of the three-launch path is as
@@ -77,9 +79,11 @@ __device__ __forceinline__ bool xcd_wait(XcdCtl* ctl, unsigned* sticky, const un
   unsigned spins = 0;
   bool ok = true;
   for (;;) {
-    __builtin_amdgcn_s_sleep(2);
+    // ~1 us between polls: every poll is a fabric read of one line, and a few hundred workgroups polling the same
+    // eight lines back to back slow down whatever else lives in those memory channels
+    __builtin_amdgcn_s_sleep(32);
     if (xcd_poll(counter) >= want) break;
-    if ((++spins & 31u) == 0u) {
+    if ((++spins & 15u) == 0u) {
       if (xcd_poll(&ctl->abort.v) != 0u) { ok = false; break; }
       if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)timeout_ticks) {
         __hip_atomic_store(&ctl->abort.v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -252,6 +256,22 @@ __device__ __forceinline__ void xcd_tile_forward(cf (&v)[F], cf* ws_slot, const 
 // ---------------------------------------------------------------------------------------------
 // The persistent kernel.  512 threads, two workgroups per CU (68 KiB LDS each), any grid size.
 // ---------------------------------------------------------------------------------------------
+#ifndef IMP_XCD_DIAG
+#define IMP_XCD_DIAG 0
+#endif
+#if IMP_XCD_DIAG
+#define XCD_STAMP(k)                                                             \
+  do {                                                                           \
+    if (tid == 0) {                                                              \
+      const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();          \
+      atomicAdd(&ctl->diag[k].v, (unsigned)(now_ - stamp_));                     \
+      stamp_ = now_;                                                             \
+    }                                                                            \
+  } while (0)
+#else
+#define XCD_STAMP(k)
+#endif
+
 template <int F, int R2, class Load>
 __global__ __launch_bounds__(512, 4) void xcd_conv_kernel(XcdArgs<Load> args, Twiddles tw, DigitTwiddles dt) {
   using Cfg = XcdCfg<F, R2>;
@@ -283,6 +303,9 @@ __global__ __launch_bounds__(512, 4) void xcd_conv_kernel(XcdArgs<Load> args, Tw
   ra.npairs = pairs;
   ra.nchan = args.nchan;
 
+#if IMP_XCD_DIAG
+  unsigned long long stamp_ = __builtin_amdgcn_s_memrealtime();
+#endif
   for (;;) {
     // the thread index is made opaque once per item: everything derived from it (row / column offsets of either
     // phase) is then recomputed per item instead of being hoisted out of the loop and kept live - and spilled -
@@ -291,6 +314,7 @@ __global__ __launch_bounds__(512, 4) void xcd_conv_kernel(XcdArgs<Load> args, Tw
     asm volatile("" : "+v"(tid));
     if (tid == 0) s_word[0] = (int)atomicAdd(&ctl->ticket[xcc].v, 1u);
     __syncthreads();
+    XCD_STAMP(0);
     const int ticket = s_word[0];
     const int r = ticket / per_round;
     const int i = ticket - r * per_round;
@@ -307,27 +331,34 @@ __global__ __launch_bounds__(512, 4) void xcd_conv_kernel(XcdArgs<Load> args, Tw
       if (has_c) {
         if (tid == 0) s_word[1] = xcd_wait(ctl, args.sticky, &ctl->done_b[xcc].v, (unsigned)(pairs * r), args.timeout_ticks) ? 1 : 0;
         __syncthreads();
+        XCD_STAMP(1);
         if (!s_word[1]) break;
         if (tid < Cfg::T) xcd_tile_inverse<F, R2>(args.st, ws_slot, tw, dt, args.n1_total, chan_c, i, lds, tid);
         else if constexpr (R2 > 1) __syncthreads();
         __syncthreads();                                     // C's LDS reads done before A writes the plane
+        XCD_STAMP(2);
       }
       if (has_a) {
         if (tid < Cfg::T) xcd_tile_forward<F, R2>(v, ws_slot, tw, dt, args.n1_total, i, lds, tid);
         else if constexpr (R2 > 1) __syncthreads();
       }
+      XCD_STAMP(3);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave: its stores have reached the L2
       __syncthreads();
+      XCD_STAMP(4);
       if (tid == 0) __hip_atomic_fetch_add(&ctl->done_ca[xcc].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       const int pair = i - tiles;
       const int chan = xcc + r * args.nx;
       if (tid == 0) s_word[1] = xcd_wait(ctl, args.sticky, &ctl->done_ca[xcc].v, (unsigned)(tiles * (r + 1)), args.timeout_ticks) ? 1 : 0;
       __syncthreads();
+      XCD_STAMP(5);
       if (!s_word[1]) break;
       rows_pair<16, 2>(ra, tw, 0, chan, pair, lds, tid);
+      XCD_STAMP(6);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      XCD_STAMP(7);
       if (tid == 0) __hip_atomic_fetch_add(&ctl->done_b[xcc].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
