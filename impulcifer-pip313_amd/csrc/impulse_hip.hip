@@ -985,6 +985,8 @@ extern "C" int imp_plan_resident_status(imp_plan* p, int* aborted, unsigned* xcc
   if (std::getenv("IMPULSE_HIP_RESIDENT_DIAG")) {
     static const char* names[8] = {"ticket", "ca_wait", "c_part", "a_part", "ca_drain", "b_wait", "b_work", "b_drain"};
     for (int k = 0; k < 8; ++k) fprintf(stderr, "  xcd diag %-9s %10.1f us (sum over workgroups)\n", names[k], last.diag[k].v * 0.01);
+    if (last.clk[1].v) fprintf(stderr, "  xcd diag shader clock %.3f GHz (s_memtime / s_memrealtime x 100 MHz)\n",
+                               0.1 * (double)last.clk[0].v / (double)last.clk[1].v);
   }
   return IMP_OK;
 }

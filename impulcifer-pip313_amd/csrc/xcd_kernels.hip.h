@@ -38,6 +38,7 @@ struct XcdCtl {
   XcdLine abort;              // set when a wait expired: outputs are invalid
   XcdLine xcc_seen;           // OR of 1 << XCC_ID over the workgroups that ran (census for the host)
   XcdLine wait_ticks;         // diagnostics: total s_memrealtime ticks lane 0 of every workgroup spent polling
+  XcdLine clk[2];             // IMP_XCD_DIAG builds: [0] s_memtime ticks / 1024, [1] s_memrealtime ticks / 1024 over workgroup lifetimes
   XcdLine diag[8];            // IMP_XCD_DIAG builds: ticks in [0] ticket fetch [1] CA prefetch+wait [2] C part [3] A part
                               // [4] CA drain [5] B wait [6] B work [7] B drain, summed over workgroups
 };
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(512, 4) void xcd_conv_kernel(XcdArgs<Load> args, Tw
 
 #if IMP_XCD_DIAG
   unsigned long long stamp_ = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long clk0_ = __builtin_amdgcn_s_memtime(), rt0_ = stamp_;
 #endif
   for (;;) {
     // the thread index is made opaque once per item: everything derived from it (row / column offsets of either
@@ -362,6 +364,12 @@ __global__ __launch_bounds__(512, 4) void xcd_conv_kernel(XcdArgs<Load> args, Tw
       if (tid == 0) __hip_atomic_fetch_add(&ctl->done_b[xcc].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+#if IMP_XCD_DIAG
+  if (threadIdx.x == 0) {
+    atomicAdd(&ctl->clk[0].v, (unsigned)((__builtin_amdgcn_s_memtime() - clk0_) >> 10));
+    atomicAdd(&ctl->clk[1].v, (unsigned)((__builtin_amdgcn_s_memrealtime() - rt0_) >> 10));
+  }
+#endif
 }
 
 }  // namespace imp
