@@ -83,3 +83,20 @@ def sweep_sequence_layout(n_speakers, N, fs, silence=2.0):
     total = int((fs * silence + N) * n_speakers + fs * silence)
     starts = [int(step * i + fs * silence) for i in range(n_speakers)]
     return total, starts
+
+
+def from_wav_samples(samples, fs):
+    """core/impulse_response_estimator.py:234-262 after the file has been read (track 0 of the WAV, float64 in
+    [-1, 1)): min_duration = (len - 1) / fs; the file's samples replace the generated sweep when the LENGTH differs
+    (:250-254, duration := len / fs) or when any sample differs by more than 1e-4 (:256-260); the inverse filter is
+    regenerated in both cases."""
+    samples = np.asarray(samples, dtype=np.float64)
+    e = Estimator(min_duration=(len(samples) - 1) / fs, fs=fs)
+    if len(e.test_signal) != len(samples):
+        e.test_signal = samples
+        e.duration = len(samples) / fs
+        e.inverse_filter = generate_inverse_filter(samples, e.n_octaves)
+    elif np.max(np.abs(e.test_signal - samples)) > 1e-4:
+        e.test_signal = samples
+        e.inverse_filter = generate_inverse_filter(samples, e.n_octaves)
+    return e

@@ -129,3 +129,55 @@ def specific_room_correction(ir_data, fs, target_raw, mic_calibration_raw=None, 
     if limit > 0:
         error = error * correction_limit_mask(freq, limit)
     return freq, raw, error, reference_gain
+
+
+def smoothen(frequency, data, window_size_oct=1 / 3, treble_window_size_oct=1 / 3, treble_f_lower=100.0,
+             treble_f_upper=10000.0):
+    """FrequencyResponse.smoothen_fractional_octave on one curve with the defaults room_correction passes."""
+    return smoothen_fractional_octave(frequency, data, window_size_oct, treble_window_size_oct, treble_f_lower,
+                                      treble_f_upper)
+
+
+def generic_room_correction(ir_datas, fs, target_raw, mic_calibration_raw=None, method="average", limit=1000):
+    """core/room_correction.py:231-292 (_calculate_generic_room_correction).  ir_datas: head-cropped responses of the
+    positions of room.wav; target_raw / mic_calibration_raw on the 10 Hz..fs/2 grid.  Returns (frequency, raw, error,
+    error_smoothed) of the combined curve."""
+    freq = generate_frequencies(10, fs / 2, 1.01)
+    raw_sum = np.zeros(len(freq))
+    errors = []
+    target_c = target_raw - center_shift(freq, target_raw, 1000)          # compensate() centres a copy at 1 kHz
+    for d in ir_datas:
+        f, raw = ir_frequency_response(d, fs)
+        if mic_calibration_raw is not None:
+            raw = raw - mic_calibration_raw
+        raw = raw - center_shift(f, raw, [100, 10000])
+        raw_sum = raw_sum + raw
+        err = raw - target_c
+        err = err - np.mean(err[np.logical_and(f >= 100, f <= 10000)])    # min_mean_error=True
+        if method == "conservative" and len(ir_datas) > 1:
+            err = smoothen(f, err)
+        errors.append(err)
+    raw = raw_sum / len(ir_datas)
+    errors = np.vstack(errors)
+    if errors.shape[0] > 1:
+        if method == "conservative":
+            share = np.mean(errors > 0, axis=0)
+            error = np.zeros(len(freq))
+            pos, neg = share == 1, share == 0
+            error[pos] = np.min(errors[:, pos], axis=0)
+            error[neg] = np.max(errors[:, neg], axis=0)
+            error = smoothen(freq, error, 1 / 6, 1 / 6)
+            error_smoothed = error.copy()
+        elif method == "average":
+            error = np.mean(errors, axis=0)
+            error_smoothed = smoothen(freq, error)
+        else:
+            raise ValueError(f'Invalid value "{method}" for method. Supported values are "conservative" and "average"')
+    else:
+        error = errors[0]
+        error_smoothed = smoothen(freq, error)
+    if limit > 0:
+        mask = correction_limit_mask(freq, limit)
+        error = error * mask
+        error_smoothed = error_smoothed * mask
+    return freq, raw, error, error_smoothed

@@ -139,3 +139,54 @@ def align_ipsilateral_all(irs, fs, speaker_pairs, segment_ms=30):
             for sd in ("left", "right"):
                 out[one][sd] = shift(out[one][sd], -lag)
     return out
+
+
+# core/constants.py:95-104
+HESUVI_TRACK_ORDER = ['FL-left', 'FL-right', 'SL-left', 'SL-right', 'BL-left', 'BL-right', 'FC-left', 'FR-right',
+                      'FR-left', 'SR-right', 'SR-left', 'BR-right', 'BR-left', 'FC-right', 'WL-left', 'WL-right',
+                      'WR-left', 'WR-right', 'TFL-left', 'TFL-right', 'TFR-left', 'TFR-right', 'TSL-left',
+                      'TSL-right', 'TSR-left', 'TSR-right', 'TBL-left', 'TBL-right', 'TBR-left', 'TBR-right']
+HEXADECAGONAL_TRACK_ORDER = ['FL-left', 'FL-right', 'FR-left', 'FR-right', 'FC-left', 'FC-right', 'LFE-left',
+                             'LFE-right', 'BL-left', 'BL-right', 'BR-left', 'BR-right', 'SL-left', 'SL-right',
+                             'SR-left', 'SR-right', 'WL-left', 'WL-right', 'WR-left', 'WR-right', 'TFL-left',
+                             'TFL-right', 'TFR-left', 'TFR-right', 'TSL-left', 'TSL-right', 'TSR-left',
+                             'TSR-right', 'TBL-left', 'TBL-right', 'TBR-left', 'TBR-right']
+
+
+def write_wav_frames(irs, track_order=None):
+    """core/hrir.py:426-455 + core/audio_io.py:82-97: the float matrix handed to soundfile, [frames, tracks]: one
+    column per name in track_order ('<speaker>-<side>'), zeros (length of the FIRST response) for absent channels;
+    the [tracks, frames] stack is transposed when it has more columns than rows."""
+    if track_order is None:
+        track_order = HEXADECAGONAL_TRACK_ORDER
+    by_name = {f"{sp}-{sd}": np.asarray(d) for sp, pair in irs.items() for sd, d in pair.items()}
+    if not by_name:
+        raise ValueError("No impulse responses available for WAV output.")
+    n = len(next(iter(by_name.values())))
+    data = np.vstack([by_name.get(ch, np.zeros(n)) for ch in track_order])
+    if data.ndim > 1 and data.shape[1] > data.shape[0]:
+        data = data.T
+    return data
+
+
+def pcm_quantise(frames, bit_depth):
+    """libsndfile's float -> PCM conversion as soundfile.write(subtype='PCM_16'|'PCM_24'|'PCM_32') performs it with
+    its defaults (normalisation on, clipping off): lrint(x * (2^(bits-1) - 1)), no clipping (out-of-range values
+    wrap).  libsndfile is a third-party dependency of the reference (via `soundfile`, unpinned) and is not under
+    /root/reference: this restates its published algorithm (src/pcm.c, d2bes/d2let/d2lei_array); the one shipped
+    output file (data/demo/room-responses.wav, peak 0.0033) cannot tell 2^31 - 1 from 2^31: PARITY UNPINNED."""
+    scale = float(2 ** (bit_depth - 1) - 1)
+    q = np.rint(np.asarray(frames, dtype=np.float64) * scale).astype(np.int64)
+    half = 1 << (bit_depth - 1)
+    return ((q + half) % (1 << bit_depth)) - half
+
+
+def equalize_all(irs, fir):
+    """core/hrir.py:858-888: row 0 of `fir` filters every left response, row 1 every right one ('full'
+    convolution); a single row / 1-D filter serves both sides."""
+    from .scipy_restated import fft_convolve
+    fir = np.asarray(fir, dtype=np.float64)
+    if fir.ndim == 1 or fir.shape[0] == 1:
+        fir = np.tile(fir, (2, 1))
+    return {sp: {sd: fft_convolve(np.asarray(d, dtype=np.float64), fir[0] if sd == "left" else fir[1], "full")
+                 for sd, d in pair.items()} for sp, pair in irs.items()}

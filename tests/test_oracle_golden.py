@@ -356,3 +356,123 @@ def test_sosfilt_restatement(golden):
     x = g["sosfilt_in"]
     np.testing.assert_array_equal(ovb.sosfilt(g["sos_hp8_250"], x), g["sosfilt_hp8"])
     np.testing.assert_array_equal(ovb.sosfilt(g["sos_lp8_250"], ovb.sosfilt(g["sos_hp4_15"], x)), g["sosfilt_lp8_of_hp4"])
+
+
+# ------------------------------------------------------------------ round 2: from_wav, class-level convolve / adjust_decay,
+# HRIR.equalize / write_wav, room_correction() with generic measurements (round2.npz, reference run)
+def _r2():
+    import round2_inputs as r2
+    return r2
+
+
+def test_from_wav_branches(golden):
+    g, r2 = golden("round2"), _r2()
+    e1 = oest.Estimator(1.0, 48000)
+    cases = {"offgrid": r2.off_grid_sweep(), "perturbed": r2.perturbed(e1.test_signal, 3e-4), "ongrid": e1.test_signal}
+    for name, sig in cases.items():
+        samples = r2.to_pcm32(sig).astype(np.float64) / 2 ** 31          # what the WAV reader returns
+        e = oest.from_wav_samples(samples, 48000)
+        assert len(e) == int(g[f"fw_{name}_N"]) and e.duration == float(g[f"fw_{name}_duration"])
+        assert e.n_octaves == float(g[f"fw_{name}_P"])
+        assert bool(np.array_equal(e.test_signal, samples)) == bool(g[f"fw_{name}_sig_is_file"])
+        for got, key in ((e.inverse_filter[:64], "inv_head"), (e.inverse_filter[-64:], "inv_tail"),
+                         (e.inverse_filter[::509], "inv_dec")):
+            np.testing.assert_allclose(got, g[f"fw_{name}_{key}"], rtol=1e-13, atol=0)
+        imp = np.zeros(len(e) + 2 * 48000)
+        imp[100: 100 + len(e)] = e.test_signal
+        y = e.estimate(imp)
+        assert int(np.argmax(np.abs(y))) == int(g[f"fw_{name}_selfpeak"]) == 100 + len(e) // 2
+        assert y[int(np.argmax(np.abs(y)))] == pytest.approx(float(g[f"fw_{name}_selfpeak_value"]), abs=1e-12)
+
+
+def test_class_level_convolve_and_adjust_decay(golden):
+    g, r2 = golden("round2"), _r2()
+    d = r2.decaying_ir(0x1111)
+    x = np.random.default_rng(0x2222).standard_normal(1500).astype(np.float32).astype(np.float64)
+    np.testing.assert_allclose(sr.fft_convolve(x, d, "full"), g["conv_y"], rtol=0, atol=1e-12)
+    for tgt in (0.2, 0.12):
+        out = d.copy()
+        odecay.apply_decay_window(out, odecay.decay_adjustment_params(d, 48000, tgt))
+        np.testing.assert_allclose(out, g[f"adj_{tgt}"], rtol=0, atol=1e-15)
+    assert odecay.decay_adjustment_params(d, 48000, 5.0) is None and bool(g["adj_noop_equal"])
+
+
+def test_hrir_equalize_and_write_wav_frames(golden):
+    g, r2 = golden("round2"), _r2()
+    base, firs = r2.hrir_set(), r2.fir_pair()
+    for name, arg in (("two_rows", firs), ("one_row", firs[:1]), ("flat", firs[1]), ("ir_list", firs), ("array_list", firs)):
+        out = ohrir.equalize_all(base, arg)
+        for sp in ("FL", "SR"):
+            for sd in ("left", "right"):
+                np.testing.assert_allclose(out[sp][sd], g[f"heq_{name}_{sp}_{sd}"], rtol=0, atol=1e-12)
+    for name, order, subtype in (("hesuvi", ohrir.HESUVI_TRACK_ORDER, "PCM_32"), ("hexa", None, "PCM_24"),
+                                 ("hexa16", ohrir.HEXADECAGONAL_TRACK_ORDER, "PCM_16")):
+        frames = ohrir.write_wav_frames(base, order)
+        assert tuple(frames.shape) == tuple(g[f"ww_{name}_shape"]) and str(g[f"ww_{name}_subtype"]) == subtype
+        assert np.array_equal(frames[:64], g[f"ww_{name}_head"]) and np.array_equal(frames.sum(axis=0), g[f"ww_{name}_colsum"])
+    # libsndfile's scale (restated from its published source; unpinned by any shipped file: see oracle/hrir.py)
+    q = ohrir.pcm_quantise(np.array([0.0, 0.5, -0.5, 1.0, -1.0, 0.9999999]), 16)
+    assert q.tolist() == [0, 16384, -16384, 32767, -32767, 32767]
+    assert ohrir.pcm_quantise(np.array([1.0, -1.0]), 32).tolist() == [2147483647, -2147483647]
+
+
+def _room_curves_on_grid(path_target, path_cal, fs):
+    """_open_room_target / _open_mic_calibration (core/room_correction.py:431-461): CSV -> log grid 10..fs/2 -> centred"""
+    from oracle import frequency_response as ofr
+    grid = oir.generate_frequencies(10, fs / 2, 1.01)
+    out = []
+    for p in (path_target, path_cal):
+        tab = np.loadtxt(p, delimiter=",", skiprows=1)
+        raw = oir.interpolate_log(tab[:, 0], tab[:, 1], grid)
+        out.append(raw - ofr.center_shift(grid, raw, 1000))
+    return grid, out[0], out[1]
+
+
+@pytest.mark.parametrize("name,method,slimit,glimit,with_generic", [("avg", "average", 400, 300, True),
+                                                                     ("cons", "conservative", 600, 500, True),
+                                                                     ("specific_only", "average", 400, 300, False)])
+def test_room_correction_top_level(golden, tmp_path, name, method, slimit, glimit, with_generic):
+    from scipy.io import wavfile
+    from oracle import frequency_response as ofr
+    g, r2 = golden("round2"), _r2()
+    fs = 48000
+    e = oest.Estimator(1.0, fs)
+    N = len(e)
+    r2.room_folder(str(tmp_path), e.test_signal, with_generic=with_generic)
+    grid, target, cal = _room_curves_on_grid(tmp_path / "room-target.csv", tmp_path / "room-mic-calibration.csv", fs)
+    np.testing.assert_array_equal(grid, g[f"rc_{name}_freq"])
+    col = 2 * fs + N
+    irs = {"FL": {}, "FR": {}}
+    for side in ("left", "right"):
+        track = wavfile.read(tmp_path / f"room-FL,FR-{side}.wav")[1].astype(np.float64) / 2 ** 31
+        for i, sp in enumerate(("FL", "FR")):
+            irs[sp][side] = oir.crop_head(e.estimate(track[2 * fs + i * col: 2 * fs + (i + 1) * col]), fs, 1)
+    tail, cropped = ohrir.crop_tails(irs, fs, N, e.n_octaves)
+    assert tail == int(g[f"rc_{name}_rir_len"])
+    frames = ohrir.write_wav_frames(cropped)
+    assert tuple(frames.shape) == tuple(g[f"rc_{name}_responses_shape"])
+    np.testing.assert_allclose(frames.sum(axis=0), g[f"rc_{name}_responses_colsum"], rtol=0, atol=1e-12)
+    ref_gain = None
+    # the reference walks rir.irs in insertion order = os.listdir order of the room-*.wav files, and levels every
+    # channel to the FIRST one (core/room_correction.py:189-199): the order the golden run saw is part of the fixture
+    for key in g[f"rc_{name}_order"]:
+        sp, sd = str(key).split("-")
+        f, raw, err, ref_gain = ofr.specific_room_correction(cropped[sp][sd], fs, target, cal, slimit, ref_gain)
+        np.testing.assert_allclose(raw, g[f"rc_{name}_{sp}_{sd}_raw"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(err, g[f"rc_{name}_{sp}_{sd}_error"], rtol=0, atol=1e-9)
+    speakers = sorted(str(s) for s in g[f"rc_{name}_speakers"])
+    if not with_generic:
+        assert speakers == ["FL", "FR"]
+        return
+    assert "FC" in speakers and "LFE" not in speakers and len(speakers) == 15
+    track = wavfile.read(tmp_path / "room.wav")[1].astype(np.float64) / 2 ** 31
+    n_cols = int(round((len(track) / fs - 2) / (len(e) / fs + 2)))
+    assert n_cols == 3
+    datas = [oir.crop_head(e.estimate(track[2 * fs + i * col: min(2 * fs + (i + 1) * col, len(track))]), fs, 1)
+             for i in range(n_cols)]
+    f, raw, err, err_s = ofr.generic_room_correction(datas, fs, target, cal, method, glimit)
+    for sp in ("FC", "BL"):
+        for sd in ("left", "right"):                                # every missing speaker gets a copy of the curve
+            np.testing.assert_allclose(raw, g[f"rc_{name}_{sp}_{sd}_raw"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(err, g[f"rc_{name}_{sp}_{sd}_error"], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(err_s, g[f"rc_{name}_{sp}_{sd}_error_smoothed"], rtol=0, atol=1e-9)
