@@ -94,6 +94,19 @@ def read_wav(file_path, expand=False):
     return int(fs), x
 
 
+def pcm_quantise(frames, bit_depth):
+    """float -> PCM integers the way the reference's writer does it.  The reference writes through soundfile /
+    libsndfile with its defaults (core/audio_io.py:82-97): samples are scaled by 2^(bits-1) - 1 (0x7FFF, 0x7FFFFF,
+    0x7FFFFFFF - NOT by 2^(bits-1), the scale its reader divides by), rounded to nearest-even (lrint) and NOT
+    clipped, so anything beyond +-1 wraps around.  libsndfile is not part of the reference tree; its published
+    conversion (src/pcm.c) is restated here and no shipped output file is loud enough to tell the two scales apart
+    (data/demo/room-responses.wav peaks at 0.0033): parity of this step is unpinned."""
+    scale = float(2 ** (bit_depth - 1) - 1)
+    q = np.rint(np.asarray(frames, dtype=np.float64) * scale).astype(np.int64)
+    half = 1 << (bit_depth - 1)
+    return ((q + half) % (1 << bit_depth)) - half
+
+
 def write_wav(file_path, fs, data, bit_depth=32):
     """PCM writer; rows are tracks (reference core/audio_io.py:82-97)."""
     if bit_depth not in (16, 24, 32):
@@ -108,8 +121,7 @@ def write_wav(file_path, fs, data, bit_depth=32):
         data = data.T                                   # frames were on rows already
     nch, nframes = data.shape
     frames = np.ascontiguousarray(data.T)
-    full = 2.0 ** (bit_depth - 1)
-    q = np.clip(np.rint(frames * full), -full, full - 1).astype(np.int64)
+    q = pcm_quantise(frames, bit_depth)
     if bit_depth == 16:
         raw = q.astype("<i2").tobytes()
     elif bit_depth == 32:

@@ -363,9 +363,9 @@ class HRIR(_PlotBase):
         fir = np.asarray(fir)
         if fir.ndim == 1 or fir.shape[0] == 1:
             fir = np.tile(fir, (2, 1))
-        for pair in self.irs.values():
-            for sd, ir in pair.items():
-                ir.equalize(fir[0] if sd == "left" else fir[1])
+        # one batched device convolution for all channels instead of the reference's per-channel loop
+        self.equalize_channels({(sp, sd): (fir[0] if sd == "left" else fir[1])
+                                for sp, pair in self.irs.items() for sd in pair})
 
     # ---- channel balance (core/hrir.py:655-799) ---------------------------------------------
     def channel_balance_firs(self, left_fr, right_fr, method):

@@ -1502,3 +1502,151 @@ def test_xcd_resident_device_buffers_and_pcm(gpu_ctx):
     assert not plan.resident_status()[0]
     plan.close()
     assert rel(got, want.astype(np.float64)) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# Round-2 fixtures (tests/golden/round2.npz, reference run): class-level entry points that had no test
+# ------------------------------------------------------------------------------------------------
+def test_from_wav_estimators_deconvolve_their_own_sweep(gpu_ctx, golden, tmp_path):
+    import round2_inputs as r2
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    g = golden("round2")
+    e1 = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+    for name, sig in (("offgrid", r2.off_grid_sweep()), ("perturbed", r2.perturbed(e1.test_signal, 3e-4))):
+        path = str(tmp_path / (name + ".wav"))
+        r2.write_pcm32(path, 48000, sig)
+        ire = ImpulseResponseEstimator.from_wav(path)
+        imp = np.zeros(len(ire) + 2 * 48000)
+        imp[100: 100 + len(ire)] = ire.test_signal
+        y = ire.estimate(imp)
+        pk = int(np.argmax(np.abs(y)))
+        assert pk == int(g[f"fw_{name}_selfpeak"]) == 100 + len(ire) // 2
+        assert y[pk] == pytest.approx(float(g[f"fw_{name}_selfpeak_value"]), abs=2e-6)
+
+
+def test_impulse_response_convolve_and_adjust_decay_through_the_class(gpu_ctx, golden):
+    import round2_inputs as r2
+    from impulse_hip.impulse_response import ImpulseResponse
+    g = golden("round2")
+    d = r2.decaying_ir(0x1111)
+    x = np.random.default_rng(0x2222).standard_normal(1500).astype(np.float32).astype(np.float64)
+    y = ImpulseResponse(d.copy(), 48000).convolve(x)
+    assert y.shape == g["conv_y"].shape and rel(y, g["conv_y"]) <= TIME_TOL
+    for tgt in (0.2, 0.12):
+        ir = ImpulseResponse(d.copy(), 48000)
+        ir.adjust_decay(tgt)                                      # in place
+        assert rel(ir.data, g[f"adj_{tgt}"]) <= 1e-7
+    ir = ImpulseResponse(d.copy(), 48000)
+    ir.adjust_decay(5.0)                                          # slower than measured: untouched
+    assert np.array_equal(ir.data, d) and bool(g["adj_noop_equal"])
+
+
+def test_hrir_equalize_two_row_fir_and_write_wav_orders(gpu_ctx, golden, tmp_path):
+    import round2_inputs as r2
+    from impulse_hip.audio_io import pcm_quantise
+    from impulse_hip.constants import HESUVI_TRACK_ORDER, HEXADECAGONAL_TRACK_ORDER
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.impulse_response import ImpulseResponse
+    from scipy.io import wavfile
+    g = golden("round2")
+
+    class Est:
+        fs = 48000
+
+    base, firs = r2.hrir_set(), r2.fir_pair()
+
+    def fresh():
+        h = HRIR(Est())
+        h.irs = {sp: {sd: ImpulseResponse(v.copy(), 48000) for sd, v in pair.items()} for sp, pair in base.items()}
+        return h
+
+    for name, arg in (("two_rows", firs), ("one_row", firs[:1]), ("flat", firs[1]),
+                      ("ir_list", [ImpulseResponse(firs[0].copy(), 48000), ImpulseResponse(firs[1].copy(), 48000)]),
+                      ("array_list", [firs[0].copy(), firs[1].copy()])):
+        h = fresh()
+        h.equalize(arg)
+        for sp in ("FL", "SR"):
+            for sd in ("left", "right"):
+                want = g[f"heq_{name}_{sp}_{sd}"]
+                assert h.irs[sp][sd].data.shape == want.shape and rel(h.irs[sp][sd].data, want) <= TIME_TOL
+    h = fresh()
+    for name, order, bits in (("hesuvi", HESUVI_TRACK_ORDER, 32), ("hexa", None, 24), ("hexa16", HEXADECAGONAL_TRACK_ORDER, 16)):
+        path = str(tmp_path / (name + ".wav"))
+        h.write_wav(path, track_order=order, bit_depth=bits)
+        n_frames, n_tracks = (int(v) for v in g[f"ww_{name}_shape"])
+        assert str(g[f"ww_{name}_subtype"]) == f"PCM_{bits}" and int(g[f"ww_{name}_rate"]) == 48000
+        if bits == 24:
+            from impulse_hip.audio_io import read_wav
+            fs, data = read_wav(path)
+            ints = np.rint(data.T * 2.0 ** 23).astype(np.int64)
+        else:
+            fs, ints = wavfile.read(path)
+            ints = ints.astype(np.int64)
+        assert fs == 48000 and ints.shape == (n_frames, n_tracks)
+        # track order + samples: the first 64 frames of the matrix the reference handed to soundfile, quantised
+        assert np.array_equal(ints[:64], pcm_quantise(g[f"ww_{name}_head"], bits))
+        lsb = 2.0 ** -(bits - 1)
+        np.testing.assert_allclose(ints.sum(axis=0) * lsb, g[f"ww_{name}_colsum"], rtol=0, atol=n_frames * lsb)
+
+
+@pytest.mark.parametrize("name,kw,with_generic", [("avg", dict(fr_combination_method="average"), True),
+                                                  ("cons", dict(fr_combination_method="conservative", specific_limit=600,
+                                                                generic_limit=500), True),
+                                                  ("specific_only", dict(), False)])
+def test_room_correction_top_level_with_generic_measurements(gpu_ctx, golden, tmp_path, monkeypatch, name, kw, with_generic):
+    """room_correction() on a folder with one file per ear (FL,FR) and a three-position generic room.wav, both
+    combination methods, against the reference's run of the same folder (core/room_correction.py:78-182, 231-292)."""
+    import round2_inputs as r2
+    from impulse_hip import room_correction as rc
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    g = golden("round2")
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+    r2.room_folder(str(tmp_path), e.test_signal, with_generic=with_generic)
+    # the reference levels every channel to the first one it meets, in os.listdir order: replay the golden run's order
+    wanted = [str(s) for s in g[f"rc_{name}_listdir"]]
+    real_listdir = os.listdir
+    monkeypatch.setattr(rc.os, "listdir", lambda p: wanted + [f for f in real_listdir(p) if f not in wanted])
+    rir, frs = rc.room_correction(e, str(tmp_path), **kw)
+    assert sorted(frs.keys()) == sorted(str(s) for s in g[f"rc_{name}_speakers"])
+    assert [f"{sp}-{sd}" for sp, pair in rir.irs.items() for sd in pair] == [str(s) for s in g[f"rc_{name}_order"]]
+    assert len(rir.irs["FL"]["left"].data) == int(g[f"rc_{name}_rir_len"])
+    assert os.path.isfile(tmp_path / "room-responses.wav")
+    np.testing.assert_array_equal(frs["FL"]["left"].frequency, g[f"rc_{name}_freq"])
+    for sp in ("FL", "FR") + (("FC", "BL") if with_generic else ()):
+        for sd in ("left", "right"):
+            fr = frs[sp][sd]
+            # dB curves from fp32 IRs: 1e-6 of the spectrum peak is ~1e-3 dB on bins 40-60 dB below it
+            assert np.max(np.abs(fr.raw - g[f"rc_{name}_{sp}_{sd}_raw"])) < 5e-3
+            assert np.max(np.abs(fr.error - g[f"rc_{name}_{sp}_{sd}_error"])) < 5e-3
+            if f"rc_{name}_{sp}_{sd}_error_smoothed" in g.files:
+                assert np.max(np.abs(fr.error_smoothed - g[f"rc_{name}_{sp}_{sd}_error_smoothed"])) < 5e-3
+    if with_generic:
+        assert frs["FC"]["left"] is not frs["FC"]["right"]
+        assert np.array_equal(frs["FC"]["left"].error, frs["TBR"]["right"].error)
+
+
+def test_leaked_plan_does_not_abort_interpreter_exit(tmp_path):
+    """A process that exits with live plans / contexts (never closed, kept alive by a global) must end with rc 0: the
+    atexit hook of impulse_hip._native releases them before the HIP runtime's own teardown (ROCm 7.2 aborts with
+    std::bad_variant_access otherwise - the failure commit 8be20fa fixed)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "leak.py"
+    script.write_text(f'''
+import sys
+sys.path.insert(0, {os.path.join(root, "impulcifer-pip313_amd")!r})
+import numpy as np
+from impulse_hip import Context, ConvPlan
+KEEP = []
+ctx = Context(0)
+plan = ConvPlan(ctx, np.ones(100), 5000, "same")
+y = plan.execute(np.ones((2, 5000), np.float32))
+KEEP.extend([ctx, plan, y])
+other = Context(0)
+KEEP.append(ConvPlan(other, np.ones(7), 300, "full"))
+print("leaking", len(KEEP), float(y[0, 2500]))
+''')
+    res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, (res.returncode, res.stderr[-1500:])
+    assert "leaking 4 100.0" in res.stdout

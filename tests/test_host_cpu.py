@@ -126,12 +126,17 @@ def test_wav_codec_roundtrip(tmp_path):
     from impulse_hip.audio_io import read_wav, write_wav
     rng = np.random.default_rng(4)
     x = rng.uniform(-0.9, 0.9, size=(3, 1000))
-    for bits, tol in ((16, 2.0 ** -15), (24, 2.0 ** -23), (32, 2.0 ** -31)):
+    # libsndfile's asymmetry, which the reference inherits through soundfile: written with scale 2^(b-1) - 1, read
+    # with 1 / 2^(b-1): a round trip has gain 1 - 2^-(b-1) on top of the half-LSB rounding
+    for bits in (16, 24, 32):
         p = str(tmp_path / f"t{bits}.wav")
         write_wav(p, 48000, x, bit_depth=bits)
         fs, y = read_wav(p)
         assert fs == 48000 and y.shape == x.shape
-        assert np.max(np.abs(y - x)) <= tol
+        lsb = 2.0 ** -(bits - 1)
+        assert np.max(np.abs(y - x * (1 - lsb))) <= 0.5 * lsb * (1 + 1e-9)
+        from impulse_hip.audio_io import pcm_quantise
+        assert np.array_equal(np.rint(y * 2.0 ** (bits - 1)).astype(np.int64), pcm_quantise(x, bits))
         # scipy reads the same integers
         from scipy.io import wavfile
         if bits != 24:
@@ -343,3 +348,30 @@ def test_bench_rank_mismatch_is_an_error():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                          timeout=120, env=env, cwd=ROOT)
     assert res.returncode != 0 and "WORLD_SIZE=3" in res.stderr
+
+
+def test_product_from_wav_branches(golden, tmp_path):
+    """ImpulseResponseEstimator.from_wav (reference core/impulse_response_estimator.py:234-262), all three branches,
+    against a reference run: off-grid length -> the file's samples become the sweep; on-grid but > 1e-4 away -> same,
+    with a warning; on-grid and equal to PCM rounding -> the generated sweep is kept.  Host fp64 set-up: no GPU."""
+    import round2_inputs as r2
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    g = golden("round2")
+    e1 = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+    cases = {"offgrid": r2.off_grid_sweep(), "perturbed": r2.perturbed(e1.test_signal, 3e-4), "ongrid": e1.test_signal}
+    for name, sig in cases.items():
+        path = str(tmp_path / (name + ".wav"))
+        r2.write_pcm32(path, 48000, sig)
+        ire = ImpulseResponseEstimator.from_wav(path)
+        assert len(ire) == int(g[f"fw_{name}_N"]) and ire.duration == float(g[f"fw_{name}_duration"])
+        assert ire.n_octaves == float(g[f"fw_{name}_P"]) and ire.fs == 48000
+        is_file = np.array_equal(ire.test_signal, r2.to_pcm32(sig).astype(np.float64) / 2 ** 31)
+        assert bool(is_file) == bool(g[f"fw_{name}_sig_is_file"])
+        for got, key in ((ire.inverse_filter[:64], "inv_head"), (ire.inverse_filter[-64:], "inv_tail"),
+                         (ire.inverse_filter[::509], "inv_dec")):
+            np.testing.assert_allclose(got, g[f"fw_{name}_{key}"], rtol=1e-11, atol=0)
+        assert float(np.sum(ire.inverse_filter)) == pytest.approx(float(g[f"fw_{name}_inv_sum"]), rel=1e-9)
+    # a two-track WAV: track 0 is the sweep
+    path = str(tmp_path / "two.wav")
+    r2.write_pcm32(path, 48000, np.vstack([r2.off_grid_sweep(), np.zeros(1 << 17)]))
+    assert len(ImpulseResponseEstimator.from_wav(path)) == 1 << 17
