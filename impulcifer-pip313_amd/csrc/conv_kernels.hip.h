@@ -437,6 +437,38 @@ __global__ __launch_bounds__((MixCfg<F, R2>::T)) void cols_mixed_kernel(Load ld,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Column pass for the short transforms N1 = F in {4, 8} (32 768 / 65 536 real points): K5's everyday size - a 0.7 s
+// response (*) a 9 600-tap equalisation FIR is 43 k samples, a third of the smallest 16-row plan.  One thread owns
+// the F rows of one column; no second stage, no LDS.  256 columns per workgroup.
+// ---------------------------------------------------------------------------------------------
+template <int F, int DIR, class Load, class Store>
+__global__ __launch_bounds__(256) void cols_small_kernel(Load ld, Store st, Twiddles tw, int nchan, int n1_total) {
+  static_assert(F == 4 || F == 8, "short column passes hold 4 or 8 rows per thread");
+  int b, tile;
+  xcd_work_item(nchan, tile, b);
+  const unsigned n2 = (unsigned)(tile * 256 + threadIdx.x);
+  const __amdgpu_buffer_rsrc_t r_full = make_rsrc(tw.full, (unsigned)n1_total * kN2 * 8u);
+  const __amdgpu_buffer_rsrc_t r_out = st.bind(b);
+  cf twd[F];
+#pragma unroll
+  for (int k = 0; k < F; ++k) twd[k] = bload_cf(r_full, n2 * 8u, (unsigned)(k * kN2) * 8u);
+  cf v[F];
+  ld.template column<kN2, F>(b, n2, v);
+  if constexpr (DIR > 0) {
+#pragma unroll
+    for (int k = 0; k < F; ++k) v[k] = cmulc(v[k], twd[k]);
+  }
+  if constexpr (F == 8) fft8<DIR>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+  else bfly4<DIR>(v[0], v[1], v[2], v[3]);
+#pragma unroll
+  for (int k = 0; k < F; ++k) {
+    cf z = v[k];
+    if constexpr (DIR < 0) z = cmul(z, twd[k]);
+    st.put(r_out, n2, (unsigned)(k * kN2), z);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row pass (pass B).  One workgroup = 512 threads = two rows (k1, N1-k1), or the two
 // self-paired rows (0, N1/2) when pair == 0.  Everything between the load and the store of a
 // row happens in registers + 68 KiB of LDS:

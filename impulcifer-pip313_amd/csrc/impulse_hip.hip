@@ -442,8 +442,20 @@ static int launch_cols_mixed(imp_plan* p, int64_t nchan, Load ld, Store st) {
   return IMP_OK;
 }
 
+template <int F, int DIR, class Load, class Store>
+static int launch_cols_small(imp_plan* p, int64_t nchan, Load ld, Store st) {
+  imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
+  dim3 grid((unsigned)(nchan * (imp::kN2 / 256))), block(256);
+  hipLaunchKernelGGL((imp::cols_small_kernel<F, DIR, Load, Store>), grid, block, 0, p->cur_stream, ld, st, tw, (int)nchan,
+                     (int)p->N1);
+  HIP_TRY(hipGetLastError());
+  return IMP_OK;
+}
+
 template <int DIR, class Load, class Store>
 static int launch_cols_any(imp_plan* p, int64_t nchan, Load ld, Store st) {
+  if (p->R2 == 1 && p->F == 4) return launch_cols_small<4, DIR>(p, nchan, ld, st);
+  if (p->R2 == 1 && p->F == 8) return launch_cols_small<8, DIR>(p, nchan, ld, st);
   if (p->F == 8) {
     switch (p->R2) {
       case 3: return launch_cols_mixed<8, 3, DIR>(p, nchan, ld, st);
@@ -499,15 +511,17 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   const int64_t full = L + M - 1;
   const int64_t need = (mode == IMP_MODE_SAME) ? std::max(L + M / 2, M) : full;
   // N1 = F * R2 rows of 4096 complex points, ascending; F = rows per thread in the column passes
-  static const struct { int f, r2; } kShapes[] = {{16, 1}, {8, 3},  {16, 2}, {8, 5},  {16, 3},  {16, 4},  {8, 9},
+  static const struct { int f, r2; } kShapes[] = {{4, 1},  {8, 1},  {16, 1}, {8, 3},  {16, 2}, {8, 5},  {16, 3},  {16, 4},  {8, 9},
                                                   {16, 5}, {16, 6}, {16, 8}, {16, 9}, {16, 10}, {16, 12}, {16, 16}};
   int r2 = 0, f1 = 16;
+  const char* min_rows_env = std::getenv("IMPULSE_HIP_MIN_ROWS");             // experiments: 16 = the round-1 smallest plan
+  const int min_rows = min_rows_env ? atoi(min_rows_env) : 0;
   const bool pow2_only = std::getenv("IMPULSE_HIP_POW2_ONLY") != nullptr;     // debug/experiments
   const bool no_wrap = std::getenv("IMPULSE_HIP_NO_WRAP") != nullptr;
   const int64_t need_eff = no_wrap ? full : need;
   for (const auto& sh : kShapes) {
     const int n1 = sh.f * sh.r2;
-    if ((!pow2_only || (n1 & (n1 - 1)) == 0) && (int64_t)n1 * 2 * imp::kN2 >= need_eff) {
+    if (n1 >= min_rows && (!pow2_only || (n1 & (n1 - 1)) == 0) && (int64_t)n1 * 2 * imp::kN2 >= need_eff) {
       r2 = sh.r2;
       f1 = sh.f;
       break;
@@ -656,6 +670,26 @@ extern "C" int imp_conv_plan_create(imp_ctx* ctx, const double* filter, int64_t 
   return IMP_OK;
 }
 
+extern "C" int imp_plan_set_filters(imp_plan* p, const double* filter, int64_t filter_ld) {
+  if (!p || !filter) return fail(IMP_ERR_INVALID, "imp_plan_set_filters: null argument");
+  IMP_CTX_LOCK(p->ctx);
+  if (p->n_filters > 1 && filter_ld < p->M) return fail(IMP_ERR_INVALID, "filter_ld < M");
+  int rc = ctx_bind(p->ctx);
+  if (rc) return rc;
+  if ((rc = plan_sync_lanes(p))) return rc;
+  const int64_t ld = p->n_filters > 1 ? filter_ld : p->M;
+  if (!p->ola) return spectrum_alpha_beta_device(p->ctx, filter, p->M, p->n_filters, ld, p->Nc, p->N1, p->ab);
+  const size_t plane = (size_t)p->N1 * imp::kN2;
+  for (int64_t j = 0; j < p->ola_parts; ++j) {
+    const int64_t m0 = j * p->ola_mp, mj = std::min(p->ola_mp, p->M - m0);
+    for (int64_t f = 0; f < p->n_filters; ++f)
+      if ((rc = spectrum_alpha_beta_device(p->ctx, filter + f * ld + m0, mj, 1, mj, p->Nc, p->N1,
+                                           p->ab + (size_t)(f * p->ola_parts + j) * plane)))
+        return rc;
+  }
+  return IMP_OK;
+}
+
 extern "C" int imp_debug_plan_geometry(int64_t M, int64_t L, int mode, int64_t* nfft, int64_t* out_start,
                                        int64_t* out_len) {
   imp_plan tmp;
@@ -668,7 +702,7 @@ extern "C" int imp_debug_plan_geometry(int64_t M, int64_t L, int mode, int64_t* 
 }
 
 extern "C" int imp_debug_host_spectrum(const double* filter, int64_t M, int n1_rows, float* ab_out) {
-  if (!filter || !ab_out || M < 1 || n1_rows < 16 || n1_rows % 8) return fail(IMP_ERR_INVALID, "imp_debug_host_spectrum: bad argument");
+  if (!filter || !ab_out || M < 1 || n1_rows < 4 || n1_rows % 4) return fail(IMP_ERR_INVALID, "imp_debug_host_spectrum: bad argument");
   const int64_t Nc = (int64_t)n1_rows * imp::kN2;
   if (M > 2 * Nc) return fail(IMP_ERR_INVALID, "filter longer than the transform");
   std::vector<cd> H;

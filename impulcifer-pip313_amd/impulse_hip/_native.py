@@ -73,6 +73,7 @@ SIGNATURES = {
     "imp_conv_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64]),
     "imp_conv_execute_device_pcm": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _i64]),
     "imp_plan_set_overlap": (C.c_int, [_vp, C.c_int]),
+    "imp_plan_set_filters": (C.c_int, [_vp, _pd, _i64]),
     "imp_plan_set_resident": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "imp_plan_resident_status": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong)]),
     "imp_plan_set_timing": (C.c_int, [_vp, C.c_int]),
@@ -503,6 +504,15 @@ class ConvPlan:
         """lanes > 1: successive launch groups of execute_device overlap on that many streams (inputs must
         be ready before each call; outputs are complete after ctx.synchronize())."""
         _check(self._lib.imp_plan_set_overlap(self._h, int(lanes)))
+
+    def set_filters(self, filt):
+        """New filter(s) of the same shape for this plan (recomputes the spectra on the device, in place)."""
+        f = np.ascontiguousarray(filt, dtype=np.float64)
+        if f.ndim == 1:
+            f = f[None, :]
+        if f.shape != (self.n_filters, self.M):
+            raise ValueError(f"plan holds {self.n_filters} filter(s) of {self.M} taps, got {f.shape}")
+        _check(self._lib.imp_plan_set_filters(self._h, f.ctypes.data_as(_pd), self.M))
 
     def resident_available(self):
         """True if this plan qualifies for the XCD-resident path (one channel's workspace fits an XCD's L2)."""

@@ -19,18 +19,44 @@ except Exception:                               # noqa: BLE001
 EPSILON = 1e-20
 
 
+class _PlanCache:
+    """K5 plans kept per shape (signal length, taps, channels): the FIRs change with every measurement, the shapes do
+    not, so a plan - workspace, tables, staging buffers - is made once per shape and only its filter spectra are
+    recomputed (imp_plan_set_filters).  A handful of shapes live at a time; the least recently used plan goes first."""
+
+    def __init__(self, capacity=8):
+        import threading
+        self.capacity = capacity
+        self.lock = threading.Lock()          # set_filters + execute of one plan is one critical section
+        self.plans = {}                       # key -> plan, in LRU order
+
+    def run(self, signals, taps):
+        ctx = _native.default_context()
+        key = (id(ctx), signals.shape[1], taps.shape[1], signals.shape[0])
+        with self.lock:
+            plan = self.plans.pop(key, None)
+            if plan is not None and not plan._h:                  # closed behind our back (context torn down)
+                plan = None
+            if plan is None:
+                plan = _native.ConvPlan(ctx, taps, signals.shape[1], "full", ws_channels=signals.shape[0])
+            else:
+                plan.set_filters(taps)
+            self.plans[key] = plan
+            while len(self.plans) > self.capacity:
+                self.plans.pop(next(iter(self.plans))).close()
+            return plan.execute(signals)
+
+
+_k5_plans = _PlanCache()
+
+
 def fir_convolve_full(x, taps):
     """scipy.signal.convolve(x, taps, 'full') on the device (K5)."""
     x = np.asarray(x)
     taps = np.asarray(taps, dtype=np.float64)
     if len(x) == 0 or len(taps) == 0:
         return np.zeros(0)
-    ctx = _native.default_context()
-    plan = _native.ConvPlan(ctx, taps, len(x), "full")
-    try:
-        return plan.execute(x).astype(np.float64)
-    finally:
-        plan.close()
+    return _k5_plans.run(x[None, :], taps[None, :])[0].astype(np.float64)
 
 
 def fir_convolve_full_batch(signals, taps):
@@ -47,16 +73,8 @@ def fir_convolve_full_batch(signals, taps):
             out[i] = np.zeros(0)
         else:
             groups.setdefault((len(x), len(h)), []).append(i)
-    ctx = _native.default_context()
-    for (n, m), idx in groups.items():
-        if len(idx) == 1:
-            out[idx[0]] = fir_convolve_full(xs[idx[0]], hs[idx[0]])
-            continue
-        plan = _native.ConvPlan(ctx, np.stack([hs[i] for i in idx]), n, "full", ws_channels=len(idx))
-        try:
-            y = plan.execute(np.stack([xs[i] for i in idx]))
-        finally:
-            plan.close()
+    for idx in groups.values():
+        y = _k5_plans.run(np.stack([xs[i] for i in idx]), np.stack([hs[i] for i in idx]))
         for row, i in zip(y, idx):
             out[i] = row.astype(np.float64)
     return out

@@ -120,6 +120,12 @@ int imp_conv_execute_device_pcm(imp_plan* plan, const void* d_pcm, int bits, int
  * in flight must not write the same output memory.  lanes = 1 restores strict stream order. */
 int imp_plan_set_overlap(imp_plan* plan, int lanes);
 
+/* Replace the filter(s) of an existing plan: same M, n_filters, L and mode as at creation; `filter` is host fp64,
+ * filter f at filter + f*filter_ld.  The alpha/beta planes are recomputed on the device in place (work in flight is
+ * drained first), so a caller can keep ONE plan - workspace, tables, buffers - per shape and refill it whenever the
+ * FIRs change: HRIR.equalize_channels gets new FIRs for every measurement (core/pipeline.py:690-691). */
+int imp_plan_set_filters(imp_plan* plan, const double* filter, int64_t filter_ld);
+
 /* XCD-resident execution (one persistent launch per call instead of three launches per group): available when one
  * channel's workspace (nfft * 4 bytes) fits an XCD's 4 MiB L2 beside the tables, i.e. nfft <= 589 824 (the 7.1 x
  * 6.15 s configuration), on a device that exposes all 8 XCDs.  Channel c is processed on XCD c mod 8 and its

@@ -153,6 +153,13 @@ def pass_c(ws, nfft, start, length):
     k1 = np.arange(N1)[:, None]
     n2 = np.arange(N2)[None, :]
     v = ws * np.conj(w(n2, k1, Nc))
+    if N1 % 16:
+        # short (4, 8 rows) and 8 x R2 shapes: whatever the staging, the result is the column IDFT
+        y = (np.fft.ifft(v, axis=0) * N1).reshape(-1)
+        full = np.empty(nfft)
+        full[0::2] = y.real
+        full[1::2] = y.imag
+        return full[start:start + length]
     # thread (g, col) holds rows k1 = g + R2*j
     v = v.reshape(16, R2, N2)                                   # [j][g][col]
     a = np.fft.ifft(v, axis=0) * 16                             # over j -> oa
@@ -169,7 +176,7 @@ def pass_c(ws, nfft, start, length):
 
 
 # N1 = F*R2 rows of 4096 complex points (F = rows per thread in the column passes) -> nfft = 8192*N1
-SUPPORTED_N1 = (16, 24, 32, 40, 48, 64, 72, 80, 96, 128, 144, 160, 192, 256)
+SUPPORTED_N1 = (4, 8, 16, 24, 32, 40, 48, 64, 72, 80, 96, 128, 144, 160, 192, 256)
 
 
 def pick_nfft(L, M, mode="same"):

@@ -49,8 +49,8 @@ def spec_rel_cropped(y, ref, fs=48000, n=None):
 # K1/K5: convolution plans against the oracle
 # ------------------------------------------------------------------------------------------------
 # sizes chosen to hit every column shape N1 = F x R2 (nfft = 8192 N1) in at least one mode:
-# 'same': N1 = 16, 16, 16, 16, 32, 40, 72, 96, 144, 24, 48, 64, 80, 128 ; 'full': 16, 16, 16, 32, 32, 48, 96, 128, 192, 32, 48, 80, 96, 160
-@pytest.mark.parametrize("L,M", [(1, 1), (17, 5), (1000, 999), (70001, 61000), (150000, 100001),
+# 'same': N1 = 4, 4, 4, 4, 8, 16, 32, 40, 72, 96, 144, 24, 48, 64, 80, 128 ; 'full': 4, 4, 4, 4, 8, 16, 32, 32, 48, 96, 128, 192, 32, 48, 80, 96, 160
+@pytest.mark.parametrize("L,M", [(1, 1), (17, 5), (1000, 999), (20000, 9600), (32640, 9600), (70001, 61000), (150000, 100001),
                                  (243635, 147635), (391270, 295270), (500000, 400000), (827965, 635965),
                                  (150000, 80000), (300000, 150000), (420000, 200000), (500000, 300000), (800000, 400000)])
 @pytest.mark.parametrize("mode", ["same", "full"])
@@ -1650,3 +1650,45 @@ print("leaking", len(KEEP), float(y[0, 2500]))
     res = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, (res.returncode, res.stderr[-1500:])
     assert "leaking 4 100.0" in res.stdout
+
+
+def test_k5_short_plans_and_filter_refill(gpu_ctx):
+    """K5 at its everyday size: a 0.68 s response (*) a 9 600-tap FIR is 42 239 samples -> a 65 536-point transform
+    (8 rows), a third of the smallest round-1 plan; per-channel FIRs refilled in place (imp_plan_set_filters) give the
+    bits of a fresh plan; the class-level entry points reuse one cached plan per shape."""
+    from impulse_hip import ConvPlan
+    from impulse_hip import impulse_response as irm
+    from oracle.scipy_restated import fft_convolve
+    rng = np.random.default_rng(55)
+    n, k, B = 32640, 9600, 6
+    x = rng.standard_normal((B, n)).astype(np.float32)
+    fa = rng.standard_normal((B, k)) * np.exp(-np.arange(k) / 700.0)
+    fb = rng.standard_normal((B, k)) * np.exp(-np.arange(k) / 300.0)
+    plan = ConvPlan(gpu_ctx, fa, n, "full", ws_channels=B)
+    assert (plan.n1, plan.nfft) == (8, 65536)
+    ya = plan.execute(x)
+    plan.set_filters(fb)
+    yb = plan.execute(x)
+    plan.set_filters(fa)
+    assert np.array_equal(plan.execute(x), ya)
+    plan.close()
+    fresh = ConvPlan(gpu_ctx, fb, n, "full", ws_channels=B)
+    assert np.array_equal(fresh.execute(x), yb)
+    fresh.close()
+    for b in (0, B - 1):
+        assert rel(ya[b], fft_convolve(x[b].astype(np.float64), fa[b], "full")) <= TIME_TOL
+        assert rel(yb[b], fft_convolve(x[b].astype(np.float64), fb[b], "full")) <= TIME_TOL
+    small = ConvPlan(gpu_ctx, fa[0, :3000], 20000, "full")
+    assert (small.n1, small.nfft) == (4, 32768)
+    assert rel(small.execute(x[0, :20000]), fft_convolve(x[0, :20000].astype(np.float64), fa[0, :3000], "full")) <= TIME_TOL
+    with pytest.raises(ValueError):
+        small.set_filters(fa[0])
+    small.close()
+    # class-level calls: same shape, new taps every call -> one plan, refilled
+    irm._k5_plans.plans.clear()
+    for i in range(3):
+        y = irm.fir_convolve_full(x[i].astype(np.float64), fa[i])
+        assert rel(y, fft_convolve(x[i].astype(np.float64), fa[i], "full")) <= TIME_TOL
+    assert len(irm._k5_plans.plans) == 1
+    ys = irm.fir_convolve_full_batch([x[i].astype(np.float64) for i in range(B)], [fb[i] for i in range(B)])
+    assert len(irm._k5_plans.plans) == 2 and all(rel(ys[i], yb[i].astype(np.float64)) <= 1e-7 for i in range(B))

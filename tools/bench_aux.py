@@ -33,6 +33,22 @@ def main():
         x = rng.standard_normal((B, n))
         ms = timeit(lambda: ctx.magnitude_db(x), reps)
         print(f"K2 magnitude_db  B={B} n={n}: {ms:.3f} ms per batch")
+    # K5: 16 x (32 640-sample response (*) 9 600-tap FIR) at C2, 26 x (65 280 (*) 19 200) at C3: device time of one
+    # launch group (HIP events of the plan) and the wall time of the host-array call around it; IMPULSE_HIP_MIN_ROWS=16
+    # reproduces the round-1 plan (smallest transform 131 072 points)
+    from impulse_hip import ConvPlan
+    for n, k, B in ((32640, 9600, 16), (65280, 19200, 26)):
+        x = rng.standard_normal((B, n)).astype(np.float32)
+        firs = rng.standard_normal((B, k)) * np.exp(-np.arange(k) / 800.0)
+        plan = ConvPlan(ctx, firs, n, "full", ws_channels=B)
+        plan.set_timing(1)
+        ms = timeit(lambda: plan.execute(x), reps)
+        kms, launches = plan.get_timing()
+        ms_set = timeit(lambda: plan.set_filters(firs), reps)
+        print(f"K5 equalize      B={B} n={n} taps={k}: nfft {plan.nfft} ({plan.n1} rows), device {sum(kms) / launches * 1e3:.1f} us "
+              f"per launch group (A/B/C {kms[0] / launches * 1e3:.1f}/{kms[1] / launches * 1e3:.1f}/{kms[2] / launches * 1e3:.1f}), "
+              f"{ms:.3f} ms per host call, set_filters {ms_set:.3f} ms")
+        plan.close()
     for n, B in ((391270, 16),):
         rows = [rng.standard_normal(n).astype(np.float32) for _ in range(B)]
         ms = timeit(lambda: ctx.peak_index(rows), reps)
