@@ -10,8 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libimpulse_hip.so")
-SOURCES = ["impulse_hip.hip", "minphase.hip"]
-HEADERS = ["conv_kernels.hip.h", "fft_regs.hip.h", "ir_kernels.hip.h", "internal.h",
+SOURCES = ["impulse_hip.hip", "minphase.hip", "curves.hip"]
+HEADERS = ["conv_kernels.hip.h", "xcd_kernels.hip.h", "fft_regs.hip.h", "ir_kernels.hip.h", "internal.h",
            os.path.join("..", "..", "include", "impulse_hip.h")]
 
 

@@ -287,25 +287,33 @@ static int run_fft(imp_ctx* ctx, const std::vector<int>& fac, const cdbl* roots,
   return IMP_OK;
 }
 
-static int minphase_run(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, double* fir_out, int stage);
+static int minphase_run(imp_ctx* ctx, const double* gain, const double* d_gain, int64_t B, int64_t n, double fs,
+                        double* fir_out, int stage);
 
 extern "C" int imp_minphase_fir(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, double* fir_out) {
-  return minphase_run(ctx, gain, B, n, fs, fir_out, 2);
+  return minphase_run(ctx, gain, nullptr, B, n, fs, fir_out, 2);
+}
+
+// the gains are already on the device (curves.hip: the FIR design grid computed from the equalisation curves there;
+// its last column is zero by construction)
+int minphase_fir_from_device_gain(imp_ctx* ctx, const double* d_gain, int64_t B, int64_t n, double fs, double* fir_out_host) {
+  return minphase_run(ctx, nullptr, d_gain, B, n, fs, fir_out_host, 2);
 }
 
 extern "C" int imp_debug_minphase_stage(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, int stage,
                                         double* out) {
   if (stage < 0 || stage > 1) return fail(IMP_ERR_INVALID, "stage must be 0 (firwin2 taps) or 1 (|FFT| of the taps)");
-  return minphase_run(ctx, gain, B, n, fs, out, stage);
+  return minphase_run(ctx, gain, nullptr, B, n, fs, out, stage);
 }
 
 // stage 0: out[B][2n] = firwin2 taps; stage 1: out[B][2n] = |FFT_2n(taps)|; stage 2: out[B][n] = FIR
-static int minphase_run(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, double* fir_out, int stage) {
-  if (!ctx || (B && (!gain || !fir_out))) return fail(IMP_ERR_INVALID, "imp_minphase_fir: null argument");
+static int minphase_run(imp_ctx* ctx, const double* gain, const double* d_gain, int64_t B, int64_t n, double fs,
+                        double* fir_out, int stage) {
+  if (!ctx || (B && ((!gain && !d_gain) || !fir_out))) return fail(IMP_ERR_INVALID, "imp_minphase_fir: null argument");
   if (B < 0 || n < 2 || n > (1 << 20)) return fail(IMP_ERR_INVALID, "imp_minphase_fir: bad B or n");
   if (!(fs > 0)) return fail(IMP_ERR_INVALID, "imp_minphase_fir: fs must be positive");
   if (B == 0) return IMP_OK;
-  for (int64_t b = 0; b < B; ++b)
+  for (int64_t b = 0; gain && b < B; ++b)
     if (gain[b * n + n - 1] != 0.0)
       return fail(IMP_ERR_INVALID, "A Type II filter must have zero gain at the Nyquist frequency (channel %lld)", (long long)b);
   IMP_CTX_LOCK(ctx);                               // plan buffers are shared by all callers of this context
@@ -359,7 +367,8 @@ static int minphase_run(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, 
     p->cap = B;
   }
   hipStream_t s = ctx->stream;
-  HIP_TRY(hipMemcpyAsync(p->gain, gain, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, s));
+  if (gain) HIP_TRY(hipMemcpyAsync(p->gain, gain, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, s));
+  else HIP_TRY(hipMemcpyAsync(p->gain, d_gain, (size_t)B * n * sizeof(double), hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipMemsetAsync(p->minbits, 0xFF, (size_t)B * sizeof(unsigned long long), s));
   auto grid_for = [&](int count) { return dim3((unsigned)((count + 255) / 256), (unsigned)B); };
   cdbl *cur = p->a, *oth = p->b;

@@ -88,6 +88,16 @@ SIGNATURES = {
     "imp_sosfilt": (C.c_int, [_vp, _pd, _i64, _pd, _pi64, _pi64, _i64, _pd]),
     "imp_xcorr_argmax": (C.c_int, [_vp, _pd, _pi64, _pi64, _pd, _pi64, _pi64, _i64, _pi64, _pd]),
     "imp_minphase_fir": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, _pd]),
+    "imp_curves_create": (C.c_int, [_vp, _pd, _i64, C.POINTER(_vp)]),
+    "imp_curves_destroy": (None, [_vp]),
+    "imp_curves_window_size": (C.c_int, [_vp, C.c_double, C.POINTER(C.c_int)]),
+    "imp_curves_smooth": (C.c_int, [_vp, _pd, _i64, C.c_double, C.c_double, C.c_double, C.c_double, _pd]),
+    "imp_curves_equalization": (C.c_int, [_vp, _pd, _i64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                          C.c_double, C.c_int, _pd, _pd, C.POINTER(C.c_int)]),
+    "imp_curves_fir_taps": (C.c_int, [_vp, C.c_double, C.c_double, _pi64]),
+    "imp_curves_fir": (C.c_int, [_vp, _pd, _i64, C.c_double, C.c_double, C.c_int, _pd, _pd]),
+    "imp_curves_equalization_fir": (C.c_int, [_vp, _pd, _i64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                              C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, _pd, _pd]),
     "imp_magnitude_db": (C.c_int, [_vp, _pd, _i64, _i64, _pd]),
     "imp_debug_minphase_stage": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, C.c_int, _pd]),
     "imp_peak_index": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
@@ -396,6 +406,98 @@ class SegSet:
         if getattr(self, "_h", None):
             if getattr(self.ctx, "_h", None):
                 self._lib.imp_segset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+class Curves:
+    """K12: curve conditioning on one frequency grid (imp_curves): batched [B, n] fp64 dB curves in, out."""
+
+    def __init__(self, ctx, frequency):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        f = np.ascontiguousarray(frequency, dtype=np.float64)
+        self.n = len(f)
+        h = _vp()
+        _check(self._lib.imp_curves_create(ctx.handle, f.ctypes.data_as(_pd), self.n, C.byref(h)))
+        self._h = h
+        ctx._plans.add(self)
+
+    def _rows(self, x):
+        a = np.ascontiguousarray(x, dtype=np.float64)
+        one = a.ndim == 1
+        if one:
+            a = a[None, :]
+        if a.ndim != 2 or a.shape[1] != self.n:
+            raise ValueError(f"curves must be [B, {self.n}], got {a.shape}")
+        return a, one
+
+    def window_size(self, octaves):
+        w = C.c_int(0)
+        _check(self._lib.imp_curves_window_size(self._h, float(octaves), C.byref(w)))
+        return w.value
+
+    def smooth(self, x, window_oct, treble_window_oct, treble_f_lower, treble_f_upper):
+        a, one = self._rows(x)
+        y = np.empty_like(a)
+        _check(self._lib.imp_curves_smooth(self._h, a.ctypes.data_as(_pd), a.shape[0], float(window_oct),
+                                           float(treble_window_oct), float(treble_f_lower), float(treble_f_upper),
+                                           y.ctypes.data_as(_pd)))
+        return y[0] if one else y
+
+    def equalization(self, error, smoothen_first, max_gain, treble_f_lower, treble_f_upper, treble_max_gain, treble_gain_k,
+                     smoothen_kinks=True):
+        """(error_smoothed, equalization, spline_used[B]) of autoeq's smoothen_heavy_light (optional) + equalize"""
+        a, one = self._rows(error)
+        es, eq = np.empty_like(a), np.empty_like(a)
+        used = np.zeros(a.shape[0], dtype=np.int32)
+        _check(self._lib.imp_curves_equalization(self._h, a.ctypes.data_as(_pd), a.shape[0], 1 if smoothen_first else 0,
+                                                 float(max_gain), float(treble_f_lower), float(treble_f_upper),
+                                                 float(treble_max_gain), float(treble_gain_k), 1 if smoothen_kinks else 0,
+                                                 es.ctypes.data_as(_pd), eq.ctypes.data_as(_pd),
+                                                 used.ctypes.data_as(C.POINTER(C.c_int))))
+        return (es[0], eq[0], used) if one else (es, eq, used)
+
+    def fir_taps(self, fs, f_res):
+        n = _i64()
+        _check(self._lib.imp_curves_fir_taps(self._h, float(fs), float(f_res), C.byref(n)))
+        return n.value
+
+    def fir(self, equalization, fs, f_res, normalize, want_gain=False):
+        a, one = self._rows(equalization)
+        taps = self.fir_taps(fs, f_res)
+        fir = np.empty((a.shape[0], taps), dtype=np.float64)
+        gain = np.empty_like(fir) if want_gain else None
+        _check(self._lib.imp_curves_fir(self._h, a.ctypes.data_as(_pd), a.shape[0], float(fs), float(f_res),
+                                        1 if normalize else 0, gain.ctypes.data_as(_pd) if want_gain else None,
+                                        fir.ctypes.data_as(_pd)))
+        if want_gain:
+            return (fir[0], gain[0]) if one else (fir, gain)
+        return fir[0] if one else fir
+
+    def equalization_fir(self, error, smoothen_first, max_gain, treble_f_lower, treble_f_upper, treble_max_gain,
+                         treble_gain_k, fs, f_res, normalize, smoothen_kinks=True):
+        """error curves -> (equalization [B, n], FIR [B, taps]) in one device chain"""
+        a, one = self._rows(error)
+        taps = self.fir_taps(fs, f_res)
+        eq = np.empty_like(a)
+        fir = np.empty((a.shape[0], taps), dtype=np.float64)
+        _check(self._lib.imp_curves_equalization_fir(self._h, a.ctypes.data_as(_pd), a.shape[0], 1 if smoothen_first else 0,
+                                                     float(max_gain), float(treble_f_lower), float(treble_f_upper),
+                                                     float(treble_max_gain), float(treble_gain_k),
+                                                     1 if smoothen_kinks else 0, float(fs), float(f_res),
+                                                     1 if normalize else 0, eq.ctypes.data_as(_pd), fir.ctypes.data_as(_pd)))
+        return (eq[0], fir[0]) if one else (eq, fir)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if getattr(self.ctx, "_h", None):
+                self._lib.imp_curves_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -1,16 +1,17 @@
 """FrequencyResponse: the part of the reference's vendored AutoEQ class that the hot path touches
-(autoeq/frequency_response.py): the log grid, log-linear interpolation, centring, target
-compensation, fractional-octave smoothing, gain-limited equalisation and the equalisation curve ->
-minimum-phase FIR step.
+(autoeq/frequency_response.py): the log grid, log-linear interpolation, centring, target compensation,
+fractional-octave smoothing, gain-limited equalisation and the equalisation curve -> minimum-phase FIR step.
 
-Curve conditioning works on ~800-point dB curves and stays on the host (NumPy, plus SciPy's
-Savitzky-Golay filter and quadratic spline, which the reference itself calls); the FIR design - four
-19 200/38 400-point transforms per channel - runs on the GPU in fp64 (kernel K6), batched over all
-speaker-ear channels.  The parametric-EQ optimiser, file writers and plots of the AutoEQ class are
-outside the path and not provided.
+Curves are handled as [B, n] float64 matrices on a shared grid: the module-level functions below take every
+speaker-ear curve of a measurement at once and run the arithmetic on the device (kernel K12, csrc/curves.hip:
+Savitzky-Golay smoothing as a fixed linear operator per window, logistic blends, the gain-limited inversion with its
+quadratic-spline kink bridge, the FIR design grid) chained into the minimum-phase FIR design (K6).  The class keeps the
+reference's per-object surface and calls the same functions with B = 1.  Re-gridding and centring are linear maps
+that depend on the two grids only; they are evaluated as one gather + lerp over the whole matrix.  The parametric-EQ
+optimiser, file writers and plots of the AutoEQ class are outside the path and not provided.
 """
 import math
-import warnings
+import threading
 
 import numpy as np
 
@@ -67,37 +68,102 @@ def log_interp(frequency, values, f_new):
     return yk[idx] + t * (yk[idx + 1] - yk[idx])
 
 
+class _Regrid:
+    """log_interp from one grid onto another as (index, weight) pairs: built once per pair of grids, applied to any
+    [B, n] matrix of curves with one gather and one lerp."""
+
+    def __init__(self, frequency, f_new):
+        xk = np.log10(np.asarray(frequency, dtype=np.float64))
+        fq = np.array(f_new, dtype=np.float64)
+        fq[fq == 0] = 0.001
+        xq = np.log10(fq)
+        self.idx = np.clip(np.searchsorted(xk, xq, side="right") - 1, 0, len(xk) - 2)
+        self.t = (xq - xk[self.idx]) / (xk[self.idx + 1] - xk[self.idx])
+
+    def __call__(self, curves):
+        y = np.asarray(curves, dtype=np.float64)
+        lo, hi = y[..., self.idx], y[..., self.idx + 1]
+        return lo + self.t * (hi - lo)
+
+
+_DEFAULT_GRID = None
+
+
+def center_shifts(frequency, raws, at=1000):
+    """What FrequencyResponse.center subtracts from each row of ``raws`` [B, n] (autoeq :903-940): the curve is read
+    on the default 20 Hz..20 kHz grid; ``at`` = one frequency (value there) or [f0, f1] (mean between them)."""
+    global _DEFAULT_GRID
+    if _DEFAULT_GRID is None:
+        _DEFAULT_GRID = generate_frequencies()
+    on_grid = _Regrid(frequency, _DEFAULT_GRID)(np.atleast_2d(raws))
+    if isinstance(at, (list, tuple, np.ndarray)) and len(at) > 1:
+        band = np.logical_and(_DEFAULT_GRID >= at[0], _DEFAULT_GRID <= at[1])
+        return np.mean(on_grid[:, band], axis=1)
+    if isinstance(at, (list, tuple, np.ndarray)):
+        at = at[0]
+    return _Regrid(_DEFAULT_GRID, [at])(on_grid)[:, 0]
+
+
+_curves_lock = threading.Lock()
+_curves_by_grid = {}
+
+
+def curves_for(frequency):
+    """The device handle (K12) of a frequency grid; grids are few (one per sampling rate), handles are kept."""
+    f = np.ascontiguousarray(frequency, dtype=np.float64)
+    ctx = _native.default_context()
+    key = (id(ctx), f.tobytes())
+    with _curves_lock:
+        h = _curves_by_grid.get(key)
+        if h is None or not h._h:
+            h = _native.Curves(ctx, f)
+            _curves_by_grid[key] = h
+            while len(_curves_by_grid) > 8:
+                _curves_by_grid.pop(next(iter(_curves_by_grid))).close()
+        return h
+
+
+def smooth_curves(frequency, curves, window_size=DEFAULT_SMOOTHING_WINDOW_SIZE,
+                  treble_window_size=DEFAULT_TREBLE_SMOOTHING_WINDOW_SIZE,
+                  treble_f_lower=DEFAULT_TREBLE_SMOOTHING_F_LOWER, treble_f_upper=DEFAULT_TREBLE_SMOOTHING_F_UPPER):
+    """_smoothen_fractional_octave (autoeq :1060-1105, one iteration per window) of every row of ``curves``."""
+    return curves_for(frequency).smooth(curves, window_size, treble_window_size, treble_f_lower, treble_f_upper)
+
+
+def equalization_curves(frequency, errors, smoothen_first=True, max_gain=DEFAULT_MAX_GAIN,
+                        treble_f_lower=DEFAULT_TREBLE_F_LOWER, treble_f_upper=DEFAULT_TREBLE_F_UPPER,
+                        treble_max_gain=DEFAULT_TREBLE_MAX_GAIN, treble_gain_k=DEFAULT_TREBLE_GAIN_K, smoothen=True):
+    """(error_smoothed, equalization) for every row of ``errors``: smoothen_heavy_light (when ``smoothen_first``)
+    followed by equalize (autoeq :1181-1310)."""
+    es, eq, _ = curves_for(frequency).equalization(errors, smoothen_first, max_gain, treble_f_lower, treble_f_upper,
+                                                   treble_max_gain, treble_gain_k, smoothen)
+    return es, eq
+
+
+def equalization_firs(frequency, errors, fs, smoothen_first=True, max_gain=DEFAULT_MAX_GAIN,
+                      treble_f_lower=DEFAULT_TREBLE_F_LOWER, treble_f_upper=DEFAULT_TREBLE_F_UPPER,
+                      treble_max_gain=DEFAULT_TREBLE_MAX_GAIN, treble_gain_k=DEFAULT_TREBLE_GAIN_K, f_res=DEFAULT_F_RES,
+                      normalize=True):
+    """error curves [B, n] -> (equalization [B, n], minimum-phase FIRs [B, taps]); nothing but the inputs and the
+    results crosses the PCIe bus."""
+    return curves_for(frequency).equalization_fir(errors, smoothen_first, max_gain, treble_f_lower, treble_f_upper,
+                                                  treble_max_gain, treble_gain_k, fs, f_res, normalize)
+
+
 def fir_design_gain(frequency, equalization, fs, f_res=5.0, normalize=True):
-    """Linear gain on linspace(0, fs//2, n) that the reference hands to firwin2
-    (autoeq/frequency_response.py:651-674): dB doubled because the homomorphic step halves them,
-    flat below the first grid frequency, zero at Nyquist."""
-    frequency = np.asarray(frequency, dtype=np.float64)
-    eq = np.asarray(equalization, dtype=np.float64)
-    f_res = f_res / 2
-    f_min = np.max([frequency[0], f_res])
-    gain_f_min = float(log_interp(frequency, eq, [f_min])[0])
-    n = next_fast_len(round(fs // 2 / f_res))
-    f = np.linspace(0.0, fs // 2, n)
-    raw = log_interp(frequency, eq, f)
-    raw[f <= f_min] = gain_f_min
-    if normalize:
-        raw -= np.max(raw)
-        raw -= 0.5
-    raw *= 2
-    lin = 10 ** (raw / 20)
-    lin[-1] = 0.0
-    return lin
+    """Linear gain on linspace(0, fs//2, n) that the reference hands to firwin2 (autoeq :651-674): dB doubled because
+    the homomorphic step halves them, flat below the first grid frequency, zero at Nyquist (computed on the device)."""
+    return curves_for(frequency).fir(equalization, fs, f_res, normalize, want_gain=True)[1]
 
 
 def minimum_phase_impulse_response(frequency, equalization, fs, f_res=5.0, normalize=True):
     """Minimum-phase FIR (n = next_fast_len(fs//2 / (f_res/2)) taps) of one equalisation curve."""
-    return _native.default_context().minphase_fir(fir_design_gain(frequency, equalization, fs, f_res, normalize), fs)
+    return curves_for(frequency).fir(equalization, fs, f_res, normalize)
 
 
 def minimum_phase_impulse_responses(frequency, equalizations, fs, f_res=5.0, normalize=True):
     """Batched form: one launch chain for all speaker-ear curves [B, len(frequency)] -> [B, n]."""
-    gains = np.stack([fir_design_gain(frequency, eq, fs, f_res, normalize) for eq in equalizations])
-    return _native.default_context().minphase_fir(gains, fs)
+    return curves_for(frequency).fir(np.asarray(equalizations, dtype=np.float64), fs, f_res, normalize)
 
 
 class FrequencyResponse(object):
@@ -242,31 +308,20 @@ class FrequencyResponse(object):
         return size + 1 if size % 2 == 0 else size
 
     def _sigmoid(self, f_lower, f_upper, a_normal=0.0, a_treble=1.0):
-        from scipy.special import expit
         centre = np.sqrt(f_upper / f_lower) * f_lower
         half = np.log10(f_upper) - np.log10(centre)
-        a = expit((np.log10(self.frequency) - np.log10(centre)) / (half / 4))
+        a = 1.0 / (1.0 + np.exp(-((np.log10(self.frequency) - np.log10(centre)) / (half / 4))))
         return a * -(a_normal - a_treble) + a_normal
 
     def _smoothen_fractional_octave(self, data, window_size=DEFAULT_SMOOTHING_WINDOW_SIZE,
                                     iterations=DEFAULT_SMOOTHING_ITERATIONS, treble_window_size=None,
                                     treble_iterations=None, treble_f_lower=DEFAULT_TREBLE_SMOOTHING_F_LOWER,
                                     treble_f_upper=DEFAULT_TREBLE_SMOOTHING_F_UPPER):
-        from scipy.signal import savgol_filter
+        if iterations != 1 or treble_iterations != 1:
+            raise NotImplementedError("every caller on the path smooths once per window")
         if np.any(np.isnan(self.frequency)) or np.any(np.isnan(np.asarray(data, dtype=float))):
             raise ValueError('NaN values present, cannot smoothen!')
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            y_normal = data
-            w = self._window_size(window_size)
-            for _ in range(iterations):
-                y_normal = savgol_filter(y_normal, w, 2)
-            y_treble = data
-            w = self._window_size(treble_window_size)
-            for _ in range(treble_iterations):
-                y_treble = savgol_filter(y_treble, w, 2)
-        k_treble = self._sigmoid(treble_f_lower, treble_f_upper)
-        return y_normal * (k_treble * -1 + 1) + y_treble * k_treble
+        return smooth_curves(self.frequency, data, window_size, treble_window_size, treble_f_lower, treble_f_upper)
 
     def smoothen_fractional_octave(self, window_size=DEFAULT_SMOOTHING_WINDOW_SIZE,
                                    iterations=DEFAULT_SMOOTHING_ITERATIONS,
@@ -276,10 +331,11 @@ class FrequencyResponse(object):
                                    treble_f_upper=DEFAULT_TREBLE_SMOOTHING_F_UPPER):
         kw = dict(window_size=window_size, iterations=iterations, treble_window_size=treble_window_size,
                   treble_iterations=treble_iterations, treble_f_lower=treble_f_lower, treble_f_upper=treble_f_upper)
-        if len(self.raw):
-            self.smoothed = self._smoothen_fractional_octave(self.raw, **kw)
-        if len(self.error):
-            self.error_smoothed = self._smoothen_fractional_octave(self.error, **kw)
+        rows = [key for key in ("raw", "error") if len(getattr(self, key))]
+        if rows:
+            out = self._smoothen_fractional_octave(np.stack([getattr(self, key) for key in rows]), **kw)
+            for key, y in zip(rows, out):
+                setattr(self, "smoothed" if key == "raw" else "error_smoothed", y)
         self.reset(raw=False, smoothed=False, error=False, error_smoothed=False, equalization=True,
                    equalized_raw=True, equalized_smoothed=True, target=False)
 
@@ -287,14 +343,10 @@ class FrequencyResponse(object):
 
     def smoothen_heavy_light(self):
         """Error curve smoothed as max(light, heavy) then once more at 1/3 octave (autoeq :1181-1239)."""
-        light = self._smoothen_fractional_octave(self.error, window_size=1 / 6, iterations=1, treble_f_lower=100,
-                                                 treble_f_upper=10000, treble_window_size=1 / 3, treble_iterations=1)
-        heavy = self._smoothen_fractional_octave(self.error, window_size=1 / 3, iterations=1, treble_f_lower=1000,
-                                                 treble_f_upper=6000, treble_window_size=1.3, treble_iterations=1)
-        third = dict(window_size=1 / 3, iterations=1, treble_f_lower=100, treble_f_upper=10000,
-                     treble_window_size=1 / 3, treble_iterations=1)
-        self.smoothed = self._smoothen_fractional_octave(self.raw, **third)
-        self.error_smoothed = self._smoothen_fractional_octave(np.max(np.vstack([light, heavy]), axis=0), **third)
+        if np.any(np.isnan(np.asarray(self.error, dtype=float))):
+            raise ValueError('NaN values present, cannot smoothen!')
+        self.smoothed = smooth_curves(self.frequency, self.raw, 1 / 3, 1 / 3, 100, 10000)
+        self.error_smoothed = equalization_curves(self.frequency, self.error, smoothen_first=True)[0]
         self.reset(raw=False, smoothed=False, error=False, error_smoothed=False, equalization=True,
                    equalized_raw=True, equalized_smoothed=True, target=False)
 
@@ -312,26 +364,10 @@ class FrequencyResponse(object):
             raise ValueError('Error data is missing. Call FrequencyResponse.compensate().')
         if np.any(np.isnan(np.asarray(error, dtype=float))):
             raise ValueError('NaN values detected during equalization, interpolating data with default parameters.')
-        limit = self._sigmoid(treble_f_lower, treble_f_upper, a_normal=max_gain, a_treble=treble_max_gain)
-        gain = -error * self._sigmoid(treble_f_lower, treble_f_upper, a_normal=1.0, a_treble=treble_gain_k)
-        clipped = gain > limit
-        edges = np.flatnonzero(np.concatenate(([clipped[0]], clipped[1:] != clipped[:-1])))
-        if len(edges) and edges[0] == 0:
-            edges = edges[1:]
-        self.equalization = np.where(clipped, limit, gain)
-        if smoothen:
-            from scipy.interpolate import InterpolatedUnivariateSpline
-            half = (self._window_size(1 / 12) - 1) // 2
-            n = len(self.equalization)
-            doomed = set()
-            for i in edges:
-                doomed.update(range(i - min(i, half), i + 1 + min(n - i - 1, half)))
-            doomed.discard(n - 1)
-            doomed.discard(n - 2)
-            keep = np.ones(n, dtype=bool)
-            keep[sorted(doomed)] = False
-            spline = InterpolatedUnivariateSpline(np.log10(self.frequency[keep]), self.equalization[keep], k=2)
-            self.equalization = spline(np.log10(self.frequency))
+        self.equalization = equalization_curves(self.frequency, error, smoothen_first=False, max_gain=max_gain,
+                                                treble_f_lower=treble_f_lower, treble_f_upper=treble_f_upper,
+                                                treble_max_gain=treble_max_gain, treble_gain_k=treble_gain_k,
+                                                smoothen=smoothen)[1]
         self.equalized_raw = self.raw + self.equalization
         if len(self.smoothed):
             self.equalized_smoothed = self.smoothed + self.equalization

@@ -369,53 +369,55 @@ class HRIR(_PlotBase):
 
     # ---- channel balance (core/hrir.py:655-799) ---------------------------------------------
     def channel_balance_firs(self, left_fr, right_fr, method):
-        """Two FIRs (left, right) that bring the ears of a speaker group to a common response.
-        Curve logic on the host (FrequencyResponse), FIR design on the device (K6, fp64)."""
-        from .frequency_response import FrequencyResponse
-        if method == "mids":
-            gain = 10 ** ((get_center_value(right_fr, [100, 3000]) - get_center_value(left_fr, [100, 3000])) / 20)
-            n = int(round(self.fs * 0.1))
+        """Two FIRs (left, right) that bring the ears of a speaker group to a common response (core/hrir.py:655-764).
+        The two curves travel as one [2, n] matrix: smoothing, gain-limited inversion and FIR design run on the device
+        (K12 -> K6) for both ears at once."""
+        from .frequency_response import equalization_firs, minimum_phase_impulse_response, smooth_curves
+        fs = self.fs
+
+        def band_mean(raws, lo, hi):                            # rows of raws on the curves' own grid
+            band = np.logical_and(left_fr.frequency >= lo, left_fr.frequency <= hi)
+            return np.mean(raws[:, band], axis=1)
+
+        def unit_gain_pair(gain):
+            n = int(round(fs * 0.1))
             return [_unit_impulse(n), _unit_impulse(n) * gain]
+
+        grid = left_fr.frequency
+        raws = np.stack([left_fr.raw, right_fr.raw])
+        if method == "mids":
+            ml, mr = band_mean(raws, 100, 3000)
+            return unit_gain_pair(10 ** ((ml - mr) / 20))
         if method == "trend":
-            trend = FrequencyResponse(name="trend", frequency=left_fr.frequency, raw=left_fr.raw - right_fr.raw)
-            trend.smoothen_fractional_octave(window_size=2, treble_f_lower=20000,
-                                             treble_f_upper=int(round(self.fs / 2)))
-            right_fr.equalization = trend.smoothed
-            fir = right_fr.minimum_phase_impulse_response(fs=self.fs, normalize=False)
+            trend = smooth_curves(grid, raws[0] - raws[1], 2, 1 / 3, 20000, int(round(fs / 2)))
+            right_fr.equalization = trend
+            fir = minimum_phase_impulse_response(grid, trend, fs, normalize=False)
             return [_unit_impulse(len(fir)), fir]
         if method in ("left", "right"):
             ref, subj = (left_fr, right_fr) if method == "left" else (right_fr, left_fr)
-            ref.smoothen_fractional_octave(window_size=1 / 3, treble_f_lower=20000,
-                                           treble_f_upper=int(round(self.fs / 2)))
-            gain = ref.center([100, 10000])
-            subj.raw += gain
+            ref.smoothed = smooth_curves(grid, ref.raw, 1 / 3, 1 / 3, 20000, int(round(fs / 2)))
+            gain = ref.center([100, 10000])                     # shifts ref.raw and ref.smoothed
+            subj.raw = subj.raw + gain
             subj.target = ref.smoothed
             subj.error = subj.raw - subj.target
-            subj.smoothen_heavy_light()
-            subj.equalize(max_gain=15, treble_f_lower=20000, treble_f_upper=self.fs / 2)
-            fir = subj.minimum_phase_impulse_response(fs=self.fs, normalize=False)
+            eq, fir = equalization_firs(grid, subj.error, fs, smoothen_first=True, max_gain=15, treble_f_lower=20000,
+                                        treble_f_upper=fs / 2, normalize=False)
+            subj.equalization = eq
             return [_unit_impulse(len(fir)), fir] if method == "left" else [fir, _unit_impulse(len(fir))]
         if method in ("avg", "min"):
-            gain = (get_center_value(left_fr, [100, 10000]) + get_center_value(right_fr, [100, 10000])) / 2
-            left_fr.raw += gain
-            right_fr.raw += gain
-            for fr in (left_fr, right_fr):
-                fr.smoothen_fractional_octave(window_size=1 / 3, treble_f_lower=20000, treble_f_upper=23999)
-            target = (left_fr.raw + right_fr.raw) / 2 if method == "avg" else np.min([left_fr.raw, right_fr.raw], axis=0)
-            firs = []
-            for fr in (left_fr, right_fr):
-                fr.target = target
-                fr.error = fr.raw - fr.target
-                fr.smoothen_fractional_octave(window_size=1 / 3, treble_f_lower=20000, treble_f_upper=23999)
-                fr.equalize(max_gain=15, treble_f_lower=2000, treble_f_upper=self.fs / 2)
-                firs.append(fr.minimum_phase_impulse_response(fs=self.fs, normalize=False))
-            return firs
+            raws = raws - np.mean(band_mean(raws, 100, 10000))   # (get_center_value(left) + get_center_value(right)) / 2
+            target = np.mean(raws, axis=0) if method == "avg" else np.min(raws, axis=0)
+            errors = smooth_curves(grid, raws - target, 1 / 3, 1 / 3, 20000, 23999)
+            eqs, firs = equalization_firs(grid, errors, fs, smoothen_first=False, max_gain=15, treble_f_lower=2000,
+                                          treble_f_upper=fs / 2, normalize=False)
+            for fr, raw, eq in zip((left_fr, right_fr), raws, eqs):
+                fr.raw, fr.target, fr.error, fr.equalization = raw, target, raw - target, eq
+            return [firs[0], firs[1]]
         try:
             gain = 10 ** (float(method) / 20)
         except ValueError:
             raise ValueError(f'"{method}" is not valid value for channel balance method.')
-        n = int(round(self.fs * 0.1))
-        return [_unit_impulse(n), _unit_impulse(n) * gain]
+        return unit_gain_pair(gain)
 
     def correct_channel_balance(self, method):
         """core/hrir.py:766-799: per speaker group, equalize the ears to the same response."""

@@ -27,29 +27,43 @@ def init_equalization_worker(room_frs, hp_left, hp_right, eq_left, eq_right, tar
     _EQUALIZATION_CONTEXT = (room_frs, hp_left, hp_right, eq_left, eq_right, target, common_freq, estimator_fs)
 
 
+def equalization_errors(tasks, room_frs, hp_left, hp_right, eq_left, eq_right, target, common_freq):
+    """[B, n] error matrix of the channels in ``tasks``: room + headphone + user EQ - target on the common grid
+    (reference :98-122), one row per (speaker, side)."""
+    import numpy as np
+    from .frequency_response import FrequencyResponse
+    n = len(common_freq)
+    err = np.zeros((len(tasks), n))
+    for row, (speaker, side) in enumerate(tasks):
+        if room_frs is not None and speaker in room_frs and side in room_frs[speaker]:
+            err[row] += room_frs[speaker][side].error
+        hp = hp_left if side == 'left' else hp_right
+        if hp is not None:
+            err[row] += hp.error
+        eq = eq_left if side == 'left' else eq_right
+        if eq is not None and isinstance(eq, FrequencyResponse):
+            err[row] += eq.error
+    err -= target.raw
+    return err
+
+
 def equalization_curve(speaker, side, room_frs, hp_left, hp_right, eq_left, eq_right, target, common_freq,
                        estimator_fs):
     """FrequencyResponse whose ``equalization`` is the curve the FIR must realise for one speaker-ear
     channel: error = room + headphone + user EQ - target, smoothed heavy/light, inverted with a
     40 dB gain limit (6 dB above 10 kHz) - reference :98-126."""
     from .frequency_response import FrequencyResponse
-    fr = FrequencyResponse(name=f'{speaker}-{side} eq', frequency=common_freq.copy(), raw=0, error=0)
-    if room_frs is not None and speaker in room_frs and side in room_frs[speaker]:
-        fr.error += room_frs[speaker][side].error
-    hp = hp_left if side == 'left' else hp_right
-    if hp is not None:
-        fr.error += hp.error
-    eq = eq_left if side == 'left' else eq_right
-    if eq is not None and isinstance(eq, FrequencyResponse):
-        fr.error += eq.error
-    fr.error -= target.raw
+    fr = FrequencyResponse(name=f'{speaker}-{side} eq', frequency=common_freq.copy(), raw=0,
+                           error=equalization_errors([(speaker, side)], room_frs, hp_left, hp_right, eq_left, eq_right,
+                                                     target, common_freq)[0])
     fr.smoothen_heavy_light()
     fr.equalize(max_gain=40, treble_f_lower=10000, treble_f_upper=estimator_fs / 2)
     return fr
 
 
 def process_equalization_worker(args):
-    """(speaker, side[, context...]) -> (speaker, side, minimum-phase FIR); the FIR is designed on the GPU."""
+    """(speaker, side[, context...]) -> (speaker, side, minimum-phase FIR): curve conditioning and FIR design both on
+    the GPU, one launch chain."""
     if len(args) == 2:
         if _EQUALIZATION_CONTEXT is None:
             raise RuntimeError("Equalization worker context was not initialized.")
@@ -57,16 +71,19 @@ def process_equalization_worker(args):
         ctx = _EQUALIZATION_CONTEXT
     else:
         speaker, side, ctx = args[0], args[1], tuple(args[2:])
-    fr = equalization_curve(speaker, side, *ctx)
-    return (speaker, side, fr.minimum_phase_impulse_response(fs=ctx[-1], normalize=False, f_res=5))
+    return process_equalization_batch([(speaker, side)], *ctx)[0]
 
 
 def process_equalization_batch(tasks, room_frs, hp_left, hp_right, eq_left, eq_right, target, common_freq,
                                estimator_fs):
-    """All (speaker, side) FIRs of a measurement in ONE device launch chain - what replaces the
-    reference's process pool over channels (core/pipeline.py:668-688)."""
-    from .frequency_response import minimum_phase_impulse_responses
-    curves = [equalization_curve(sp, sd, room_frs, hp_left, hp_right, eq_left, eq_right, target, common_freq,
-                                 estimator_fs).equalization for sp, sd in tasks]
-    firs = minimum_phase_impulse_responses(common_freq, curves, estimator_fs, f_res=5, normalize=False)
+    """All (speaker, side) FIRs of a measurement in ONE device launch chain - what replaces the reference's process
+    pool over channels (core/pipeline.py:668-688): the error matrix goes up, the FIRs come down; smoothing, gain-limited
+    inversion, FIR design grid and the minimum-phase design never leave the device."""
+    from .frequency_response import equalization_firs
+    tasks = list(tasks)
+    if not tasks:
+        return []
+    errors = equalization_errors(tasks, room_frs, hp_left, hp_right, eq_left, eq_right, target, common_freq)
+    _, firs = equalization_firs(common_freq, errors, estimator_fs, smoothen_first=True, max_gain=40,
+                                treble_f_lower=10000, treble_f_upper=estimator_fs / 2, f_res=5, normalize=False)
     return [(sp, sd, fir) for (sp, sd), fir in zip(tasks, firs)]

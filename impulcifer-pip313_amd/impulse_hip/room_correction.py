@@ -2,8 +2,9 @@
 (surface of reference core/room_correction.py:36-461; plotting left out).
 
 The measurements are deconvolved on the GPU through HRIR.open_recording (all tracks/columns of a
-file in one batch); cropping uses the device peak search; the curve arithmetic on the resulting
-~800-point responses is host NumPy.
+file in one batch); cropping uses the device peak search; the responses of all channels become one [B, n]
+matrix of dB curves (one batched spectrum launch, one re-gridding map), levelled, compared with the target and masked
+row-wise; the fractional-octave smoothing of the generic path runs on the device (K12).
 """
 import os
 import re
@@ -71,10 +72,6 @@ def _correction_limit_mask(frequency, limit):
     return np.concatenate([np.ones(start if start > 0 else 0), _hann(end - start), np.zeros(len(frequency) - end)])
 
 
-def _apply_correction_limit(fr, limit):
-    fr.error *= _correction_limit_mask(fr.frequency, limit)
-
-
 def _open_curve(estimator, path, default_flat):
     if path is not None and os.path.isfile(path):
         fr = FrequencyResponse.read_csv(path)
@@ -110,70 +107,100 @@ def open_room_measurements(estimator, dir_path, debug=False):
     return rir
 
 
+def response_curves(irs, fs):
+    """ImpulseResponse.frequency_response() of several responses at once -> (grid 10 Hz..fs/2, raw [B, n]).  Equal-length
+    responses share one batched spectrum launch (K2) and one re-gridding map."""
+    from .audio_io import magnitude_responses
+    from .frequency_response import _Regrid, generate_frequencies
+    grid = generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
+    raws = np.zeros((len(irs), len(grid)))
+    by_len = {}
+    for i, ir in enumerate(irs):
+        by_len.setdefault(len(ir.data), []).append(i)
+    for n, idx in by_len.items():
+        if n < 2:
+            continue                                           # reference: flat curve for degenerate responses
+        f, m = magnitude_responses(np.stack([irs[i].data for i in idx]), fs)
+        wanted = (fs / 2) / 4.0
+        step = 1 if (wanted < 2 or len(f) < 2) else (int(round(len(f) / wanted)) or 1)
+        sel = slice(1, None, step) if len(f[1::step]) else slice(1, None)
+        if len(f[sel]) < 2:
+            continue
+        raws[idx] = _Regrid(f[sel], grid)(m[:, sel])
+    return grid, raws
+
+
+def _curve_objects(names, grid, raws, errors, targets=None):
+    out = []
+    for k, name in enumerate(names):
+        fr = FrequencyResponse(name=name, frequency=grid.copy(), raw=raws[k], error=errors[k])
+        if targets is not None:
+            fr.target = np.array(targets[k] if np.ndim(targets) > 1 else targets, dtype=np.float64)
+        out.append(fr)
+    return out
+
+
 def calculate_specific_room_corrections(rir, target, mic_calibration=None, limit=400):
-    """{speaker: {side: FrequencyResponse}} with ``error`` = measured - target, levelled to the first
-    channel's 100 Hz-10 kHz mean and faded out between limit/2 and limit Hz."""
+    """{speaker: {side: FrequencyResponse}} with ``error`` = measured - target, every channel levelled with the gain
+    that centres the FIRST channel's 100 Hz-10 kHz mean (core/room_correction.py:185-210), faded out between limit/2
+    and limit Hz.  All channels are handled as one [B, n] matrix: one batched spectrum, one re-gridding, row-wise
+    arithmetic."""
+    from .frequency_response import center_shifts
+    keys = [(sp, sd) for sp, pair in rir.irs.items() for sd in pair]
+    if not keys:
+        return dict()
+    fs = rir.irs[keys[0][0]][keys[0][1]].fs
+    grid, raws = response_curves([rir.irs[sp][sd] for sp, sd in keys], fs)
+    if mic_calibration is not None:
+        raws = raws - mic_calibration.raw
+    raws = raws - center_shifts(grid, raws[:1], [100, 10000])[0]              # the first channel's gain for everyone
+    wanted = target.raw + np.array([IR_ROOM_SPL[sp][sd] for sp, sd in keys])[:, None]
+    targets = wanted - center_shifts(target.frequency, wanted, 1000)[:, None]  # compensate() centres a copy at 1 kHz
+    errors = raws - targets
+    if limit > 0:
+        errors = errors * _correction_limit_mask(grid, limit)
     frs = dict()
-    reference_gain = None
-    for speaker, pair in rir.irs.items():
-        frs[speaker] = dict()
-        for side, ir in pair.items():
-            fr = ir.frequency_response()
-            if mic_calibration is not None:
-                fr.raw -= mic_calibration.raw
-            if reference_gain is None:
-                reference_gain = fr.center([100, 10000])
-            else:
-                fr.raw += reference_gain
-            wanted = target.copy()
-            wanted.raw += IR_ROOM_SPL[speaker][side]
-            fr.compensate(wanted, min_mean_error=False)
-            if limit > 0:
-                _apply_correction_limit(fr, limit)
-            frs[speaker][side] = fr
+    for (sp, sd), fr in zip(keys, _curve_objects(["Frequency response"] * len(keys), grid, raws, errors, targets)):
+        frs.setdefault(sp, dict())[sd] = fr
     return frs
 
 
 def calculate_generic_room_correction(irs, target, mic_calibration=None, method='average', limit=1000):
-    """One correction curve from several positions of a generic room measurement."""
-    room_fr = FrequencyResponse(name='generic_room',
-                                frequency=FrequencyResponse.generate_frequencies(f_min=10, f_max=irs[0].fs / 2,
-                                                                                 f_step=1.01),
-                                raw=0, error=0, target=target.raw)
-    errors = []
-    for ir in irs:
-        fr = ir.frequency_response()
-        if mic_calibration is not None:
-            fr.raw -= mic_calibration.raw
-        fr.center([100, 10000])
-        room_fr.raw += fr.raw
-        fr.compensate(target, min_mean_error=True)
-        if method == 'conservative' and len(irs) > 1:
-            fr.smoothen(window_size=1 / 3, treble_window_size=1 / 3)
-            errors.append(fr.error_smoothed)
-        else:
-            errors.append(fr.error)
-    room_fr.raw /= len(irs)
-    errors = np.vstack(errors)
-    if errors.shape[0] > 1:
-        if method == 'conservative':
-            share = np.mean(errors > 0, axis=0)
-            pos, neg = share == 1, share == 0
-            room_fr.error[pos] = np.min(errors[:, pos], axis=0)
-            room_fr.error[neg] = np.max(errors[:, neg], axis=0)
-            room_fr.smoothen(window_size=1 / 6, treble_window_size=1 / 6)
-            room_fr.error = room_fr.error_smoothed.copy()
-        elif method == 'average':
-            room_fr.error = np.mean(errors, axis=0)
-            room_fr.smoothen(window_size=1 / 3, treble_window_size=1 / 3)
-        else:
-            raise ValueError(f'Invalid value "{method}" for method. Supported values are "conservative" and "average"')
+    """One correction curve from the positions of a generic room measurement (core/room_correction.py:231-292):
+    'average' = mean of the per-position errors, 'conservative' = the smallest correction every position agrees on."""
+    from .frequency_response import center_shifts, smooth_curves
+    if len(irs) > 1 and method not in ('average', 'conservative'):
+        raise ValueError(f'Invalid value "{method}" for method. Supported values are "conservative" and "average"')
+    grid, raws = response_curves(irs, irs[0].fs)
+    if mic_calibration is not None:
+        raws = raws - mic_calibration.raw
+    raws = raws - center_shifts(grid, raws, [100, 10000])[:, None]
+    target_c = target.raw - center_shifts(target.frequency, target.raw, 1000)[0]
+    errors = raws - target_c
+    band = np.logical_and(grid >= 100, grid <= 10000)
+    errors = errors - np.mean(errors[:, band], axis=1)[:, None]                # min_mean_error=True, per position
+    several = len(irs) > 1
+    if method == 'conservative' and several:
+        errors = smooth_curves(grid, errors, 1 / 3, 1 / 3)
+        share = np.mean(errors > 0, axis=0)
+        error = np.zeros(len(grid))
+        pos, neg = share == 1, share == 0
+        error[pos] = np.min(errors[:, pos], axis=0)
+        error[neg] = np.max(errors[:, neg], axis=0)
+        error = smooth_curves(grid, error, 1 / 6, 1 / 6)
+        error_smoothed = error.copy()
     else:
-        room_fr.error = errors[0, :]
-        room_fr.smoothen(window_size=1 / 3, treble_window_size=1 / 3)
+        error = np.mean(errors, axis=0) if several else errors[0]
+        error_smoothed = smooth_curves(grid, error, 1 / 3, 1 / 3)
+    raw = np.sum(raws, axis=0) / len(irs)
+    room_fr = FrequencyResponse(name='generic_room', frequency=grid, raw=raw, error=error, target=target.raw)
+    room_fr.smoothed = smooth_curves(grid, raw, 1 / 3 if not (method == 'conservative' and several) else 1 / 6,
+                                     1 / 3 if not (method == 'conservative' and several) else 1 / 6)
+    room_fr.error_smoothed = error_smoothed
     if limit > 0:
-        _apply_correction_limit(room_fr, limit)
-        room_fr.error_smoothed *= _correction_limit_mask(room_fr.frequency, limit)
+        mask = _correction_limit_mask(grid, limit)
+        room_fr.error = room_fr.error * mask
+        room_fr.error_smoothed = room_fr.error_smoothed * mask
     return room_fr
 
 

@@ -189,6 +189,43 @@ int imp_decay_times(imp_ctx* ctx, const double* x, const int64_t* off, const int
                     const int64_t* peak, const int64_t* knee, const double* noise_floor, const int64_t* window,
                     double fs, double* out);
 
+/* ---- K12: equalisation-curve conditioning ----------------------------------------------------
+ * The EQ worker's front half (core/parallel_workers.py:69-131 -> autoeq/frequency_response.py) for all speaker-ear
+ * curves of a measurement at once, fp64, one workgroup per curve: fractional-octave smoothing (scipy.signal.
+ * savgol_filter(polyorder 2, mode 'interp') as a fixed linear operator per window, logistic blend towards the treble
+ * window, autoeq :1060-1105), smoothen_heavy_light (:1181-1239), equalize (:1241-1310: gain-limited inversion, the
+ * samples around every clip on/off transition replaced by FITPACK's quadratic interpolating spline in log10 f), the
+ * gain grid of the FIR design (:651-674) and, chained on the device, the minimum-phase FIR (K6).
+ * A handle belongs to one frequency grid (frequency[n] Hz, strictly increasing, 8 <= n <= 1024); curves are host
+ * fp64 [B][n] in dB.  Grid-only quantities (log10 f, window coefficients, blend weights) are prepared once per handle
+ * on the host in fp64; all per-curve arithmetic runs on the device. */
+typedef struct imp_curves imp_curves;
+int imp_curves_create(imp_ctx* ctx, const double* frequency, int64_t n, imp_curves** out);
+void imp_curves_destroy(imp_curves* c);
+/* FrequencyResponse._window_size (autoeq :1033-1050): odd number of grid points covering `octaves` */
+int imp_curves_window_size(imp_curves* c, double octaves, int* window);
+/* y = savgol(x, w(window_oct)) * (1 - k) + savgol(x, w(treble_window_oct)) * k, k = logistic between treble_f_lower and
+ * treble_f_upper (one iteration each, as every caller on the path asks) */
+int imp_curves_smooth(imp_curves* c, const double* x, int64_t B, double window_oct, double treble_window_oct,
+                      double treble_f_lower, double treble_f_upper, double* y);
+/* error -> [smoothen_heavy_light if smoothen_first] -> equalize(max_gain, treble_f_lower, treble_f_upper, treble_max_gain,
+ * treble_gain_k, smoothen = smoothen_kinks).  error_smoothed_out (the curve the inversion used) and spline_used_out
+ * ([B], 1 where the kink-bridging spline ran) may be NULL. */
+int imp_curves_equalization(imp_curves* c, const double* error, int64_t B, int smoothen_first, double max_gain,
+                            double treble_f_lower, double treble_f_upper, double treble_max_gain, double treble_gain_k,
+                            int smoothen_kinks, double* error_smoothed_out, double* equalization_out, int* spline_used_out);
+/* number of taps minimum_phase_impulse_response(fs, f_res) yields: next_fast_len(round(fs // 2 / (f_res / 2))) */
+int imp_curves_fir_taps(imp_curves* c, double fs, double f_res, int64_t* ntaps);
+/* equalization [B][n] -> minimum-phase FIRs [B][ntaps] (autoeq :637-681); gain_out (the linear gains handed to
+ * firwin2, [B][ntaps]) or fir_out may be NULL */
+int imp_curves_fir(imp_curves* c, const double* equalization, int64_t B, double fs, double f_res, int normalize,
+                   double* gain_out, double* fir_out);
+/* the whole worker: error -> equalization -> FIR without leaving the device; equalization_out may be NULL */
+int imp_curves_equalization_fir(imp_curves* c, const double* error, int64_t B, int smoothen_first, double max_gain,
+                                double treble_f_lower, double treble_f_upper, double treble_max_gain, double treble_gain_k,
+                                int smoothen_kinks, double fs, double f_res, int normalize, double* equalization_out,
+                                double* fir_out);
+
 /* ---- K11: cascaded second-order sections -------------------------------------------------------
  * core/virtual_bass.py:121-176: scipy.signal.sosfilt(sos, x) (zero initial state) over every response.
  * sos: host [n_sections][6] = b0 b1 b2 a0 a1 a2 with a0 = 1 (SciPy's layout);

@@ -466,7 +466,8 @@ def test_ingest_recording_matches_oracle_split(gpu_ctx, tmp_path):
     h = HRIR(e)
     h.open_recording(path, ["FL", "FR"])
     assert list(h.irs) == ["FL", "FR"] and all(set(p) == {"left", "right"} for p in h.irs.values())
-    pcm = np.rint(tracks * 2 ** 31) / 2 ** 31                       # what PCM_32 stored
+    from impulse_hip.audio_io import pcm_quantise
+    pcm = pcm_quantise(tracks, 32) / 2.0 ** 31                      # what PCM_32 stored (libsndfile's write scale)
     jobs = ohrir.split_recording(pcm, ["FL", "FR"], N, fs)
     assert [(sp, sd) for sp, sd, _ in jobs] == [("FL", "left"), ("FL", "right"), ("FR", "left"), ("FR", "right")]
     for sp, sd, col in jobs:
@@ -635,7 +636,8 @@ def test_pipeline_slice_product(gpu_ctx, golden, tmp_path):
     import slice_input                                   # tests/golden/slice_input.py (inputs only)
     tracks = slice_input.make_tracks(e.test_signal, fs)
     path = str(tmp_path / "FL,FR.wav")
-    write_wav(path, fs, tracks, bit_depth=32)
+    from scipy.io import wavfile
+    wavfile.write(path, fs, slice_input.to_pcm32(tracks).T)        # the bytes the golden run read (clipped, scale 2^31)
     order = [("FL", "left"), ("FL", "right"), ("FR", "left"), ("FR", "right")]
     common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
     room = {sp: {} for sp in ("FL", "FR")}
@@ -1692,3 +1694,113 @@ def test_k5_short_plans_and_filter_refill(gpu_ctx):
     assert len(irm._k5_plans.plans) == 1
     ys = irm.fir_convolve_full_batch([x[i].astype(np.float64) for i in range(B)], [fb[i] for i in range(B)])
     assert len(irm._k5_plans.plans) == 2 and all(rel(ys[i], yb[i].astype(np.float64)) <= 1e-7 for i in range(B))
+
+
+# ------------------------------------------------------------------------------------------------
+# K12: curve conditioning on the device (csrc/curves.hip) - SURVEY 8(f)-3
+# ------------------------------------------------------------------------------------------------
+CURVE_TOL = 1e-12          # dB, against the reference's own curves / the oracle's restatement of SciPy
+
+
+def test_k12_equalization_curves_match_reference_run(gpu_ctx, golden):
+    """process_equalization_worker's curve (autoeq smoothen_heavy_light + equalize) for the six reference curves of
+    minphase.npz (three shapes x two sampling rates), through the class surface (B = 1 calls) and as one batch."""
+    from impulse_hip.frequency_response import FrequencyResponse, equalization_curves
+    from impulse_hip.parallel_workers import equalization_curve
+    mp = golden("minphase")
+    worst = 0.0
+    for fs in (48000, 96000):
+        freq = mp[f"fs{fs}_freq"]
+        flat = FrequencyResponse("t", frequency=freq.copy(), raw=0)
+        names = ("flat", "wavy", "tilt")
+        for nm in names:
+            room = {"FL": {"left": FrequencyResponse("r", frequency=freq.copy(), raw=0, error=mp[f"fs{fs}_{nm}_error"])}}
+            cur = equalization_curve("FL", "left", room, None, None, None, None, flat, freq, fs)
+            worst = max(worst, float(np.max(np.abs(cur.equalization - mp[f"fs{fs}_{nm}_eq"]))))
+            assert len(cur.error_smoothed) == len(freq) and len(cur.smoothed) == len(freq)
+        _, eqs = equalization_curves(freq, np.stack([mp[f"fs{fs}_{nm}_error"] for nm in names]), smoothen_first=True,
+                                     max_gain=40, treble_f_lower=10000, treble_f_upper=fs / 2)
+        for nm, eq in zip(names, eqs):
+            worst = max(worst, float(np.max(np.abs(eq - mp[f"fs{fs}_{nm}_eq"]))))
+    print(f"K12 equalization curves vs the reference run: max |d| = {worst:.2e} dB")
+    assert worst <= CURVE_TOL
+
+
+def test_k12_smoothing_clipping_and_fir_grid_match_the_oracle(gpu_ctx):
+    from impulse_hip.frequency_response import (curves_for, equalization_curves, fir_design_gain, generate_frequencies,
+                                                smooth_curves)
+    from oracle import frequency_response as ofr
+    from oracle.impulse_response import interpolate_log
+    from oracle.scipy_restated import next_fast_len_real
+    rng = np.random.default_rng(12)
+    for fs in (44100, 48000, 96000):
+        freq = generate_frequencies(10, fs / 2, 1.01)
+        n = len(freq)
+        curves = np.cumsum(rng.standard_normal((5, n)), axis=1) * 0.4                      # wandering dB curves
+        h = curves_for(freq)
+        for octv in (1 / 12, 1 / 6, 1 / 3, 1.3, 2):
+            assert h.window_size(octv) == ofr.window_size(freq, octv)
+        for (wn, wt, fl, fu) in ((1 / 3, 1 / 3, 100, 10000), (1 / 6, 1 / 3, 100, 10000), (1 / 3, 1.3, 1000, 6000),
+                                 (2, 1 / 3, 20000, int(round(fs / 2))), (1 / 6, 1 / 6, 100, 10000)):
+            got = smooth_curves(freq, curves, wn, wt, fl, fu)
+            for b in range(len(curves)):
+                want = ofr.smoothen_fractional_octave(freq, curves[b], wn, wt, fl, fu)
+                assert np.max(np.abs(got[b] - want)) <= CURVE_TOL
+        # deep notches ask for more than the 40 dB limit: clipping, kink removal and the quadratic-spline bridge
+        errors = curves.copy()
+        errors[0, 300:340] -= 65.0
+        errors[1, 5:40] -= 70.0                                   # a kink window that reaches the first grid point
+        errors[2, n - 60:n - 20] -= 80.0
+        errors[3] -= 45.0 + 10 * np.sin(np.arange(n) / 37.0)      # in and out of clipping many times
+        for smoothen_first in (True, False):
+            es, eq, used = h.equalization(errors, smoothen_first, 40, 10000, fs / 2, 6.0, 1.0)
+            assert used[:4].all() and not used[4]
+            for b in range(len(errors)):
+                want_es = ofr.smoothen_heavy_light(freq, errors[b]) if smoothen_first else errors[b]
+                assert np.max(np.abs(es[b] - want_es)) <= CURVE_TOL
+                want = ofr.equalize(freq, want_es, 40, 10000, fs / 2)
+                assert np.max(np.abs(eq[b] - want)) <= 1e-10, (fs, b, smoothen_first)
+        _, eq_lim = equalization_curves(freq, errors, smoothen_first=False, max_gain=15, treble_f_lower=2000,
+                                        treble_f_upper=fs / 2, smoothen=False)
+        assert np.max(np.abs(eq_lim - np.minimum(-errors, ofr.sigmoid(freq, 2000, fs / 2, 15, 6.0)))) <= CURVE_TOL
+        # the gain grid handed to firwin2 (autoeq :651-674), with and without normalisation
+        for f_res, normalize in ((5, False), (10, True)):
+            got = fir_design_gain(freq, curves[:2], fs, f_res, normalize)
+            ntaps = next_fast_len_real(round(fs // 2 / (f_res / 2)))
+            assert got.shape == (2, ntaps) and h.fir_taps(fs, f_res) == ntaps
+            f = np.linspace(0.0, fs // 2, ntaps)
+            for b in range(2):
+                f_min = max(freq[0], f_res / 2)
+                raw = interpolate_log(freq, curves[b], f)
+                raw[f <= f_min] = interpolate_log(freq, curves[b], np.array([f_min]))[0]
+                if normalize:
+                    raw -= np.max(raw)
+                    raw -= 0.5
+                want = 10 ** (raw * 2 / 20)
+                want[-1] = 0.0
+                assert np.max(np.abs(got[b] - want) / np.maximum(want, 1e-300)) <= 1e-12
+    with pytest.raises(Exception, match="NaN"):
+        smooth_curves(freq, np.full(len(freq), np.nan))
+
+
+def test_k12_worker_batch_equals_per_channel_calls_and_reference_firs(gpu_ctx, golden):
+    """error -> FIR in one device chain for a whole measurement = the per-channel worker calls = the reference's FIRs."""
+    from impulse_hip.frequency_response import FrequencyResponse
+    from impulse_hip.parallel_workers import (init_equalization_worker, process_equalization_batch,
+                                              process_equalization_worker)
+    mp = golden("minphase")
+    for fs in (48000, 96000):
+        freq = mp[f"fs{fs}_freq"]
+        names = ("flat", "wavy", "tilt")
+        room = {nm.upper()[:2]: {"left": FrequencyResponse("r", frequency=freq.copy(), raw=0, error=mp[f"fs{fs}_{nm}_error"])}
+                for nm in names}
+        flat = FrequencyResponse("t", frequency=freq.copy(), raw=0)
+        tasks = [(nm.upper()[:2], "left") for nm in names]
+        batch = process_equalization_batch(tasks, room, None, None, None, None, flat, freq, fs)
+        init_equalization_worker(room, None, None, None, None, flat, freq, fs)
+        for (sp, sd, fir), nm in zip(batch, names):
+            want = mp[f"fs{fs}_{nm}_fir"]
+            assert fir.shape == want.shape
+            assert np.max(np.abs(fir - want)) <= 5e-8 * np.max(np.abs(want))
+            sp1, sd1, fir1 = process_equalization_worker((sp, sd))
+            assert (sp1, sd1) == (sp, sd) and np.array_equal(fir1, fir)

@@ -286,13 +286,12 @@ print("rank", rank, "ok")
 
 
 def test_product_curve_logic_matches_reference(golden, tmp_path):
-    """Host-side FrequencyResponse of the product (CSV parsing, interpolate, center, compensate,
-    smoothing, equalize incl. the clipped branch, limit mask) against the reference's outputs."""
+    """Host-side part of the product's curve handling (file discovery, CSV parsing, interpolate, center) against the
+    reference's outputs."""
     from impulse_hip.frequency_response import FrequencyResponse
     from impulse_hip.impulse_response import ImpulseResponse
-    from impulse_hip.parallel_workers import equalization_curve
     from impulse_hip.room_correction import discover_room_measurements, open_mic_calibration, open_room_target
-    g, mp = golden("room_fc"), golden("minphase")
+    g = golden("room_fc")
 
     class Est:
         fs = 48000
@@ -315,13 +314,7 @@ def test_product_curve_logic_matches_reference(golden, tmp_path):
     with pytest.raises(FileNotFoundError):
         open_mic_calibration(Est(), str(tmp_path), str(tmp_path / "nope.txt"))
 
-    for fs in (48000, 96000):
-        freq = mp[f"fs{fs}_freq"]
-        flat = FrequencyResponse("t", frequency=freq.copy(), raw=0)
-        for nm in ("flat", "wavy", "tilt"):
-            room = {"FL": {"left": FrequencyResponse("r", frequency=freq.copy(), raw=0, error=mp[f"fs{fs}_{nm}_error"])}}
-            cur = equalization_curve("FL", "left", room, None, None, None, None, flat, freq, fs)
-            np.testing.assert_allclose(cur.equalization, mp[f"fs{fs}_{nm}_eq"], rtol=0, atol=1e-12)
+    # (the smoothing / equalisation curves themselves are device work: tests/test_hip_parity.py)
     with pytest.raises(ValueError):
         FrequencyResponse("dup", frequency=[10, 20, 20], raw=[0, 0, 0])
 
