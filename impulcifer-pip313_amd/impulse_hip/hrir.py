@@ -391,7 +391,7 @@ class HRIR(_PlotBase):
         if method == "trend":
             trend = smooth_curves(grid, raws[0] - raws[1], 2, 1 / 3, 20000, int(round(fs / 2)))
             right_fr.equalization = trend
-            fir = minimum_phase_impulse_response(grid, trend, fs, normalize=False)
+            fir = minimum_phase_impulse_response(grid, trend, fs, f_res=10, normalize=False)   # the method's default f_res
             return [_unit_impulse(len(fir)), fir]
         if method in ("left", "right"):
             ref, subj = (left_fr, right_fr) if method == "left" else (right_fr, left_fr)
