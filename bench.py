@@ -156,9 +156,10 @@ def synth_recordings(est, n_channels, seed0, column=None):
 
 
 def slice_rate(est, rec, L, reps=3):
-    """SURVEY 8(d) secondary figure: the whole hot-path slice (ingest K1 -> crop_heads K3/K4 -> crop_tails ->
-    FIR design K2/K6 -> equalize K5 -> normalize K2) on ONE 7.1 x 2-ear measurement laid out as a recording
-    (2 s lead + one column per speaker), host arrays in, host arrays out, curve logic on the host."""
+    """SURVEY 8(d) secondary figure: the whole hot-path slice (ingest K1 -> crop_heads K3/K4 -> crop_tails K7/K4 ->
+    EQ curves + FIR design K12/K6 -> equalize K5 -> normalize K2) on ONE 7.1 x 2-ear measurement laid out as a recording
+    (2 s lead + one column per speaker): interleaved PCM frames in, float64 host arrays out; the responses stay on the
+    device between the stages."""
     from impulse_hip.pipeline_slice import run_slice
     fs = est.fs
     speakers = ["FL", "FR", "FC", "BL", "BR", "SL", "SR", "WL"]
@@ -166,17 +167,19 @@ def slice_rate(est, rec, L, reps=3):
     for i in range(8):
         for ear in range(2):
             tracks[ear, 2 * fs + i * L: 2 * fs + (i + 1) * L] = rec[2 * i + ear, :L]
-    job = [((fs, tracks), speakers)]
+    # the recording as a capture buffer / WAV data chunk holds it: interleaved 32-bit PCM frames
+    frames = np.ascontiguousarray(np.clip(np.rint(tracks.T * 2.0 ** 31), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int32))
+    job = [((fs, frames), speakers)]
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         run_slice(est, job)                                   # plans, tables
         t0 = time.perf_counter()
         for _ in range(reps):
-            run_slice(est, job)
+            run_slice(est, job)[0].to_host()                  # float64 host arrays out
         dt = (time.perf_counter() - t0) / reps
     return dict(value=16 / dt, unit="IR/s", ms_per_measurement=dt * 1e3,
-                note="end to end incl. PCIe and host curve logic; 16 IRs per measurement; not the headline metric")
+                note="end to end: PCM frames in host memory -> float64 responses in host memory, incl. PCIe; 16 IRs per measurement; not the headline metric")
 
 
 def cpu_baseline(est, rec, L, budget_s=12.0):

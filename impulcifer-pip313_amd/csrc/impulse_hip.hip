@@ -1377,6 +1377,74 @@ extern "C" int imp_segset_create(imp_ctx* ctx, const double* x, const int64_t* o
   return IMP_OK;
 }
 
+extern "C" int imp_segset_create_device(imp_ctx* ctx, const float* d_x, const int64_t* off, const int64_t* len, int64_t B,
+                                        imp_segset** out, double* maxabs_out) {
+  if (!ctx || !out || (B && (!d_x || !off || !len))) return fail(IMP_ERR_INVALID, "imp_segset_create_device: null argument");
+  IMP_CTX_LOCK(ctx);
+  *out = nullptr;
+  if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
+  int64_t total = 0, maxlen = 0;
+  std::vector<int64_t> packed((size_t)std::max<int64_t>(B, 1));
+  for (int64_t b = 0; b < B; ++b) {
+    if (off[b] < 0 || len[b] < 0) return fail(IMP_ERR_INVALID, "negative offset/length in segment %lld", (long long)b);
+    packed[(size_t)b] = total;
+    total += len[b];
+    maxlen = std::max(maxlen, len[b]);
+  }
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  imp_segset* s = new (std::nothrow) imp_segset();
+  if (!s) return fail(IMP_ERR_ALLOC, "out of host memory");
+  s->ctx = ctx;
+  s->B = B;
+  s->h_len.assign(len, len + B);
+  hipStream_t st = ctx->stream;
+  unsigned long long* d_max = nullptr;
+  int64_t* d_src_off = nullptr;
+  auto bail = [&](int code) {
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(d_max);
+    (void)hipFree(d_src_off);
+    imp_segset_destroy(s);
+    return code;
+  };
+  if (hipMalloc((void**)&s->e, (size_t)std::max<int64_t>(total, 1) * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&s->off, (size_t)std::max<int64_t>(2 * B, 1) * sizeof(int64_t)) != hipSuccess ||
+      hipMalloc((void**)&d_src_off, (size_t)std::max<int64_t>(B, 1) * sizeof(int64_t)) != hipSuccess ||
+      hipMalloc((void**)&d_max, (size_t)std::max<int64_t>(B, 1) * sizeof(unsigned long long)) != hipSuccess)
+    return bail(fail(IMP_ERR_ALLOC, "imp_segset_create_device: device allocation of %lld samples failed", (long long)total));
+  s->len = s->off + B;
+  if (B == 0 || total == 0) {
+    (void)hipFree(d_max);
+    (void)hipFree(d_src_off);
+    *out = s;
+    if (maxabs_out)
+      for (int64_t b = 0; b < B; ++b) maxabs_out[b] = 0.0;
+    return IMP_OK;
+  }
+  if (hipMemcpyAsync(s->off, packed.data(), (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(s->len, len, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(d_src_off, off, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemsetAsync(d_max, 0, (size_t)B * sizeof(unsigned long long), st) != hipSuccess)
+    return bail(fail(IMP_ERR_HIP, "imp_segset_create_device: upload failed"));
+  const int bpr = (int)std::max<int64_t>(1, std::min<int64_t>(256, (maxlen + 4095) / 4096));
+  dim3 grid((unsigned)bpr, (unsigned)B), block(256);
+  hipLaunchKernelGGL(imp::seg_from_float_kernel, grid, block, 0, st, d_x, d_src_off, s->e, s->off, s->len);
+  hipLaunchKernelGGL(imp::seg_maxabs_kernel, grid, block, 0, st, s->e, s->off, s->len, d_max);
+  hipLaunchKernelGGL(imp::seg_square_kernel, grid, block, 0, st, s->e, s->off, s->len, d_max);
+  if (hipGetLastError() != hipSuccess) return bail(fail(IMP_ERR_HIP, "imp_segset_create_device: launch failed"));
+  std::vector<unsigned long long> h((size_t)B);
+  if (hipMemcpyAsync(h.data(), d_max, (size_t)B * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return bail(fail(IMP_ERR_HIP, "imp_segset_create_device: readback failed"));
+  (void)hipFree(d_max);
+  (void)hipFree(d_src_off);
+  if (maxabs_out)
+    for (int64_t b = 0; b < B; ++b) std::memcpy(&maxabs_out[b], &h[(size_t)b], sizeof(double));
+  *out = s;
+  return IMP_OK;
+}
+
 extern "C" int imp_segset_range_means(imp_segset* s, const int64_t* q_seg, const int64_t* q_a, const int64_t* q_b,
                                       int64_t Q, double* mean_out) {
   if (!s || (Q && (!q_seg || !q_a || !q_b || !mean_out))) return fail(IMP_ERR_INVALID, "imp_segset_range_means: null argument");
@@ -1601,6 +1669,48 @@ extern "C" int imp_apply_window(imp_ctx* ctx, float* x, const int64_t* off, cons
   if (hipMemcpyAsync(x, d_x, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess)
     return cleanup(fail(IMP_ERR_HIP, "imp_apply_window: d2h copy failed"));
   return cleanup(IMP_OK);
+}
+
+extern "C" int imp_apply_window_device(imp_ctx* ctx, const float* d_src, const int64_t* src_off, float* d_dst,
+                                       const int64_t* dst_off, const int64_t* len, int64_t B,
+                                       const imp_window_params* params) {
+  if (!ctx || (B && (!d_src || !d_dst || !src_off || !dst_off || !len || !params)))
+    return fail(IMP_ERR_INVALID, "imp_apply_window_device: null argument");
+  IMP_CTX_LOCK(ctx);
+  if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
+  if (B == 0) return IMP_OK;
+  int64_t maxlen = 0;
+  for (int64_t b = 0; b < B; ++b) {
+    if (len[b] < 0 || src_off[b] < 0 || dst_off[b] < 0) return fail(IMP_ERR_INVALID, "negative offset/length in row %lld", (long long)b);
+    if (params[b].fade_in < 0 || params[b].fade_out < 0 || params[b].fade_in > len[b] || params[b].fade_out > len[b])
+      return fail(IMP_ERR_INVALID, "fade longer than row %lld", (long long)b);
+    if (params[b].decay_half >= 0 && (params[b].decay_start < 0 || params[b].decay_knee > len[b] ||
+                                      params[b].decay_start + params[b].decay_half != params[b].decay_knee))
+      return fail(IMP_ERR_INVALID, "decay window of row %lld does not tile the row", (long long)b);
+    maxlen = std::max(maxlen, len[b]);
+  }
+  if (maxlen == 0) return IMP_OK;
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  const size_t meta = (size_t)B * sizeof(int64_t);
+  void* scr = nullptr;
+  if ((rc = ctx_scratch(ctx, 3 * meta + (size_t)B * sizeof(imp_window_params), &scr))) return rc;
+  int64_t* d_so = (int64_t*)scr;
+  int64_t* d_do = d_so + B;
+  int64_t* d_len = d_do + B;
+  imp_window_params* d_par = (imp_window_params*)(d_len + B);
+  HIP_TRY(hipMemcpyAsync(d_so, src_off, meta, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_do, dst_off, meta, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_len, len, meta, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_par, params, (size_t)B * sizeof(imp_window_params), hipMemcpyHostToDevice, s));
+  const int bpr = (int)std::max<int64_t>(1, std::min<int64_t>(256, (maxlen + 1023) / 1024));
+  hipLaunchKernelGGL(imp::apply_window_copy_kernel, dim3((unsigned)bpr, (unsigned)B), dim3(256), 0, s, d_src, d_so, d_dst, d_do,
+                     d_len, reinterpret_cast<const imp::WindowParams*>(d_par));
+  HIP_TRY(hipGetLastError());
+  // the scratch block is reused by the next call on this context: the kernel must have read it by then
+  HIP_TRY(hipStreamSynchronize(s));
+  return IMP_OK;
 }
 
 #ifdef IMP_PHASE_TRACE

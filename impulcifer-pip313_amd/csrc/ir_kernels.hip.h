@@ -132,6 +132,44 @@ __global__ __launch_bounds__(256) void apply_window_kernel(float* __restrict__ x
   }
 }
 
+// the same window, read from one set of rows and written to another (device-resident responses: head/tail crops are an
+// offset into the source row, the result is compacted into rows of a common pitch for the next stage)
+__global__ __launch_bounds__(256) void apply_window_copy_kernel(const float* __restrict__ src, const int64_t* __restrict__ src_off,
+                                                                float* __restrict__ dst, const int64_t* __restrict__ dst_off,
+                                                                const int64_t* __restrict__ len,
+                                                                const WindowParams* __restrict__ par) {
+  const int b = blockIdx.y;
+  const int64_t n = len[b];
+  const float* in = src + src_off[b];
+  float* out = dst + dst_off[b];
+  const WindowParams p = par[b];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double g = (double)p.gain;
+    if (i < p.fade_in) g *= hann_sym(i, 2 * p.fade_in);
+    if (p.fade_out > 0 && i >= n - p.fade_out) g *= hann_sym(p.fade_out + (i - (n - p.fade_out)), 2 * p.fade_out);
+    if (p.decay_half >= 0) {
+      double w;
+      if (i < p.decay_start) w = 1.0;
+      else if (i < p.decay_knee) w = hann_sym(p.decay_half + (i - p.decay_start), 2 * p.decay_half);
+      else w = 0.0;
+      g *= pow(10.0, (w - 1.0) * (-(double)p.decay_level_db) / 20.0);
+    }
+    out[i] = (float)((double)in[i] * g);
+  }
+}
+
+// fp32 device rows -> packed fp64 segments (K7 analysis spans of device-resident responses)
+__global__ __launch_bounds__(256) void seg_from_float_kernel(const float* __restrict__ src, const int64_t* __restrict__ src_off,
+                                                             double* __restrict__ dst, const int64_t* __restrict__ dst_off,
+                                                             const int64_t* __restrict__ len) {
+  const int b = blockIdx.y;
+  const int64_t n = len[b];
+  const float* in = src + src_off[b];
+  double* out = dst + dst_off[b];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (double)in[i];
+}
+
 // K10: argmax of the full cross-correlation of B pairs of short segments (core/hrir.py:934-937, :946-949,
 // scipy.signal.correlate(a, b, "full") then np.argmax).  corr[k] = sum_l a[l + k - (nb - 1)] b[l],
 // k = 0 .. na + nb - 2, summed in fp64 in index order.  One workgroup per pair, both segments in LDS,

@@ -440,8 +440,47 @@ void magnitude_plans_destroy(imp_ctx* ctx) {
   m.clear();
 }
 
+namespace {
+// out[g][i] = sum over the rows of group g (in row order, zero beyond a row's end) - np.sum(np.vstack(padded), axis=0)
+__global__ __launch_bounds__(256) void rows_group_sum_kernel(const float* __restrict__ src, const int64_t* __restrict__ off,
+                                                             const int64_t* __restrict__ len, const int64_t* __restrict__ group,
+                                                             int B, double* __restrict__ out, int64_t n) {
+  const int g = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int b = 0; b < B; ++b)
+      if (group[b] == g && i < len[b]) acc += (double)src[off[b] + i];
+    out[(int64_t)g * n + i] = acc;
+  }
+}
+
+}  // namespace
+
+static int magnitude_db_core(imp_ctx* ctx, const double* x, const float* d_rows, const int64_t* off, const int64_t* len,
+                             const int64_t* group, int64_t n_rows, int64_t B, int64_t n, double* db_out);
+
 extern "C" int imp_magnitude_db(imp_ctx* ctx, const double* x, int64_t B, int64_t n, double* db_out) {
-  if (!ctx || (B && n && (!x || !db_out))) return fail(IMP_ERR_INVALID, "imp_magnitude_db: null argument");
+  return magnitude_db_core(ctx, x, nullptr, nullptr, nullptr, nullptr, 0, B, n, db_out);
+}
+
+// Device-resident rows (fp32 at d_rows + off[r], len[r] samples, r < n_rows) are summed per group (group[r] in
+// [0, n_groups), rows of a group added in row order in fp64, zero beyond a row's end: np.sum(np.vstack(padded), axis=0)
+// of core/hrir.py:496-503) and the magnitude response of every sum (n points) is returned: HRIR.normalize without
+// bringing the responses back to the host.
+extern "C" int imp_magnitude_db_sum_device(imp_ctx* ctx, const float* d_rows, const int64_t* off, const int64_t* len,
+                                           const int64_t* group, int64_t n_rows, int64_t n_groups, int64_t n,
+                                           double* db_out) {
+  if (!ctx || !d_rows || !off || !len || !group || n_rows < 1 || n_groups < 1)
+    return fail(IMP_ERR_INVALID, "imp_magnitude_db_sum_device: bad argument");
+  for (int64_t r = 0; r < n_rows; ++r)
+    if (off[r] < 0 || len[r] < 0 || len[r] > n || group[r] < 0 || group[r] >= n_groups)
+      return fail(IMP_ERR_INVALID, "imp_magnitude_db_sum_device: row %lld out of range", (long long)r);
+  return magnitude_db_core(ctx, nullptr, d_rows, off, len, group, n_rows, n_groups, n, db_out);
+}
+
+static int magnitude_db_core(imp_ctx* ctx, const double* x, const float* d_rows, const int64_t* off, const int64_t* len,
+                             const int64_t* group, int64_t n_rows, int64_t B, int64_t n, double* db_out) {
+  if (!ctx || (B && n && ((!x && !d_rows) || !db_out))) return fail(IMP_ERR_INVALID, "imp_magnitude_db: null argument");
   IMP_CTX_LOCK(ctx);
   if (B < 0 || n < 0 || n > (1 << 22)) return fail(IMP_ERR_INVALID, "imp_magnitude_db: bad B or n");
   if (B == 0 || n == 0) return IMP_OK;
@@ -507,7 +546,24 @@ extern "C" int imp_magnitude_db(imp_ctx* ctx, const double* x, int64_t B, int64_
     p->cap = B;
   }
   hipStream_t s = ctx->stream;
-  HIP_TRY(hipMemcpyAsync(p->x, x, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, s));
+  if (x) {
+    HIP_TRY(hipMemcpyAsync(p->x, x, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, s));
+  } else {
+    int64_t* d_meta = nullptr;
+    const size_t meta = (size_t)n_rows * sizeof(int64_t);
+    HIP_TRY(hipMalloc((void**)&d_meta, 3 * meta));
+    hipError_t e1 = hipMemcpyAsync(d_meta, off, meta, hipMemcpyHostToDevice, s);
+    hipError_t e2 = hipMemcpyAsync(d_meta + n_rows, len, meta, hipMemcpyHostToDevice, s);
+    hipError_t e3 = hipMemcpyAsync(d_meta + 2 * n_rows, group, meta, hipMemcpyHostToDevice, s);
+    if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess)
+      hipLaunchKernelGGL(rows_group_sum_kernel, dim3((unsigned)std::min<int64_t>(256, (n + 255) / 256), (unsigned)B),
+                         dim3(256), 0, s, d_rows, d_meta, d_meta + n_rows, d_meta + 2 * n_rows, (int)n_rows, p->x, n);
+    hipError_t e4 = hipGetLastError();
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(d_meta);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess)
+      return fail(IMP_ERR_HIP, "imp_magnitude_db_sum_device: row sum failed");
+  }
   auto grid_for = [&](int count) { return dim3((unsigned)((count + 255) / 256), (unsigned)B); };
   cdbl *cur = p->a, *oth = p->b;
   hipLaunchKernelGGL(bluestein_pre, grid_for(p->mfft), dim3(256), 0, s, p->x, p->chirp, cur, p->n, p->mfft);

@@ -103,6 +103,9 @@ SIGNATURES = {
     "imp_peak_index": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
     "imp_peak_index_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
     "imp_apply_window": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.POINTER(WindowParams)]),
+    "imp_apply_window_device": (C.c_int, [_vp, _vp, _pi64, _vp, _pi64, _pi64, _i64, C.POINTER(WindowParams)]),
+    "imp_segset_create_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, C.POINTER(_vp), _pd]),
+    "imp_magnitude_db_sum_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _pi64, _i64, _i64, _i64, _pd]),
 }
 
 _lib = None
@@ -260,6 +263,47 @@ class Context:
                                         float(peak_height), _ptr_i64(idx), _ptr_f(mx)))
         return idx, mx
 
+    # ---- device-resident rows (fp32 at dptr + off[b], len[b] samples) ---------------------------
+    @staticmethod
+    def _window_array(params, B):
+        arr = (WindowParams * B)()
+        for i, p in enumerate(params):
+            arr[i] = WindowParams(float(p.get("gain", 1.0)), int(p.get("fade_in", 0)), int(p.get("fade_out", 0)),
+                                  int(p.get("decay_start", 0)), int(p.get("decay_half", -1)),
+                                  int(p.get("decay_knee", 0)), float(p.get("decay_level_db", 0.0)))
+        return arr
+
+    def peak_index_device(self, dptr, offs, lens, peak_height=0.12589):
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int64)
+        B = len(offs)
+        idx = np.zeros(B, dtype=np.int64)
+        mx = np.zeros(B, dtype=np.float32)
+        if B:
+            _check(self._lib.imp_peak_index_device(self._h, _vp(int(dptr)), _ptr_i64(offs), _ptr_i64(lens), B,
+                                                   float(peak_height), _ptr_i64(idx), _ptr_f(mx)))
+        return idx, mx
+
+    def apply_window_device(self, d_src, src_off, d_dst, dst_off, lens, params):
+        src_off = np.ascontiguousarray(src_off, dtype=np.int64)
+        dst_off = np.ascontiguousarray(dst_off, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int64)
+        B = len(lens)
+        if B:
+            _check(self._lib.imp_apply_window_device(self._h, _vp(int(d_src)), _ptr_i64(src_off), _vp(int(d_dst)),
+                                                     _ptr_i64(dst_off), _ptr_i64(lens), B, self._window_array(params, B)))
+
+    def magnitude_db_sum_device(self, dptr, offs, lens, groups, n_groups, n):
+        """[n_groups, ceil(n/2)] dB spectra of the per-group sums of device rows (HRIR.normalize)."""
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int64)
+        groups = np.ascontiguousarray(groups, dtype=np.int64)
+        out = np.empty((int(n_groups), (int(n) + 1) // 2), dtype=np.float64)
+        _check(self._lib.imp_magnitude_db_sum_device(self._h, _vp(int(dptr)), _ptr_i64(offs), _ptr_i64(lens),
+                                                     _ptr_i64(groups), len(offs), int(n_groups), int(n),
+                                                     out.ctypes.data_as(_pd)))
+        return out
+
     def decay_times(self, rows, peaks, knees, noise_floors, windows, fs):
         """Batched core/decay.py decay_times on the device: [B, 4] = EDT, RT20, RT30, RT60 (NaN = undefined)."""
         rows = [np.ascontiguousarray(r, dtype=np.float64).ravel() for r in rows]
@@ -390,6 +434,23 @@ class SegSet:
                                            C.byref(h), self.maxabs.ctypes.data_as(_pd)))
         self._h = h
         ctx._plans.add(self)
+
+    @classmethod
+    def from_device(cls, ctx, dptr, offs, lens):
+        """Segments cut from fp32 device rows (dptr + offs[b], lens[b] samples), converted on the device."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self._lib = ctx._lib
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        self.lens = np.ascontiguousarray(lens, dtype=np.int64)
+        B = len(offs)
+        self.maxabs = np.zeros(max(B, 1), dtype=np.float64)[:B]
+        h = _vp()
+        _check(self._lib.imp_segset_create_device(ctx.handle, _vp(int(dptr)), _ptr_i64(offs), _ptr_i64(self.lens), B,
+                                                  C.byref(h), self.maxabs.ctypes.data_as(_pd)))
+        self._h = h
+        ctx._plans.add(self)
+        return self
 
     def range_means(self, queries):
         """queries: iterable of (segment, a, b) with 0 <= a <= b <= len(segment).  Returns float64 means."""
@@ -601,6 +662,26 @@ class ConvPlan:
             ctx.free(d_in)
             ctx.free(d_out)
         return out[:, :, :self.out_len]
+
+    def execute_pcm_columns_device(self, frames, column_starts, d_out, pitch):
+        """As execute_pcm_columns, but the result stays on the device: column j, track t -> d_out + 4 * (j * tracks
+        + t) * pitch (pitch >= out_len floats).  The PCM block is uploaded once and freed after the launches."""
+        frames = np.ascontiguousarray(frames)
+        if frames.dtype not in (np.int16, np.int32) or frames.ndim != 2:
+            raise ValueError("frames must be int16/int32 [n_frames, tracks]")
+        bits = 16 if frames.dtype == np.int16 else 32
+        n_frames, tracks = frames.shape
+        ctx = self.ctx
+        d_in = ctx.malloc(frames.nbytes)
+        try:
+            ctx.h2d(d_in, frames)
+            for j, s0 in enumerate(column_starts):
+                if s0 < 0 or s0 + self.L > n_frames:
+                    raise ValueError("column outside the recording")
+                self.execute_device_pcm(d_in + s0 * tracks * frames.itemsize, bits, tracks, 1, tracks,
+                                        d_out + j * tracks * pitch * 4, pitch)
+        finally:
+            ctx.free(d_in)                                  # synchronises the stream first
 
     def set_overlap(self, lanes):
         """lanes > 1: successive launch groups of execute_device overlap on that many streams (inputs must

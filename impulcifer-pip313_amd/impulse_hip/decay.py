@@ -154,37 +154,34 @@ def _lundeby(n_sq, fs):
     return grid.nearest(knee_time), floor, w
 
 
-def decay_params_batch(datas, fs):
-    """decay_params for many responses at once: one upload of all analysis segments, then the knee
-    searches advance in lock step so that each round of np.mean queries is ONE device call (K7)."""
-    datas = [np.asarray(d, dtype=np.float64) for d in datas]
-    results = [None] * len(datas)
-    ctx = _native.default_context()
-    live = []
-    for k, ir in enumerate(datas):
-        if len(ir) < 10:
-            results[k] = (0, len(ir), -200.0, len(ir) if len(ir) > 0 else 1)
-        else:
-            live.append(k)
+def _knee_searches(ctx, lengths, peaks, segset_for, fs):
+    """The lock-step Lundeby searches shared by the host-array and the device-row entry points.  lengths / peaks per
+    response; segset_for(starts, seg_lens) builds the K7 segment set of the analysis spans."""
+    results = [None] * len(lengths)
+    live = [k for k, n in enumerate(lengths) if n >= 10]
+    for k, n in enumerate(lengths):
+        if n < 10:
+            results[k] = (0, n, -200.0, n if n > 0 else 1)
     if not live:
         return results
-    peaks, _ = ctx.peak_index([datas[k] for k in live])
-    segs, seg_peak = [], {}
-    for k, pk in zip(live, peaks):
-        ir, pk = datas[k], int(pk)
-        end = min(pk + int(2 * fs), len(ir))
+    starts, seg_lens, seg_peak = [], [], {}
+    for k in live:
+        n, pk = lengths[k], int(peaks[k])
+        end = min(pk + int(2 * fs), n)
         if pk >= end:
-            pk = min(max(pk, 0), len(ir) - 1)
-            segs.append(ir[pk:pk + 1])
+            pk = min(max(pk, 0), n - 1)
+            starts.append(pk)
+            seg_lens.append(1)
         else:
-            segs.append(ir[pk:end])
+            starts.append(pk)
+            seg_lens.append(end - pk)
         seg_peak[k] = pk
-    segset = _native.SegSet(ctx, segs)
+    segset = segset_for(live, starts, seg_lens)
     try:
         runs = {}
         pending = {}
         for j, k in enumerate(live):
-            gen = _lundeby(len(segs[j]), fs)
+            gen = _lundeby(seg_lens[j], fs)
             runs[k] = (j, gen)
             pending[k] = next(gen)                         # every search asks at least one question
         while pending:
@@ -205,6 +202,38 @@ def decay_params_batch(datas, fs):
     finally:
         segset.close()
     return results
+
+
+def decay_params_batch(datas, fs):
+    """decay_params for many responses at once: one upload of all analysis segments, then the knee
+    searches advance in lock step so that each round of np.mean queries is ONE device call (K7)."""
+    datas = [np.asarray(d, dtype=np.float64) for d in datas]
+    ctx = _native.default_context()
+    lengths = [len(d) for d in datas]
+    live = [k for k, n in enumerate(lengths) if n >= 10]
+    peaks = np.zeros(len(datas), dtype=np.int64)
+    if live:
+        peaks[live] = ctx.peak_index([datas[k] for k in live])[0]
+
+    def segset_for(idx, starts, seg_lens):
+        return _native.SegSet(ctx, [datas[k][a:a + n] for k, a, n in zip(idx, starts, seg_lens)])
+
+    return _knee_searches(ctx, lengths, peaks, segset_for, fs)
+
+
+def decay_params_rows(rows, fs):
+    """decay_params_batch for device-resident responses (device_rows.Row): the peak search and the analysis spans are
+    read where the rows are; only peak indices and window levels come back."""
+    from .device_rows import span
+    ctx = _native.default_context()
+    base, offs, lens = span(rows)
+    lengths = [int(n) for n in lens]
+    peaks, _ = ctx.peak_index_device(base, offs, lens)
+
+    def segset_for(idx, starts, seg_lens):
+        return _native.SegSet.from_device(ctx, base, [offs[k] + a for k, a in zip(idx, starts)], seg_lens)
+
+    return _knee_searches(ctx, lengths, peaks, segset_for, fs)
 
 
 def decay_params(data, fs):

@@ -184,13 +184,19 @@ def ingest_pcm_frames(estimator, expected_fs, fs, frames, speakers, side=None, s
     for job in jobs:
         by_len.setdefault(job[4] - job[3], []).append(job)
     irs = {}
+    from .device_rows import DeviceBlock, Row
     for length, group in by_len.items():
         starts = sorted({origin + a for (_, _, _, a, _) in group})
-        out = estimator._plan(length).execute_pcm_columns(frames, starts)
+        plan = estimator._plan(length)
+        # the deconvolved columns stay on the device as rows of one block (device_rows.py); `recording`, the raw
+        # column the reference keeps beside every response (core/hrir.py:336-341), is cut from the PCM block on demand
+        pitch = (plan.out_len + 63) // 64 * 64
+        block = DeviceBlock(plan.ctx, len(starts) * tracks * pitch)
+        plan.execute_pcm_columns_device(frames, starts, block.ptr, pitch)
         for sp, sd, tr, a, b in group:
-            y = out[starts.index(origin + a), tr].astype(np.float64)
-            column = frames[origin + a: origin + b, tr].astype(np.float64) * scale
-            irs.setdefault(sp, {})[sd] = ImpulseResponse(y, fs, column)
+            row = Row(block, (starts.index(origin + a) * tracks + tr) * pitch, plan.out_len)
+            column = (lambda a=a, b=b, tr=tr: frames[origin + a: origin + b, tr].astype(np.float64) * scale)
+            irs.setdefault(sp, {})[sd] = ImpulseResponse.on_device(row, fs, column)
     ordered = {}
     for sp, sd, *_ in jobs:
         ordered.setdefault(sp, {})[sd] = irs[sp][sd]
@@ -233,6 +239,18 @@ class HRIR(_PlotBase):
         fs, recording = read_wav(file_path, expand=True)                   # 24-bit / float files, duck-typed estimators
         self.open_recording_data(fs, recording, speakers, side=side, silence_length=silence_length)
 
+    def open_recording_frames(self, fs, frames, speakers, side=None, silence_length=2.0):
+        """open_recording for a recording that is already in memory as interleaved PCM frames [n_frames, tracks]
+        (int16 / int32, WAV wire order - what a capture buffer or a WAV data chunk holds): the block goes to the GPU
+        as it is and the deconvolved responses stay there (see device_rows.py)."""
+        self._require_matching_fs("open recording")
+        frames = np.asarray(frames)
+        if frames.ndim != 2 or frames.dtype not in (np.int16, np.int32):
+            raise ValueError("frames must be int16 / int32 [n_frames, tracks]")
+        got = ingest_pcm_frames(self.estimator, self.fs, fs, frames, speakers, side, silence_length)
+        for sp, sides in got.items():
+            self.irs.setdefault(sp, {}).update(sides)
+
     def open_recording_data(self, fs, recording, speakers, side=None, silence_length=2.0):
         self._require_matching_fs("open recording")
         got = ingest_recording(self.estimator, self.fs, fs, np.asarray(recording), speakers, side, silence_length)
@@ -260,8 +278,18 @@ class HRIR(_PlotBase):
             n = max(len(a) for a in arrs)
             return np.sum(np.vstack([np.pad(a, (0, n - len(a)), "constant") for a in arrs]), axis=0)
 
-        f_l, m_l = magnitude_response(summed("left"), self.fs)
-        f_r, m_r = magnitude_response(summed("right"), self.fs)
+        sides = [(sd, pair[sd]) for pair in self.irs.values() for sd in ("left", "right")]
+        dev = self._device_rows([ir for _, ir in sides]) if sides and all(len(ir) > 0 for _, ir in sides) else None
+        if dev is not None:
+            from .device_rows import span
+            ctx = _native.default_context()
+            base, offs, lens = span(dev)
+            n = int(max(lens))
+            m_l, m_r = ctx.magnitude_db_sum_device(base, offs, lens, [0 if sd == "left" else 1 for sd, _ in sides], 2, n)
+            f_l = f_r = np.arange(int(np.ceil(n / 2))) * (self.fs / n)
+        else:
+            f_l, m_l = magnitude_response(summed("left"), self.fs)
+            f_r, m_r = magnitude_response(summed("right"), self.fs)
         if peak_target is not None and avg_target is None:
             gain = np.max(np.vstack([m_l, m_r])) * -1 + peak_target
         elif peak_target is None and avg_target is not None:
@@ -271,6 +299,11 @@ class HRIR(_PlotBase):
         else:
             raise ValueError('One and only one of the parameters "peak_target" and "avg_target" must be given!')
         g = 10 ** (gain / 20)
+        if dev is not None:
+            ctx.apply_window_device(base, offs, base, offs, lens, [dict(gain=g)] * len(dev))
+            for r in dev:
+                r.block.touch()
+            return gain
         for pair in self.irs.values():
             for ir in pair.values():
                 ir.data *= g
@@ -280,14 +313,36 @@ class HRIR(_PlotBase):
     def _all_irs(self):
         return [(sp, sd, ir) for sp, pair in self.irs.items() for sd, ir in pair.items()]
 
+    def to_host(self):
+        """Bring every device-resident response to the host (one transfer per device block); returns self."""
+        for pair in self.irs.values():
+            for ir in pair.values():
+                ir.data                                         # noqa: B018 - the property does the transfer
+        return self
+
+    def _device_rows(self, irs):
+        """the device rows of `irs` if EVERY one of them still lives on the default context's device, else None"""
+        rows = [getattr(ir, "_row", None) if getattr(ir, "_data", 0) is None else None for ir in irs]
+        if not rows or any(r is None for r in rows):
+            return None
+        ctx = _native.default_context()
+        return rows if all(r.block.ctx is ctx for r in rows) else None
+
     def crop_heads(self, head_ms=1):
         """Crop leading silence of every pair at the earlier ear's first peak minus ``head_ms``
         (interaural delay preserved) and fade the head in.  Peak search is one batched launch."""
         self._require_matching_fs("crop heads")
         pairs = list(self.irs.items())
-        flat = [pair[sd].data for _, pair in pairs for sd in ("left", "right")]
-        peaks, _ = _native.default_context().peak_index(flat) if flat else (np.zeros(0, np.int64), None)
         head = int(head_ms * self.fs / 1000)
+        dev = self._device_rows([pair[sd] for _, pair in pairs for sd in ("left", "right")])
+        if dev is not None:
+            from .device_rows import span
+            ctx = _native.default_context()
+            base, offs, lens = span(dev)
+            peaks, _ = ctx.peak_index_device(base, offs, lens)
+        else:
+            flat = [pair[sd].data for _, pair in pairs for sd in ("left", "right")]
+            peaks, _ = _native.default_context().peak_index(flat) if flat else (np.zeros(0, np.int64), None)
         rows, owners = [], []
         for i, (sp, pair) in enumerate(pairs):
             p_left, p_right = int(peaks[2 * i]), int(peaks[2 * i + 1])
@@ -305,12 +360,27 @@ class HRIR(_PlotBase):
                     f"{wrong} ear. This is usually a problem with the measurement process or the speaker order "
                     f"given is not correct. Detected delay difference is {itd_ms:.4f} milliseconds.")
             at = max(0, first - delay)
+            if dev is not None:                              # a crop is a change of (offset, length)
+                for sd in ("left", "right"):
+                    r = pair[sd]._row
+                    cut = min(at, r.n)
+                    r.off, r.n = r.off + cut, r.n - cut
+                if pair["left"]._row.n >= head and pair["right"]._row.n >= head:
+                    rows.extend(pair[sd]._row for sd in ("left", "right"))
+                continue
             pair["left"].data = pair["left"].data[at:]
             pair["right"].data = pair["right"].data[at:]
             if len(pair["left"].data) >= head and len(pair["right"].data) >= head:
                 for sd in ("left", "right"):
                     rows.append(pair[sd].data[:head])
                     owners.append(pair[sd])
+        if dev is not None:
+            if rows and head > 0:
+                base, offs, _ = span(rows)
+                ctx.apply_window_device(base, offs, base, offs, [head] * len(rows), [dict(fade_in=head)] * len(rows))
+                for r in rows:
+                    r.block.touch()
+            return
         if rows and head > 0:
             faded = _native.default_context().apply_window(rows, [dict(fade_in=head)] * len(rows))
             for ir, seg in zip(owners, faded):
@@ -325,6 +395,26 @@ class HRIR(_PlotBase):
         if not items:
             return 0
         from .decay import decay_params_batch
+        dev = self._device_rows([ir for _, _, ir in items])
+        if dev is not None:
+            from .decay import decay_params_rows
+            from .device_rows import DeviceBlock, Row, span
+            ctx = _native.default_context()
+            knees = [p[1] for p in decay_params_rows(dev, self.fs)]
+            per_octave = len(self.estimator) / self.estimator.fs / self.estimator.n_octaves
+            fade = 2 * int(self.fs * per_octave * (1 / 24)) // 2
+            keep = int(min(min(r.n for r in dev), next_fast_len(max(knees))))
+            if fade > keep:
+                raise ValueError("operands could not be broadcast together: fade-out longer than the response")
+            # truncate + fade out into rows of a common pitch: the layout the FIR stage (K5) reads
+            pitch = (keep + 63) // 64 * 64
+            block = DeviceBlock(ctx, len(dev) * pitch)
+            base, offs, _ = span(dev)
+            ctx.apply_window_device(base, offs, block.ptr, [i * pitch for i in range(len(dev))], [keep] * len(dev),
+                                    [dict(fade_out=fade)] * len(dev))
+            for i, (_, _, ir) in enumerate(items):
+                ir._row = Row(block, i * pitch, keep)
+            return keep
         lengths = [len(ir.data) for _, _, ir in items]
         try:                                                # all knee searches in lock step on the device (K7)
             knees = [p[1] for p in decay_params_batch([ir.data for _, _, ir in items], self.fs)]
@@ -437,8 +527,21 @@ class HRIR(_PlotBase):
     def equalize_channels(self, firs):
         """`firs`: {(speaker, side): taps}.  Same result as calling ir.equalize(taps) on each channel
         (core/pipeline.py:690-691 does exactly that loop), sent to the device as one batch."""
-        from .impulse_response import fir_convolve_full_batch
+        from .impulse_response import _k5_plans, fir_convolve_full_batch
         keys = [k for k in firs if k[0] in self.irs and k[1] in self.irs[k[0]]]
+        dev = self._device_rows([self.irs[sp][sd] for sp, sd in keys])
+        taps = [np.asarray(firs[k], dtype=np.float64) for k in keys]
+        if dev is not None and len({len(t) for t in taps}) == 1 and len(taps[0]) > 0 and dev[0].n > 0:
+            from .device_rows import DeviceBlock, Row, uniform
+            pitch = uniform(dev)
+            if pitch is not None:                            # device rows in, device rows out
+                n, k = dev[0].n, len(taps[0])
+                out_pitch = (n + k - 1 + 63) // 64 * 64
+                block = DeviceBlock(_native.default_context(), len(dev) * out_pitch)
+                out_len = _k5_plans.run_device(dev[0].ptr, len(dev), pitch, n, np.stack(taps), block.ptr, out_pitch)
+                for i, (sp, sd) in enumerate(keys):
+                    self.irs[sp][sd]._row = Row(block, i * out_pitch, out_len)
+                return
         ys = fir_convolve_full_batch([self.irs[sp][sd].data for sp, sd in keys], [firs[k] for k in keys])
         for (sp, sd), y in zip(keys, ys):
             self.irs[sp][sd].data = y

@@ -46,6 +46,25 @@ class _PlanCache:
                 self.plans.pop(next(iter(self.plans))).close()
             return plan.execute(signals)
 
+    def run_device(self, d_in, B, stride_in, n, taps, d_out, stride_out):
+        """Device rows in (B rows of n samples, stride_in apart), device rows out (n + taps - 1 samples, stride_out
+        apart); taps: host [B, K].  Asynchronous on the context stream."""
+        ctx = _native.default_context()
+        key = (id(ctx), int(n), taps.shape[1], int(B))
+        with self.lock:
+            plan = self.plans.pop(key, None)
+            if plan is not None and not plan._h:
+                plan = None
+            if plan is None:
+                plan = _native.ConvPlan(ctx, taps, int(n), "full", ws_channels=int(B))
+            else:
+                plan.set_filters(taps)
+            self.plans[key] = plan
+            while len(self.plans) > self.capacity:
+                self.plans.pop(next(iter(self.plans))).close()
+            plan.execute_device(d_in, B, stride_in, d_out, stride_out)
+            return plan.out_len
+
 
 _k5_plans = _PlanCache()
 
@@ -83,14 +102,60 @@ def fir_convolve_full_batch(signals, taps):
 class ImpulseResponse(_PlotBase):
     def __init__(self, data, fs, recording=None):
         self.fs = fs
-        self.data = data
-        self.recording = recording
+        self._row = None              # device_rows.Row while the samples live on the GPU (then _data is None)
+        self._data = data
+        self._recording = recording   # array, or a callable producing it on first use
+
+    @classmethod
+    def on_device(cls, row, fs, recording=None):
+        """A response whose samples are a row of a device block (see device_rows.py)."""
+        ir = cls(None, fs, recording)
+        ir._row = row
+        return ir
+
+    @property
+    def data(self):
+        """The samples as a writable float64 array.  Reading this from a device-resident response brings the row to the
+        host; from then on the host array is the truth (callers mutate and re-bind it, as with the reference)."""
+        if self._data is None and self._row is not None:
+            self._data = self._row.to_host()
+            self._row = None
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data = value
+        self._row = None
+
+    def peek(self):
+        """A copy of the samples that leaves a device-resident response on the device (tests, snapshots)."""
+        return self._row.to_host() if (self._data is None and self._row is not None) else np.array(self._data, copy=True)
+
+    @property
+    def recording(self):
+        if callable(self._recording):
+            self._recording = self._recording()
+        return self._recording
+
+    @recording.setter
+    def recording(self, value):
+        self._recording = value
+
+    def __getstate__(self):
+        return {"fs": self.fs, "_row": None, "_data": self.data, "_recording": self.recording}
 
     def copy(self):
         return deepcopy(self)
 
+    def __deepcopy__(self, memo):
+        other = ImpulseResponse(deepcopy(self.data, memo), self.fs, deepcopy(self.recording, memo))
+        for k, v in self.__dict__.items():
+            if k not in ("fs", "_row", "_data", "_recording"):
+                other.__dict__[k] = deepcopy(v, memo)
+        return other
+
     def __len__(self):
-        return len(self.data)
+        return self._row.n if (self._data is None and self._row is not None) else len(self._data)
 
     def duration(self):
         return len(self) / self.fs

@@ -25,12 +25,15 @@ def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, deca
         side = rec[2] if len(rec) > 2 else None
         if isinstance(src, str):
             hrir.open_recording(src, speakers, side=side)
+        elif np.asarray(src[1]).dtype in (np.int16, np.int32):
+            hrir.open_recording_frames(src[0], src[1], speakers, side=side)     # PCM frames [n_frames, tracks]
         else:
             hrir.open_recording_data(src[0], src[1], speakers, side=side)
 
     def snap(name):
         if stages is not None:
-            stages[name] = {(sp, sd): ir.data.copy() for sp, pair in hrir.irs.items() for sd, ir in pair.items()}
+            # peek(): a copy that leaves device-resident responses where they are
+            stages[name] = {(sp, sd): ir.peek() for sp, pair in hrir.irs.items() for sd, ir in pair.items()}
 
     snap("ingest")
     hrir.crop_heads(head_ms=head_ms)

@@ -290,6 +290,24 @@ typedef struct imp_window_params {
 int imp_apply_window(imp_ctx* ctx, float* x, const int64_t* off, const int64_t* len, int64_t B,
                      const imp_window_params* params /* [B] */);
 
+/* ---- device-resident responses ----------------------------------------------------------------
+ * The stages between ingest and output (crop_heads, crop_tails, equalize, normalize: core/hrir.py:457-653, 858-888)
+ * on responses that STAY on the device as fp32 rows: a row is (device pointer, offset, length) and a head / tail crop
+ * is a change of offset / length.  Together with imp_conv_execute_device(_pcm) and imp_peak_index_device these let
+ * the host class keep a measurement on the GPU from the WAV's PCM block to the final responses. */
+/* window parameters as imp_apply_window; row b is read at d_src + src_off[b] and written at d_dst + dst_off[b]
+ * (len[b] samples; the two may be the same memory for an in-place window) */
+int imp_apply_window_device(imp_ctx* ctx, const float* d_src, const int64_t* src_off, float* d_dst,
+                            const int64_t* dst_off, const int64_t* len, int64_t B, const imp_window_params* params);
+/* imp_segset_create on fp32 device rows (converted exactly to fp64 on the device) */
+int imp_segset_create_device(imp_ctx* ctx, const float* d_x, const int64_t* off, const int64_t* len, int64_t B,
+                             imp_segset** out, double* maxabs_out);
+/* magnitude response (as imp_magnitude_db, n points, ceil(n/2) bins each) of the per-group SUMS of device rows:
+ * rows of group g are added in row order in fp64, zero beyond their end - np.sum(np.vstack(padded), axis=0) of
+ * HRIR.normalize (core/hrir.py:496-503).  db_out: host [n_groups][ceil(n/2)]. */
+int imp_magnitude_db_sum_device(imp_ctx* ctx, const float* d_rows, const int64_t* off, const int64_t* len,
+                                const int64_t* group, int64_t n_rows, int64_t n_groups, int64_t n, double* db_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1806,3 +1806,50 @@ def test_k12_worker_batch_equals_per_channel_calls_and_reference_firs(gpu_ctx, g
             assert np.max(np.abs(fir - want)) <= 5e-8 * np.max(np.abs(want))
             sp1, sd1, fir1 = process_equalization_worker((sp, sd))
             assert (sp1, sd1) == (sp, sd) and np.array_equal(fir1, fir)
+
+
+# ------------------------------------------------------------------------------------------------
+# Device-resident responses (impulse_hip/device_rows.py): the stages between ingest and output on rows that stay on the GPU
+# ------------------------------------------------------------------------------------------------
+def test_device_resident_stages_equal_the_host_array_stages(gpu_ctx, golden):
+    """The same measurement through HRIR twice: once from PCM frames (responses stay on the device through crop_heads,
+    crop_tails, equalize_channels, normalize) and once from float arrays (every stage on host arrays, uploading per
+    call).  Lengths, crops and gains must agree exactly; samples to fp32 rounding of the final gain."""
+    import slice_input
+    from impulse_hip.frequency_response import FrequencyResponse
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.pipeline_slice import run_slice
+    g = golden("pipeline_slice")
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+    fs = 48000
+    pcm = slice_input.to_pcm32(slice_input.make_tracks(e.test_signal, fs))            # [4, n]
+    order = [("FL", "left"), ("FL", "right"), ("FR", "left"), ("FR", "right")]
+    common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
+    room = {sp: {} for sp in ("FL", "FR")}
+    for sp, sd in order:
+        room[sp][sd] = FrequencyResponse("r", frequency=common.copy(), raw=0, error=g[f"room_error_{sp}_{sd}"])
+    st_dev, st_host = {}, {}
+    h_dev, gain_dev = run_slice(e, [((fs, np.ascontiguousarray(pcm.T)), ["FL", "FR"])], room_frs=room, stages=st_dev)
+    assert all(ir._data is None and ir._row is not None for pair in h_dev.irs.values() for ir in pair.values())
+    h_host, gain_host = run_slice(e, [((fs, pcm.astype(np.float64) / 2 ** 31), ["FL", "FR"])], room_frs=room, stages=st_host)
+    assert all(ir._row is None for pair in h_host.irs.values() for ir in pair.values())
+    assert gain_dev == pytest.approx(gain_host, abs=1e-9) and gain_dev == pytest.approx(float(g["norm_gain_db"]), abs=2e-4)
+    for stage in ("ingest", "crop_heads", "crop_tails", "equalize", "normalize"):
+        for k in order:
+            a, b = st_dev[stage][k], st_host[stage][k]
+            assert a.shape == b.shape, (stage, k)
+            assert rel(a, b) <= 2e-7, (stage, k, rel(a, b))
+    # reading .data hands the response over to the host for good; the raw column is cut from the PCM block on demand
+    ir = h_dev.irs["FL"]["left"]
+    d = ir.data
+    assert ir._row is None and d.dtype == np.float64 and d.flags.writeable and ir.data is d
+    assert rel(d, g["final_FL_left"]) <= 2e-6
+    assert np.array_equal(ir.recording, pcm[0, 2 * fs: 2 * fs + len(e) + 2 * fs].astype(np.float64) / 2 ** 31)
+    d *= 0.5                                                      # in-place mutation, as the reference's callers do
+    assert np.array_equal(ir.data, d)
+    import copy
+    import pickle
+    twin = pickle.loads(pickle.dumps(h_dev.irs["FR"]["right"]))
+    assert np.array_equal(twin.data, h_dev.irs["FR"]["right"].peek()) and twin.fs == fs
+    assert np.array_equal(copy.deepcopy(h_dev).irs["FR"]["left"].data, h_dev.irs["FR"]["left"].peek())

@@ -28,12 +28,14 @@ def main():
     for i in range(8):
         for ear in range(2):
             tracks[ear, 2 * fs + i * L: 2 * fs + (i + 1) * L] = cols[2 * i + ear, :L]
-    rec = [((fs, tracks), speakers)]
+    # the recording as a capture buffer / WAV data chunk holds it: interleaved 32-bit PCM frames
+    frames = np.ascontiguousarray(np.clip(np.rint(tracks.T * 2.0 ** 31), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int32))
+    rec = [((fs, frames), speakers)]
     run_slice(est, rec)                                  # warm-up: plans, twiddles, K6 roots
     stages = {}
     t0 = time.perf_counter()
     for _ in range(reps):
-        run_slice(est, rec)
+        run_slice(est, rec)[0].to_host()                     # float64 host arrays out
     dt = (time.perf_counter() - t0) / reps
     print(f"slice: {dt * 1e3:.1f} ms per 16-channel measurement = {16 / dt:.0f} IR/s end to end (host arrays in, host arrays out)")
     if "--profile" in sys.argv:
