@@ -182,6 +182,77 @@ def slice_rate(est, rec, L, reps=3):
                 note="end to end: PCM frames in host memory -> float64 responses in host memory, incl. PCIe; 16 IRs per measurement; not the headline metric")
 
 
+def deconv_fir_leg(ctx, est, rec, L, pitch, reps=300):
+    """The metric's "+FIR" on device pointers: one 7.1 x 2-ear measurement resident in HBM goes through K1 (deconvolution)
+    -> K3 (first-peak search, indices to the host) -> K4 (head crop at peak - 1 ms, 0.68 s long, Hann fades, compacted) ->
+    K5 (per-channel 9 600-tap FIRs whose spectra are cached in the plan); nothing but 16 peak indices crosses the bus.
+    Algorithmic bytes per IR: 4 L in + 4 (n + K - 1) out."""
+    from impulse_hip import ConvPlan
+    from oracle.estimator import estimate
+    from oracle.scipy_restated import fft_convolve, hann
+    fs, B = est.fs, rec.shape[0]
+    n, K, head = int(0.68 * fs), 9600, fs // 1000
+    fade = 2 * int(fs * (len(est) / fs / est.n_octaves) * (1 / 24)) // 2
+    rng = np.random.default_rng(0xF1)
+    firs = rng.standard_normal((B, K)) * np.exp(-np.arange(K) / 400.0) * 0.05
+    firs[:, 0] += 1.0
+    plan1 = ConvPlan(ctx, np.asarray(est.inverse_filter, dtype=np.float64), L, "same", ws_channels=B)
+    plan5 = ConvPlan(ctx, firs, n, "full", ws_channels=B)
+    pn, po = (n + 63) // 64 * 64, (n + K - 1 + 63) // 64 * 64
+    d_x, d_ir = ctx.malloc(B * pitch * 4), ctx.malloc(B * pitch * 4)
+    d_crop, d_out = ctx.malloc(B * pn * 4), ctx.malloc(B * po * 4)
+    ctx.h2d(d_x, rec)
+    offs = np.arange(B, dtype=np.int64) * pitch
+    lens = np.full(B, L, dtype=np.int64)
+    win = [dict(fade_in=head, fade_out=fade)] * B
+    dst = np.arange(B, dtype=np.int64) * pn
+    peaks = [None]
+
+    def once():
+        plan1.execute_device(d_x, B, pitch, d_ir, pitch)
+        idx, _ = ctx.peak_index_device(d_ir, offs, lens)
+        starts = np.minimum(np.maximum(idx - head, 0), L - n)
+        ctx.apply_window_device(d_ir, offs + starts, d_crop, dst, [n] * B, win)
+        plan5.execute_device(d_crop, B, pn, d_out, po)
+        peaks[0] = idx
+
+    try:
+        for _ in range(10):
+            once()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            once()
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        y = np.empty((B, po), dtype=np.float32)
+        ctx.d2h(y, d_out)
+    finally:
+        for p in (d_x, d_ir, d_crop, d_out):
+            ctx.free(p)
+        plan1.close()
+        plan5.close()
+    errs, peaks_ok = [], True
+    w = np.ones(n)
+    w[:head] *= hann(2 * head)[:head]
+    w[n - fade:] *= hann(2 * fade)[fade:]
+    for c in (0, B - 1):
+        ir = estimate(rec[c, :L].astype(np.float64), np.asarray(est.inverse_filter, dtype=np.float64))
+        from oracle.impulse_response import peak_index
+        pk = peak_index(ir)
+        peaks_ok &= pk == int(peaks[0][c])
+        s0 = min(max(pk - head, 0), L - n)
+        ref = fft_convolve(ir[s0:s0 + n] * w, firs[c], "full")
+        errs.append(float(np.max(np.abs(y[c, :n + K - 1] - ref)) / np.max(np.abs(ref))))
+    alg = B * (4.0 * L + 4.0 * (n + K - 1))
+    return dict(value=B / dt, unit="IR/s", ms_per_measurement=dt * 1e3, channels=B,
+                stages="K1 deconvolution -> K3 first peak (16 indices to the host) -> K4 crop (peak - 1 ms, 0.68 s) + Hann fades "
+                       "-> K5 per-channel 9 600-tap FIR (spectra cached in the plan); device pointers throughout, one launch "
+                       "group at a time (two host round trips per measurement: the peak indices, the crop offsets)",
+                algorithmic_bytes_per_measurement=alg, achieved_GBps=alg / dt / 1e9, frac_of_hbm_peak=alg / dt / 1e9 / HBM_PEAK_GBS,
+                parity=dict(peak_indices_exact=bool(peaks_ok), time_max_rel_err=max(errs), tolerance=1e-6, channels_checked=2))
+
+
 def cpu_baseline(est, rec, L, budget_s=12.0):
     """The oracle's restatement of estimate() (float64, nfft = next_fast_len, rfft(h) recomputed per
     call exactly like core/impulse_response_estimator.py:149-151), serial over channels as the
@@ -315,6 +386,21 @@ def rehearse_launch(args, rank, world):
     return 0
 
 
+def spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world, tag):
+    """The path's one collective.  With the RCCL backend the LIBRARY does it (imp_comm_* over librccl; the 128-byte
+    unique id travels through a file private to this launch) - torch.distributed only provides the launcher's barriers
+    and clock reductions; the gloo rehearsal stages the bytes through host memory instead."""
+    from impulse_hip.sharding import broadcast_plan_spectrum, broadcast_plan_spectrum_rccl
+    if backend != "nccl" or os.environ.get("IMPULSE_BENCH_BCAST", "lib") != "lib":
+        return broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0, via_host=(backend != "nccl"))
+    import tempfile
+    run = os.environ.get("TORCHELASTIC_RUN_ID", "single") + "_" + os.environ.get("MASTER_PORT", "0")
+    path = os.path.join(tempfile.gettempdir(), f"impulse_rccl_{run}_{tag}.id")
+    n = broadcast_plan_spectrum_rccl(plan, ctx, rank, world, path)
+    dist.barrier()
+    return n
+
+
 class DeviceBatch:
     """A workload resident in HBM: plan, rotating input sets, per-lane output buffers (torch = device memory
     plumbing only)."""
@@ -374,7 +460,7 @@ def strong_block(args, torch, dist, device, comm_device, ctx, rank, world, backe
         plan = ConvPlan(ctx, None, M, "same", ws_channels=lanes * grp, empty_M=M, n_filters=1)
     bcast = 0
     if dist is not None:
-        bcast = broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0, via_host=(backend != "nccl"))
+        bcast = spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world, "c5")
     base, L, pitch, dl = synth_recordings(est, 64, seed0=0xC5, column=M)
     d_base = torch.from_numpy(base).to(device)
 
@@ -516,8 +602,7 @@ def main(argv=None):
         plan = ConvPlan(ctx, None, L, "same", ws_channels=ws_channels, empty_M=M, n_filters=1)
     bcast_bytes = 0
     if dist is not None:
-        bcast_bytes = broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0,
-                                              via_host=(backend != "nccl"))   # RCCL over xGMI
+        bcast_bytes = spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world, "c2")
 
     # Successive measurements read DIFFERENT copies of the batch, 1 GiB in rotation, so that no input line survives in
     # the 256 MiB Infinity Cache from one use to the next: inputs come from HBM, as a stream of new measurements would.
@@ -665,6 +750,13 @@ def main(argv=None):
                 whole_slice = slice_rate(est, rec, L)
             except Exception as exc:                          # noqa: BLE001 - secondary figure only
                 whole_slice = dict(error=repr(exc))
+        fir_leg = None
+        if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
+            try:
+                fir_leg = deconv_fir_leg(ctx, est, rec, L, pitch)
+                peaks_ok &= fir_leg["parity"]["peak_indices_exact"] and fir_leg["parity"]["time_max_rel_err"] <= 1e-6
+            except Exception as exc:                          # noqa: BLE001 - secondary figure only
+                fir_leg = dict(error=repr(exc))
         result = {
             "metric": METRIC, "value": value, "unit": "IR/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -672,7 +764,7 @@ def main(argv=None):
             "timed_region_s": elapsed, "irs_per_step": irs_per_step, "ranks_seen": ranks_seen,
             "config": {"workload": desc, "stage": "K1 ONLY: batched sweep deconvolution incl. 'same' crop "
                        "(inverse-filter spectrum prepared once, outside the timed region); the FIR stages are not in the "
-                       "timed region (see `slice` / deconv_fir for figures that include them)",
+                       "timed region (`deconv_fir` = K1 -> peak -> crop -> K5 FIR on device pointers; `slice` = the whole hot-path slice end to end)",
                        "step": f"one pass over {n_sets} resident measurements of {B} channels per GPU",
                        "channels_per_gpu_per_measurement": B, "measurements_per_step": n_sets,
                        "sweep_samples": M, "column_samples": L,
@@ -680,10 +772,11 @@ def main(argv=None):
                                  f"{wl.skew} samples into 256-byte aligned buffers so the cropped stores fall on cache lines",
                        "nfft": nfft, "launch_groups_in_flight": lanes, "workspace_channels": plan_ws,
                        "sharding": (f"channels x{world}, no data-path collective; "
-                                    f"one {'RCCL' if backend == 'nccl' else backend + ' (rehearsal)'} broadcast of "
+                                    f"one {'RCCL (by libimpulse_hip, no torch in the data path)' if backend == 'nccl' else backend + ' (rehearsal)'} broadcast of "
                                     f"{bcast_bytes} B spectrum at plan creation") if dist is not None else
                                    "single rank: no collective"},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "slice": whole_slice, "strong_c5": strong_c5,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "slice": whole_slice, "deconv_fir": fir_leg,
+            "strong_c5": strong_c5,
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(result) + "\n").encode())

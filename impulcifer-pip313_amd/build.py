@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libimpulse_hip.so")
-SOURCES = ["impulse_hip.hip", "minphase.hip", "curves.hip"]
+SOURCES = ["impulse_hip.hip", "minphase.hip", "curves.hip", "comm.hip"]
 HEADERS = ["conv_kernels.hip.h", "xcd_kernels.hip.h", "fft_regs.hip.h", "ir_kernels.hip.h", "internal.h",
            os.path.join("..", "..", "include", "impulse_hip.h")]
 
@@ -37,7 +37,7 @@ def build_variant(name, defines):
     """Diagnostic builds (tools/): csrc/libimpulse_hip_<name>.so with extra -D flags."""
     out = os.path.join(CSRC, f"libimpulse_hip_{name}.so")
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
-    cmd += [f"-D{d}" for d in defines] + SOURCES + ["-o", out]
+    cmd += [f"-D{d}" for d in defines] + SOURCES + ["-ldl", "-o", out]
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout + res.stderr)
@@ -49,7 +49,7 @@ def build_library(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-unused-value"] + SOURCES + ["-o", LIB + ".tmp"]
+           "-Wno-unused-value"] + SOURCES + ["-ldl", "-o", LIB + ".tmp"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)

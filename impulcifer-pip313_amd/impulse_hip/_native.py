@@ -73,6 +73,11 @@ SIGNATURES = {
     "imp_conv_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64]),
     "imp_conv_execute_device_pcm": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _i64]),
     "imp_plan_set_overlap": (C.c_int, [_vp, C.c_int]),
+    "imp_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
+    "imp_comm_create": (C.c_int, [_vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(_vp)]),
+    "imp_comm_destroy": (None, [_vp]),
+    "imp_comm_broadcast": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
+    "imp_plan_broadcast_spectrum": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(C.c_size_t)]),
     "imp_plan_set_filters": (C.c_int, [_vp, _pd, _i64]),
     "imp_plan_set_resident": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "imp_plan_resident_status": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong)]),
@@ -467,6 +472,48 @@ class SegSet:
         if getattr(self, "_h", None):
             if getattr(self.ctx, "_h", None):
                 self._lib.imp_segset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+def comm_unique_id():
+    """128 bytes that identify a new RCCL communicator (rank 0 makes them and shares them with the other ranks)."""
+    buf = (C.c_ubyte * 128)()
+    _check(load_library().imp_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """RCCL communicator of one rank (imp_comm): collective construction, broadcast of device buffers."""
+
+    def __init__(self, ctx, unique_id, rank, nranks):
+        if len(unique_id) != 128:
+            raise ValueError("the unique id is 128 bytes")
+        self.ctx, self._lib = ctx, ctx._lib
+        self.rank, self.nranks = int(rank), int(nranks)
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        h = _vp()
+        _check(self._lib.imp_comm_create(ctx.handle, buf, self.rank, self.nranks, C.byref(h)))
+        self._h = h
+        ctx._plans.add(self)
+
+    def broadcast(self, dptr, nbytes, root=0):
+        _check(self._lib.imp_comm_broadcast(self._h, _vp(int(dptr)), int(nbytes), int(root)))
+
+    def broadcast_plan_spectrum(self, plan, root=0):
+        n = C.c_size_t(0)
+        _check(self._lib.imp_plan_broadcast_spectrum(plan.handle, self._h, int(root), C.byref(n)))
+        return int(n.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if getattr(self.ctx, "_h", None):
+                self._lib.imp_comm_destroy(self._h)
             self._h = None
 
     def __del__(self):

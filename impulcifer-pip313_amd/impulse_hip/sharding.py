@@ -55,6 +55,51 @@ def broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0, via_host=Fals
     return nbytes
 
 
+def share_unique_id(rank, path, make_id=None, timeout_s=120.0):
+    """File rendezvous for the 128-byte RCCL unique id: rank 0 creates it (make_id()) and publishes it at ``path``
+    (written beside and renamed, so a reader never sees half of it); every other rank waits for the file.  ``path``
+    must be private to one launch (bench.py derives it from the launcher's run id and port)."""
+    import os
+    import time
+    if rank == 0:
+        uid = make_id()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as fh:
+            fh.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.monotonic()
+    while True:
+        try:
+            with open(path, "rb") as fh:
+                uid = fh.read()
+            if len(uid) == 128:
+                return uid
+        except FileNotFoundError:
+            pass
+        if time.monotonic() - t0 > timeout_s:
+            raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout_s:.0f} s")
+        time.sleep(0.01)
+
+
+def broadcast_plan_spectrum_rccl(plan, ctx, rank, world_size, rendezvous_path, src=0):
+    """The spectrum broadcast done by libimpulse_hip itself over RCCL (imp_comm_*): no torch, no mpi4py.  Collective:
+    every rank calls it with the same rendezvous_path.  Returns the bytes broadcast."""
+    from . import _native
+    uid = share_unique_id(rank, rendezvous_path, _native.comm_unique_id)
+    comm = _native.Comm(ctx, uid, rank, world_size)
+    try:
+        return comm.broadcast_plan_spectrum(plan, root=src)
+    finally:
+        comm.close()
+        if rank == 0:
+            import os
+            try:
+                os.remove(rendezvous_path)
+            except OSError:
+                pass
+
+
 def split_evenly(total, parts):
     """Sizes of ``parts`` near-equal chunks of ``total`` items."""
     base, extra = divmod(int(total), int(parts))

@@ -308,6 +308,22 @@ int imp_segset_create_device(imp_ctx* ctx, const float* d_x, const int64_t* off,
 int imp_magnitude_db_sum_device(imp_ctx* ctx, const float* d_rows, const int64_t* off, const int64_t* len,
                                 const int64_t* group, int64_t n_rows, int64_t n_groups, int64_t n, double* db_out);
 
+/* ---- the one collective: RCCL broadcast of the prepared filter spectrum -----------------------------
+ * Channels shard across GPUs with no data-path collective; the only shared datum is the inverse-sweep spectrum rank 0
+ * prepares.  The library does that broadcast itself over RCCL (xGMI inside a node), so the host side needs no
+ * communication package: rank 0 calls imp_comm_unique_id and hands the 128 bytes to the other ranks by whatever the
+ * launcher offers (an environment variable, a file, a socket); every rank then calls imp_comm_create with its rank
+ * and the world size (collective), imp_plan_broadcast_spectrum on a plan of the same geometry (rank != root: made
+ * with imp_conv_plan_create_empty), and imp_comm_destroy.  librccl is opened on first use. */
+typedef struct imp_comm imp_comm;
+int imp_comm_unique_id(unsigned char id_out[128]);
+int imp_comm_create(imp_ctx* ctx, const unsigned char id[128], int rank, int nranks, imp_comm** out);
+void imp_comm_destroy(imp_comm* c);
+/* in-place broadcast of `bytes` at device pointer dptr from rank `root`; returns when the data has arrived */
+int imp_comm_broadcast(imp_comm* c, void* dptr, size_t bytes, int root);
+/* imp_plan_spectrum + imp_comm_broadcast; *bytes_out (may be NULL) = bytes moved */
+int imp_plan_broadcast_spectrum(imp_plan* plan, imp_comm* c, int root, size_t* bytes_out);
+
 #ifdef __cplusplus
 }
 #endif

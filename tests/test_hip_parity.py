@@ -1853,3 +1853,30 @@ def test_device_resident_stages_equal_the_host_array_stages(gpu_ctx, golden):
     twin = pickle.loads(pickle.dumps(h_dev.irs["FR"]["right"]))
     assert np.array_equal(twin.data, h_dev.irs["FR"]["right"].peek()) and twin.fs == fs
     assert np.array_equal(copy.deepcopy(h_dev).irs["FR"]["left"].data, h_dev.irs["FR"]["left"].peek())
+
+
+def test_library_rccl_broadcast_single_rank(gpu_ctx, tmp_path):
+    """imp_comm_*: the spectrum broadcast by the library itself over RCCL (one rank on this one-GPU box: communicator
+    creation from a unique id shared through a file, in-place broadcast of the plan's spectrum, teardown)."""
+    from impulse_hip import ConvPlan
+    from impulse_hip._native import Comm, comm_unique_id
+    from impulse_hip.sharding import broadcast_plan_spectrum_rccl
+    h = np.random.default_rng(3).standard_normal(5000)
+    plan = ConvPlan(gpu_ctx, h, 20000, "same")
+    x = np.random.default_rng(4).standard_normal((2, 20000)).astype(np.float32)
+    before = plan.execute(x)
+    n = broadcast_plan_spectrum_rccl(plan, gpu_ctx, 0, 1, str(tmp_path / "uid"))
+    assert n == plan.spectrum_buffer()[1] == plan.n1 * 4096 * 16
+    assert np.array_equal(plan.execute(x), before)              # root's buffer is unchanged by its own broadcast
+    uid = comm_unique_id()
+    assert len(uid) == 128
+    comm = Comm(gpu_ctx, uid, 0, 1)
+    d = gpu_ctx.malloc(4096)
+    gpu_ctx.h2d(d, np.arange(1024, dtype=np.float32))
+    comm.broadcast(d, 4096, root=0)
+    back = np.empty(1024, dtype=np.float32)
+    gpu_ctx.d2h(back, d)
+    gpu_ctx.free(d)
+    comm.close()
+    plan.close()
+    assert np.array_equal(back, np.arange(1024, dtype=np.float32))

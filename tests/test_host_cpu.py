@@ -368,3 +368,27 @@ def test_product_from_wav_branches(golden, tmp_path):
     path = str(tmp_path / "two.wav")
     r2.write_pcm32(path, 48000, np.vstack([r2.off_grid_sweep(), np.zeros(1 << 17)]))
     assert len(ImpulseResponseEstimator.from_wav(path)) == 1 << 17
+
+
+def test_unique_id_file_rendezvous(tmp_path):
+    """The 128-byte RCCL id reaches the other ranks through a file published atomically by rank 0 (no torch)."""
+    import threading
+    from impulse_hip.sharding import share_unique_id
+    path = str(tmp_path / "uid")
+    want = bytes(range(128))
+    got = {}
+
+    def reader(r):
+        got[r] = share_unique_id(r, path, timeout_s=30)
+
+    threads = [threading.Thread(target=reader, args=(r,)) for r in (1, 2, 3)]
+    for t in threads:
+        t.start()
+    import time
+    time.sleep(0.05)
+    assert share_unique_id(0, path, lambda: want) == want
+    for t in threads:
+        t.join(30)
+    assert got == {1: want, 2: want, 3: want}
+    with pytest.raises(TimeoutError):
+        share_unique_id(1, str(tmp_path / "never"), timeout_s=0.05)
