@@ -18,11 +18,11 @@ GROUPS = {"c2": "16 channels at circular length 589824", "c3": "9 channels at ci
 
 def main(out, tag="r01"):
     prof = os.path.join(ROOT, "profiles")
-    kt = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 400 --warmup 20 "
+    kt = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 2 "
                      "--no-cpu-baseline  (tools/run_profiles.sh)",
-          "note": "bench.py spends 0.25 s ramping the clocks, then warm-up, 400 timed overlapped steps (3 launch groups in "
-                  "flight) and 40 strictly serial ones for the isolated roofline; the kernel_stats.csv averages over ALL launches "
-                  "of each kernel (ramp included), this file splits out the timed region and the serial tail",
+          "note": "bench.py runs 2 warm-up steps, 10 timed steps (a step = 40 resident measurements = 40 launch groups, 3 "
+                  "groups in flight) and 40 strictly serial launch groups for the isolated roofline; the kernel_stats.csv "
+                  "averages over ALL launches of each kernel, this file splits out the timed region and the serial tail",
           "kernels": profile_summary.main(os.path.join(out, "trace"), 400)}
     json.dump(kt, open(os.path.join(prof, f"{tag}_kernel_trace_summary.json"), "w"), indent=1)
     for root, _, files in os.walk(os.path.join(out, "trace")):
@@ -47,9 +47,9 @@ def main(out, tag="r01"):
                               "WRITE_SIZE)*1024 per the gfx950 correction in MI355X_MICROARCH.md (FETCH_SIZE reports half of a "
                               "coalesced read stream; calibrated on the inverse column pass whose read volume is known); one launch = "
                               + what}
-    json.dump(traffic, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(prof, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py "
-                          "--workload W --lanes 1 --no-events --no-ramp --no-cpu-baseline  (tools/run_profiles.sh)",
+                          "--workload W --lanes 1 --no-events --no-cpu-baseline  (tools/run_profiles.sh)",
                "unit": "KB per launch, raw counter values (FETCH_SIZE needs the x2 gfx950 correction)", "workloads": pmc_all},
               open(os.path.join(prof, f"{tag}_pmc_summary.json"), "w"), indent=1)
     print(json.dumps(traffic, indent=1))
@@ -57,4 +57,4 @@ def main(out, tag="r01"):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r02")

@@ -7,11 +7,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_round
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $R/bench.py --steps 400 --warmup 20 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 for W in c2 c3 c5; do
-  ST=20; [ $W = c5 ] && ST=2
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_$W/fetch -o p -- python3 $R/bench.py --workload $W --steps $ST --warmup 2 --no-cpu-baseline --lanes 1 --no-events --no-ramp > $OUT/bench_pmc_${W}_1.json 2> $OUT/bench_pmc_${W}_1.err
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_$W/write -o p -- python3 $R/bench.py --workload $W --steps $ST --warmup 2 --no-cpu-baseline --lanes 1 --no-events --no-ramp > $OUT/bench_pmc_${W}_2.json 2> $OUT/bench_pmc_${W}_2.err
+  ST=1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_$W/fetch -o p -- python3 $R/bench.py --workload $W --steps $ST --warmup 2 --no-cpu-baseline --lanes 1 --no-events > $OUT/bench_pmc_${W}_1.json 2> $OUT/bench_pmc_${W}_1.err
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_$W/write -o p -- python3 $R/bench.py --workload $W --steps $ST --warmup 2 --no-cpu-baseline --lanes 1 --no-events > $OUT/bench_pmc_${W}_2.json 2> $OUT/bench_pmc_${W}_2.err
 done
 cd $R
-python3 tools/assemble_profiles.py $OUT
+python3 tools/assemble_profiles.py $OUT ${ROUND_TAG:-r02}
