@@ -181,3 +181,13 @@ def generic_room_correction(ir_datas, fs, target_raw, mic_calibration_raw=None, 
         error = error * mask
         error_smoothed = error_smoothed * mask
     return freq, raw, error, error_smoothed
+
+
+def headphone_curves(ir_left, ir_right, fs):
+    """core/pipeline_stages.py:424-443: frequency responses of FL-left and FR-right (un-cropped responses), both shifted
+    by the gain that centres the LEFT one between 100 Hz and 10 kHz; compensate(zero target, min_mean_error=False)
+    leaves error = raw.  Returns (frequency, raw_left, raw_right)."""
+    f, left = ir_frequency_response(ir_left, fs)
+    _, right = ir_frequency_response(ir_right, fs)
+    shift = center_shift(f, left, [100, 10000])
+    return f, left - shift, right - shift

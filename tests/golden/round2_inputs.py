@@ -117,3 +117,21 @@ def room_folder(dir_path, test_signal, with_generic=True, generic_positions=3):
         fh.write("frequency,raw\n" + "".join(f"{a:.1f},{b:.2f}\n" for a, b in zip(f, tgt)))
     with open(os.path.join(dir_path, "room-mic-calibration.csv"), "w") as fh:
         fh.write("frequency,raw\n" + "".join(f"{a:.1f},{b:.2f}\n" for a, b in zip(f, cal)))
+
+
+def headphone_file(path, test_signal):
+    """headphones.wav: two tracks (left cup, right cup), two columns (FL then FR): FL plays into the left cup only, FR
+    into the right cup only, each through its own short "headphone" response; the other cup records leakage noise."""
+    N, fs = len(test_signal), FS
+    col = 2 * fs + N
+    total = 2 * fs + 2 * col
+    tracks = np.zeros((2, total))
+    for i in range(2):                                            # column i: speaker FL (0) / FR (1); loud cup = i
+        rng = np.random.default_rng(0xE0 + i)
+        h = np.zeros(600)
+        h[20 + 3 * i] = 0.8 - 0.1 * i
+        h[21 + 3 * i: 300] += rng.standard_normal(279 - 3 * i) * 0.15 * np.exp(-np.arange(279 - 3 * i) / 25.0)
+        h = np.concatenate([h, np.zeros(ROOM_LEN - len(h))])
+        tracks[i] += _play(test_signal, h, total, 2 * fs + i * col, 0xE8 + i)
+        tracks[1 - i] += np.random.default_rng(0xEC + i).standard_normal(total) * 10 ** (-80 / 20)
+    write_pcm32(path, fs, tracks)

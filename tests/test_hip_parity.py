@@ -1880,3 +1880,30 @@ def test_library_rccl_broadcast_single_rank(gpu_ctx, tmp_path):
     comm.close()
     plan.close()
     assert np.array_equal(back, np.arange(1024, dtype=np.float32))
+
+
+def test_headphone_compensation_matches_reference_run(gpu_ctx, golden, tmp_path):
+    """headphone_compensation() (core/pipeline_stages.py:353-482) on a synthetic stereo headphone measurement: the
+    two error curves the EQ worker adds to every channel, and the file resolution rules."""
+    import round2_inputs as r2
+    from impulse_hip.headphone_compensation import headphone_compensation, resolve_headphone_file
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    g = golden("round2")
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+    r2.headphone_file(str(tmp_path / "headphones.wav"), e.test_signal)
+    left, right = headphone_compensation(e, str(tmp_path))
+    assert os.path.isfile(tmp_path / "headphone-responses.wav")
+    np.testing.assert_array_equal(left.frequency, g["hp_freq"])
+    for nm, fr in (("left", left), ("right", right)):
+        assert np.max(np.abs(fr.raw - g[f"hp_{nm}_raw"])) < 5e-3         # dB curves from fp32 responses
+        assert np.max(np.abs(fr.error - g[f"hp_{nm}_error"])) < 5e-3
+        assert not np.any(fr.target)
+    assert headphone_compensation(e, str(tmp_path / "nowhere")) == (None, None)
+    # resolution rules: explicit relative file, directory with a fallback name, directory with some other WAV
+    (tmp_path / "sub").mkdir()
+    os.rename(tmp_path / "headphones.wav", tmp_path / "sub" / "hp.wav")
+    assert resolve_headphone_file(str(tmp_path), "sub/hp.wav") == str(tmp_path / "sub" / "hp.wav")
+    assert resolve_headphone_file(str(tmp_path), str(tmp_path / "sub")) == str(tmp_path / "sub" / "hp.wav")
+    os.rename(tmp_path / "sub" / "hp.wav", tmp_path / "sub" / "other.WAV")
+    assert resolve_headphone_file(str(tmp_path), str(tmp_path / "sub")) == str(tmp_path / "sub" / "other.WAV")
+    assert resolve_headphone_file(str(tmp_path), "missing.wav") is None

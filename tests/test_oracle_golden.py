@@ -476,3 +476,24 @@ def test_room_correction_top_level(golden, tmp_path, name, method, slimit, glimi
             np.testing.assert_allclose(raw, g[f"rc_{name}_{sp}_{sd}_raw"], rtol=0, atol=1e-9)
             np.testing.assert_allclose(err, g[f"rc_{name}_{sp}_{sd}_error"], rtol=0, atol=1e-9)
             np.testing.assert_allclose(err_s, g[f"rc_{name}_{sp}_{sd}_error_smoothed"], rtol=0, atol=1e-9)
+
+
+def test_headphone_compensation_curves(golden, tmp_path):
+    from scipy.io import wavfile
+    from oracle import frequency_response as ofr
+    g, r2 = golden("round2"), _r2()
+    fs = 48000
+    e = oest.Estimator(1.0, fs)
+    path = tmp_path / "headphones.wav"
+    r2.headphone_file(str(path), e.test_signal)
+    pcm = wavfile.read(path)[1].astype(np.float64).T / 2 ** 31            # [2 tracks, n]
+    col = 2 * fs + len(e)
+    fl_left = e.estimate(pcm[0, 2 * fs: 2 * fs + col])                    # column 0 = FL, track 0 = left
+    fr_right = e.estimate(pcm[1, 2 * fs + col: 2 * fs + 2 * col])         # column 1 = FR, track 1 = right
+    f, left, right = ofr.headphone_curves(fl_left, fr_right, fs)
+    np.testing.assert_array_equal(f, g["hp_freq"])
+    for nm, raw in (("left", left), ("right", right)):
+        np.testing.assert_allclose(raw, g[f"hp_{nm}_raw"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(raw, g[f"hp_{nm}_error"], rtol=0, atol=1e-9)
+        assert not np.any(g[f"hp_{nm}_target"])
+    assert tuple(g["hp_responses_shape"]) == (col, 32) and bool(g["hp_missing"][0])
