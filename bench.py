@@ -388,15 +388,16 @@ def rehearse_launch(args, rank, world):
 
 def spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world, tag):
     """The path's one collective.  With the RCCL backend the LIBRARY does it (imp_comm_* over librccl; the 128-byte
-    unique id travels through a file private to this launch) - torch.distributed only provides the launcher's barriers
+    communicator id is handed round by the launcher's process group) - torch.distributed only provides the launcher's barriers
     and clock reductions; the gloo rehearsal stages the bytes through host memory instead."""
     from impulse_hip.sharding import broadcast_plan_spectrum, broadcast_plan_spectrum_rccl
     if backend != "nccl" or os.environ.get("IMPULSE_BENCH_BCAST", "lib") != "lib":
         return broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0, via_host=(backend != "nccl"))
-    import tempfile
-    run = os.environ.get("TORCHELASTIC_RUN_ID", "single") + "_" + os.environ.get("MASTER_PORT", "0")
-    path = os.path.join(tempfile.gettempdir(), f"impulse_rccl_{run}_{tag}.id")
-    n = broadcast_plan_spectrum_rccl(plan, ctx, rank, world, path)
+    # the communicator id is 128 bytes of control plane: rank 0 makes it, the launcher's process group hands it round
+    from impulse_hip._native import comm_unique_id
+    box = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    n = broadcast_plan_spectrum_rccl(plan, ctx, rank, world, unique_id=box[0])
     dist.barrier()
     return n
 

@@ -82,18 +82,23 @@ def share_unique_id(rank, path, make_id=None, timeout_s=120.0):
         time.sleep(0.01)
 
 
-def broadcast_plan_spectrum_rccl(plan, ctx, rank, world_size, rendezvous_path, src=0):
-    """The spectrum broadcast done by libimpulse_hip itself over RCCL (imp_comm_*): no torch, no mpi4py.  Collective:
-    every rank calls it with the same rendezvous_path.  Returns the bytes broadcast."""
+def broadcast_plan_spectrum_rccl(plan, ctx, rank, world_size, unique_id=None, rendezvous_path=None, src=0):
+    """The spectrum broadcast done by libimpulse_hip itself over RCCL (imp_comm_*): no torch, no mpi4py in the data
+    path.  Collective.  The 128-byte communicator id is either given (``unique_id``: made by rank 0 with
+    _native.comm_unique_id() and handed round by the launcher's own control plane) or exchanged through a file
+    (``rendezvous_path``: must be private to this launch and must not exist beforehand).  Returns the bytes broadcast."""
+    import os
     from . import _native
-    uid = share_unique_id(rank, rendezvous_path, _native.comm_unique_id)
-    comm = _native.Comm(ctx, uid, rank, world_size)
+    if unique_id is None:
+        if rendezvous_path is None:
+            raise ValueError("give the communicator id or a rendezvous path")
+        unique_id = share_unique_id(rank, rendezvous_path, _native.comm_unique_id)
+    comm = _native.Comm(ctx, unique_id, rank, world_size)
     try:
         return comm.broadcast_plan_spectrum(plan, root=src)
     finally:
         comm.close()
-        if rank == 0:
-            import os
+        if rank == 0 and rendezvous_path is not None:
             try:
                 os.remove(rendezvous_path)
             except OSError:

@@ -1865,7 +1865,8 @@ def test_library_rccl_broadcast_single_rank(gpu_ctx, tmp_path):
     plan = ConvPlan(gpu_ctx, h, 20000, "same")
     x = np.random.default_rng(4).standard_normal((2, 20000)).astype(np.float32)
     before = plan.execute(x)
-    n = broadcast_plan_spectrum_rccl(plan, gpu_ctx, 0, 1, str(tmp_path / "uid"))
+    n = broadcast_plan_spectrum_rccl(plan, gpu_ctx, 0, 1, rendezvous_path=str(tmp_path / "uid"))
+    assert not os.path.exists(tmp_path / "uid")
     assert n == plan.spectrum_buffer()[1] == plan.n1 * 4096 * 16
     assert np.array_equal(plan.execute(x), before)              # root's buffer is unchanged by its own broadcast
     uid = comm_unique_id()
