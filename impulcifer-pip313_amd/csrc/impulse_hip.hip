@@ -1713,6 +1713,49 @@ extern "C" int imp_apply_window_device(imp_ctx* ctx, const float* d_src, const i
   return IMP_OK;
 }
 
+extern "C" int imp_rows_to_pcm_device(imp_ctx* ctx, const float* d_rows, const int64_t* off, const int64_t* len,
+                                      int64_t n_rows, const int64_t* row_of_track, int64_t n_tracks, int64_t n_frames,
+                                      int bits, void* pcm_out) {
+  if (!ctx || !d_rows || !off || !len || !row_of_track || !pcm_out)
+    return fail(IMP_ERR_INVALID, "imp_rows_to_pcm_device: null argument");
+  IMP_CTX_LOCK(ctx);
+  if (bits != 16 && bits != 24 && bits != 32) return fail(IMP_ERR_INVALID, "Invalid bit depth. Accepted values are 16, 24 and 32.");
+  if (n_rows < 0 || n_tracks < 1 || n_tracks > 4096 || n_frames < 0) return fail(IMP_ERR_INVALID, "imp_rows_to_pcm_device: bad sizes");
+  for (int64_t r = 0; r < n_rows; ++r)
+    if (off[r] < 0 || len[r] < 0) return fail(IMP_ERR_INVALID, "negative offset/length in row %lld", (long long)r);
+  for (int64_t t = 0; t < n_tracks; ++t)
+    if (row_of_track[t] < -1 || row_of_track[t] >= n_rows) return fail(IMP_ERR_INVALID, "track %lld names row %lld", (long long)t, (long long)row_of_track[t]);
+  if (n_frames == 0) return IMP_OK;
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  const size_t sample = bits == 16 ? 2 : 4;
+  const size_t out_bytes = (size_t)n_frames * (size_t)n_tracks * sample;
+  const size_t meta = (size_t)(2 * std::max<int64_t>(n_rows, 1) + n_tracks) * sizeof(int64_t);
+  char* d_buf = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_buf, meta + out_bytes));
+  int64_t* d_off = (int64_t*)d_buf;
+  int64_t* d_len = d_off + std::max<int64_t>(n_rows, 1);
+  int64_t* d_map = d_len + std::max<int64_t>(n_rows, 1);
+  void* d_out = d_buf + meta;
+  auto done = [&](int code) {
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(d_buf);
+    return code;
+  };
+  if ((n_rows && (hipMemcpyAsync(d_off, off, (size_t)n_rows * sizeof(int64_t), hipMemcpyHostToDevice, s) != hipSuccess ||
+                  hipMemcpyAsync(d_len, len, (size_t)n_rows * sizeof(int64_t), hipMemcpyHostToDevice, s) != hipSuccess)) ||
+      hipMemcpyAsync(d_map, row_of_track, (size_t)n_tracks * sizeof(int64_t), hipMemcpyHostToDevice, s) != hipSuccess)
+    return done(fail(IMP_ERR_HIP, "imp_rows_to_pcm_device: upload failed"));
+  const int64_t total = n_frames * n_tracks;
+  hipLaunchKernelGGL(imp::rows_to_pcm_kernel, dim3((unsigned)std::min<int64_t>(4096, (total + 255) / 256)), dim3(256), 0, s, d_rows,
+                     d_off, d_len, d_map, (int)n_tracks, n_frames, bits, d_out);
+  if (hipGetLastError() != hipSuccess) return done(fail(IMP_ERR_HIP, "imp_rows_to_pcm_device: launch failed"));
+  if (hipMemcpyAsync(pcm_out, d_out, out_bytes, hipMemcpyDeviceToHost, s) != hipSuccess)
+    return done(fail(IMP_ERR_HIP, "imp_rows_to_pcm_device: download failed"));
+  return done(IMP_OK);
+}
+
 #ifdef IMP_PHASE_TRACE
 // Diagnostic build only (not in include/impulse_hip.h): copies the rows-kernel phase marks to the host.
 extern "C" int imp_debug_phase_trace(unsigned long long* out, int64_t n_words) {

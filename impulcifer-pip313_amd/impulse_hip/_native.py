@@ -110,6 +110,7 @@ SIGNATURES = {
     "imp_apply_window": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.POINTER(WindowParams)]),
     "imp_apply_window_device": (C.c_int, [_vp, _vp, _pi64, _vp, _pi64, _pi64, _i64, C.POINTER(WindowParams)]),
     "imp_segset_create_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, C.POINTER(_vp), _pd]),
+    "imp_rows_to_pcm_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, _pi64, _i64, _i64, C.c_int, _vp]),
     "imp_magnitude_db_sum_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _pi64, _i64, _i64, _i64, _pd]),
 }
 
@@ -297,6 +298,18 @@ class Context:
         if B:
             _check(self._lib.imp_apply_window_device(self._h, _vp(int(d_src)), _ptr_i64(src_off), _vp(int(d_dst)),
                                                      _ptr_i64(dst_off), _ptr_i64(lens), B, self._window_array(params, B)))
+
+    def rows_to_pcm_device(self, dptr, offs, lens, row_of_track, n_frames, bits):
+        """Interleaved PCM frames [n_frames, n_tracks] (int16 / int32) of device rows: track t = row row_of_track[t]
+        or silence (-1); libsndfile's float -> PCM conversion."""
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int64)
+        rot = np.ascontiguousarray(row_of_track, dtype=np.int64)
+        out = np.empty((int(n_frames), len(rot)), dtype=np.int16 if bits == 16 else np.int32)
+        _check(self._lib.imp_rows_to_pcm_device(self._h, _vp(int(dptr)), _ptr_i64(offs), _ptr_i64(lens), len(offs),
+                                                _ptr_i64(rot), len(rot), int(n_frames), int(bits),
+                                                out.ctypes.data_as(_vp)))
+        return out
 
     def magnitude_db_sum_device(self, dptr, offs, lens, groups, n_groups, n):
         """[n_groups, ceil(n/2)] dB spectra of the per-group sums of device rows (HRIR.normalize)."""

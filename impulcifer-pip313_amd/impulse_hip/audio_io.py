@@ -107,6 +107,30 @@ def pcm_quantise(frames, bit_depth):
     return ((q + half) % (1 << bit_depth)) - half
 
 
+def write_wav_frames(file_path, fs, frames, bit_depth):
+    """PCM WAV from already quantised interleaved frames [n_frames, n_tracks] (int16 for 16 bit, integers in int32 for
+    24 / 32 bit) - the block a device-side conversion returns (imp_rows_to_pcm_device)."""
+    if bit_depth not in (16, 24, 32):
+        raise ValueError('Invalid bit depth. Accepted values are 16, 24 and 32.')
+    d = os.path.dirname(file_path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    q = np.ascontiguousarray(frames)
+    nframes, nch = q.shape
+    if bit_depth == 16:
+        raw = q.astype("<i2").tobytes()
+    elif bit_depth == 32:
+        raw = q.astype("<i4").tobytes()
+    else:
+        u = (q.astype(np.int64) & 0xFFFFFF).astype(np.uint32).reshape(-1)
+        raw = np.stack([u & 0xFF, (u >> 8) & 0xFF, (u >> 16) & 0xFF], axis=1).astype(np.uint8).tobytes()
+    nbytes = bit_depth // 8
+    hdr = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + len(raw), b"WAVE", b"fmt ", 16, 1, nch, int(fs),
+                      int(fs) * nch * nbytes, nch * nbytes, bit_depth, b"data", len(raw))
+    with open(file_path, "wb") as fh:
+        fh.write(hdr + raw)
+
+
 def write_wav(file_path, fs, data, bit_depth=32):
     """PCM writer; rows are tracks (reference core/audio_io.py:82-97)."""
     if bit_depth not in (16, 24, 32):

@@ -260,6 +260,23 @@ class HRIR(_PlotBase):
     def write_wav(self, file_path, track_order=None, bit_depth=32):
         if track_order is None:
             track_order = HEXADECAGONAL_TRACK_ORDER
+        named = [(track_name(sp, sd), ir) for sp, pair in self.irs.items() for sd, ir in pair.items()]
+        dev = self._device_rows([ir for _, ir in named]) if named else None
+        if dev is not None and len({r.n for r in dev}) == 1 and bit_depth in (16, 24, 32):
+            # responses on the device: ordering, silence for absent channels and the PCM conversion happen there and
+            # the WAV data chunk comes back as it will be written (imp_rows_to_pcm_device)
+            from .audio_io import write_wav_frames
+            from .device_rows import span
+            names = [nm for nm, _ in named]
+            n = dev[0].n
+            if n <= len(track_order):                            # the reference's transpose rule: fewer frames than tracks
+                dev = None
+            else:
+                base, offs, lens = span(dev)
+                frames = _native.default_context().rows_to_pcm_device(
+                    base, offs, lens, [names.index(ch) if ch in names else -1 for ch in track_order], n, bit_depth)
+                write_wav_frames(file_path, self.fs, frames, bit_depth)
+                return
         by_name = {track_name(sp, sd): ir.data for sp, pair in self.irs.items() for sd, ir in pair.items()}
         if not by_name:
             raise ValueError("No impulse responses available for WAV output.")

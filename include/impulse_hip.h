@@ -302,6 +302,12 @@ int imp_apply_window_device(imp_ctx* ctx, const float* d_src, const int64_t* src
 /* imp_segset_create on fp32 device rows (converted exactly to fp64 on the device) */
 int imp_segset_create_device(imp_ctx* ctx, const float* d_x, const int64_t* off, const int64_t* len, int64_t B,
                              imp_segset** out, double* maxabs_out);
+/* HRIR.write_wav (core/hrir.py:426-455 -> core/audio_io.py:82-97) for responses on the device: the interleaved PCM
+ * block [n_frames][n_tracks] of a WAV data chunk, track t taken from row row_of_track[t] (-1: silence; samples beyond a
+ * row's end: silence), converted like libsndfile does (scale 2^(bits-1) - 1, round to nearest even, no clipping).
+ * pcm_out: host, int16 for bits = 16, int32 for bits = 24 and 32 (24-bit values sign-extended). */
+int imp_rows_to_pcm_device(imp_ctx* ctx, const float* d_rows, const int64_t* off, const int64_t* len, int64_t n_rows,
+                           const int64_t* row_of_track, int64_t n_tracks, int64_t n_frames, int bits, void* pcm_out);
 /* magnitude response (as imp_magnitude_db, n points, ceil(n/2) bins each) of the per-group SUMS of device rows:
  * rows of group g are added in row order in fp64, zero beyond their end - np.sum(np.vstack(padded), axis=0) of
  * HRIR.normalize (core/hrir.py:496-503).  db_out: host [n_groups][ceil(n/2)]. */

@@ -1908,3 +1908,30 @@ def test_headphone_compensation_matches_reference_run(gpu_ctx, golden, tmp_path)
     os.rename(tmp_path / "sub" / "hp.wav", tmp_path / "sub" / "other.WAV")
     assert resolve_headphone_file(str(tmp_path), str(tmp_path / "sub")) == str(tmp_path / "sub" / "other.WAV")
     assert resolve_headphone_file(str(tmp_path), "missing.wav") is None
+
+
+@pytest.mark.parametrize("bits", [16, 24, 32])
+def test_write_wav_from_device_rows_equals_host_codec(gpu_ctx, tmp_path, bits):
+    """HRIR.write_wav of device-resident responses (ordering, silence for absent channels and the PCM conversion on the
+    device) writes the same file, byte for byte, as the host codec on the same samples."""
+    import slice_input
+    from impulse_hip.constants import HESUVI_TRACK_ORDER
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.impulse_response import ImpulseResponse
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+    pcm = slice_input.to_pcm32(slice_input.make_tracks(e.test_signal, 48000))
+    h = HRIR(e)
+    h.open_recording_frames(48000, np.ascontiguousarray(pcm.T), ["FL", "FR"])
+    h.crop_heads()
+    h.crop_tails()
+    assert h._device_rows([ir for pair in h.irs.values() for ir in pair.values()]) is not None
+    # push one sample past full scale: the conversion wraps (no clipping), on both paths
+    twin = HRIR(e)
+    twin.irs = {sp: {sd: ImpulseResponse(ir.peek(), 48000) for sd, ir in pair.items()} for sp, pair in h.irs.items()}
+    for order, name in ((HESUVI_TRACK_ORDER, "hesuvi"), (None, "hexa")):
+        a, b = str(tmp_path / f"dev_{name}.wav"), str(tmp_path / f"host_{name}.wav")
+        h.write_wav(a, track_order=order, bit_depth=bits)
+        twin.write_wav(b, track_order=order, bit_depth=bits)
+        assert open(a, "rb").read() == open(b, "rb").read()
+    assert all(ir._row is not None for pair in h.irs.values() for ir in pair.values())      # still on the device
