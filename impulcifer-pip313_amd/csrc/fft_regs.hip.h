@@ -181,11 +181,44 @@ __host__ __device__ __forceinline__ void fft8(cf& x0, cf& x1, cf& x2, cf& x3, cf
   x1 = t2; x2 = t4; x3 = t6; x4 = t1; x5 = t3; x6 = t5;
 }
 
+// 11-point DFT (prime): pairs s_j = x_j + x_{11-j}, d_j = x_j - x_{11-j}; X_k / X_{11-k} = a_k -+ i b_k with
+// a_k = x_0 + sum_j cos(2 pi j k / 11) s_j and b_k = sum_j sin(2 pi j k / 11) d_j (forward; the inverse swaps the
+// signs).  Serves the 66-row column pass (66 = 11 x 6): the 7.1 / 6.15 s configuration needs 65.8 rows.
+template <int DIR>
+__host__ __device__ __forceinline__ void fft11(cf* x) {
+  constexpr float C[11] = {1.00000000000000000000f, 0.84125353283118120551f, 0.41541501300188643508f, -0.14231483827328500480f, -0.65486073394528498959f, -0.95949297361449736865f, -0.95949297361449747967f, -0.65486073394528521163f, -0.14231483827328522684f, 0.41541501300188604651f, 0.84125353283118120551f};
+  constexpr float S[11] = {0.00000000000000000000f, 0.54064081745559755543f, 0.90963199535451833011f, 0.98982144188093279524f, 0.75574957435425826890f, 0.28173255684142967104f, -0.28173255684142939348f, -0.75574957435425815788f, -0.98982144188093268422f, -0.90963199535451855215f, -0.54064081745559744441f};
+  cf s[5], d[5];
+#pragma unroll
+  for (int j = 1; j <= 5; ++j) {
+    s[j - 1] = cadd(x[j], x[11 - j]);
+    d[j - 1] = csub(x[j], x[11 - j]);
+  }
+  const cf x0 = x[0];
+  cf sum = x0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) sum = cadd(sum, s[j]);
+  x[0] = sum;
+#pragma unroll
+  for (int k = 1; k <= 5; ++k) {
+    cf a = x0, b = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 1; j <= 5; ++j) {
+      const int m = (j * k) % 11;
+      a = cfma_real(s[j - 1], make_float2(C[m], C[m]), a);
+      b = (j == 1) ? cmul_real(d[0], make_float2(S[m], S[m])) : cfma_real(d[j - 1], make_float2(S[m], S[m]), b);
+    }
+    x[k] = cadd_rot<DIR>(a, b);          // a -+ i b
+    x[11 - k] = csub_rot<DIR>(a, b);
+  }
+}
+
 // first stage of the column passes: F-point DFT of the thread's F rows
 template <int DIR, int F>
 __host__ __device__ __forceinline__ void fft_first(cf (&v)[F]) {
-  static_assert(F == 16 || F == 8, "first stage holds 16 or 8 rows per thread");
+  static_assert(F == 16 || F == 8 || F == 11, "first stage holds 16, 11 or 8 rows per thread");
   if constexpr (F == 16) fft16<DIR>(v);
+  else if constexpr (F == 11) fft11<DIR>(v);
   else fft8<DIR>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
 }
 
@@ -242,11 +275,14 @@ __host__ __device__ __forceinline__ void bfly5(cf& a, cf& b, cf& c, cf& d, cf& e
   d = csub_rot<DIR>(m2, n2);
 }
 
-// R-point DFT of x[0..R-1] in place, natural order in and out, R in {3, 5, 6, 9, 10, 12}.
+
+// R-point DFT of x[0..R-1] in place, natural order in and out, R in {3, 5, 6, 9, 10, 11, 12}.
 template <int DIR, int R>
 __host__ __device__ __forceinline__ void fft_small(cf* x) {
   if constexpr (R == 3) {
     bfly3<DIR>(x[0], x[1], x[2]);
+  } else if constexpr (R == 11) {
+    fft11<DIR>(x);
   } else if constexpr (R == 9) {
     // n = 3 n1 + n2 ; k = k1 + 3 k2 : three radix-3 over n1, twiddle w9^(n2 k1), three radix-3 over n2
     constexpr float C1 = 0.76604444311897803520f, S1 = 0.64278760968653932632f;    // 2 pi / 9

@@ -285,14 +285,14 @@ static void host_fft_rec(const cd* in, cd* out, size_t n, size_t in_stride, cons
     out[0] = in[0];
     return;
   }
-  const size_t p = (n % 2 == 0) ? 2 : (n % 3 == 0) ? 3 : 5;
+  const size_t p = (n % 2 == 0) ? 2 : (n % 3 == 0) ? 3 : (n % 5 == 0) ? 5 : 11;
   const size_t m = n / p;
   for (size_t r = 0; r < p; ++r)
     host_fft_rec(in + r * in_stride, scratch + r * m, m, in_stride * p, w, w_stride * p, out + r * m);
   // scratch[r*m + k] = DFT_m of the r-th decimated sequence; combine
   const size_t wn = w.size();
   for (size_t k = 0; k < m; ++k) {
-    cd t[5];
+    cd t[11];
     for (size_t r = 0; r < p; ++r) t[r] = scratch[r * m + k] * w[(r * k * w_stride) % wn];
     for (size_t q = 0; q < p; ++q) {
       cd acc = t[0];
@@ -305,7 +305,7 @@ static void host_fft_rec(const cd* in, cd* out, size_t n, size_t in_stride, cons
 static bool host_fft(std::vector<cd>& a) {
   const size_t n = a.size();
   size_t r = n;
-  for (size_t p : {2u, 3u, 5u})
+  for (size_t p : {2u, 3u, 5u, 11u})
     while (r % p == 0) r /= p;
   if (r != 1) return false;
   std::vector<cd> w(n), out(n), scratch(n);
@@ -456,6 +456,7 @@ template <int DIR, class Load, class Store>
 static int launch_cols_any(imp_plan* p, int64_t nchan, Load ld, Store st) {
   if (p->R2 == 1 && p->F == 4) return launch_cols_small<4, DIR>(p, nchan, ld, st);
   if (p->R2 == 1 && p->F == 8) return launch_cols_small<8, DIR>(p, nchan, ld, st);
+  if (p->F == 11 && p->R2 == 6) return launch_cols_mixed<11, 6, DIR>(p, nchan, ld, st);
   if (p->F == 8) {
     switch (p->R2) {
       case 3: return launch_cols_mixed<8, 3, DIR>(p, nchan, ld, st);
@@ -511,7 +512,7 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   const int64_t full = L + M - 1;
   const int64_t need = (mode == IMP_MODE_SAME) ? std::max(L + M / 2, M) : full;
   // N1 = F * R2 rows of 4096 complex points, ascending; F = rows per thread in the column passes
-  static const struct { int f, r2; } kShapes[] = {{4, 1},  {8, 1},  {16, 1}, {8, 3},  {16, 2}, {8, 5},  {16, 3},  {16, 4},  {8, 9},
+  static const struct { int f, r2; } kShapes[] = {{4, 1},  {8, 1},  {16, 1}, {8, 3},  {16, 2}, {8, 5},  {16, 3},  {16, 4},  {11, 6}, {8, 9},
                                                   {16, 5}, {16, 6}, {16, 8}, {16, 9}, {16, 10}, {16, 12}, {16, 16}};
   int r2 = 0, f1 = 16;
   const char* min_rows_env = std::getenv("IMPULSE_HIP_MIN_ROWS");             // experiments: 16 = the round-1 smallest plan
@@ -702,7 +703,7 @@ extern "C" int imp_debug_plan_geometry(int64_t M, int64_t L, int mode, int64_t* 
 }
 
 extern "C" int imp_debug_host_spectrum(const double* filter, int64_t M, int n1_rows, float* ab_out) {
-  if (!filter || !ab_out || M < 1 || n1_rows < 4 || n1_rows % 4) return fail(IMP_ERR_INVALID, "imp_debug_host_spectrum: bad argument");
+  if (!filter || !ab_out || M < 1 || n1_rows < 4 || n1_rows % 2) return fail(IMP_ERR_INVALID, "imp_debug_host_spectrum: bad argument");
   const int64_t Nc = (int64_t)n1_rows * imp::kN2;
   if (M > 2 * Nc) return fail(IMP_ERR_INVALID, "filter longer than the transform");
   std::vector<cd> H;

@@ -277,6 +277,7 @@ static int run_fft(imp_ctx* ctx, const std::vector<int>& fac, const cdbl* roots,
       case 2: hipLaunchKernelGGL(stockham_pass<2>, grid, block, 0, ctx->stream, *cur, *other, roots, N, n, s, dir); break;
       case 3: hipLaunchKernelGGL(stockham_pass<3>, grid, block, 0, ctx->stream, *cur, *other, roots, N, n, s, dir); break;
       case 5: hipLaunchKernelGGL(stockham_pass<5>, grid, block, 0, ctx->stream, *cur, *other, roots, N, n, s, dir); break;
+      case 11: hipLaunchKernelGGL(stockham_pass<11>, grid, block, 0, ctx->stream, *cur, *other, roots, N, n, s, dir); break;
       default: return fail(IMP_ERR_UNSUPPORTED, "radix %d", r);
     }
     HIP_TRY(hipGetLastError());

@@ -54,7 +54,7 @@ def pass_a(x, nfft):
     xp[: len(x)] = x
     z = (xp[0::2] + 1j * xp[1::2]).reshape(N1, N2)          # [n1][n2]
     if N1 % 16:
-        # N1 = 8*R2 shapes (24, 40, 72): the staging differs (8 rows per thread) but the result is the same
+        # N1 = 8*R2 shapes (24, 40, 72), the short plans (4, 8) and 66 = 11 x 6: the staging differs but the result is the same
         # column DFT times the four-step twiddle, whatever the factorisation
         k1 = np.arange(N1)[:, None]
         return np.fft.fft(z, axis=0) * w(np.arange(N2)[None, :], k1, Nc)
@@ -176,7 +176,7 @@ def pass_c(ws, nfft, start, length):
 
 
 # N1 = F*R2 rows of 4096 complex points (F = rows per thread in the column passes) -> nfft = 8192*N1
-SUPPORTED_N1 = (4, 8, 16, 24, 32, 40, 48, 64, 72, 80, 96, 128, 144, 160, 192, 256)
+SUPPORTED_N1 = (4, 8, 16, 24, 32, 40, 48, 64, 66, 72, 80, 96, 128, 144, 160, 192, 256)
 
 
 def pick_nfft(L, M, mode="same"):

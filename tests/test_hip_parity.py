@@ -49,7 +49,7 @@ def spec_rel_cropped(y, ref, fs=48000, n=None):
 # K1/K5: convolution plans against the oracle
 # ------------------------------------------------------------------------------------------------
 # sizes chosen to hit every column shape N1 = F x R2 (nfft = 8192 N1) in at least one mode:
-# 'same': N1 = 4, 4, 4, 4, 8, 16, 32, 40, 72, 96, 144, 24, 48, 64, 80, 128 ; 'full': 4, 4, 4, 4, 8, 16, 32, 32, 48, 96, 128, 192, 32, 48, 80, 96, 160
+# 'same': N1 = 4, 4, 4, 4, 8, 16, 32, 40, 66, 96, 144, 24, 48, 64, 80, 128 ; 'full': 4, 4, 4, 4, 8, 16, 32, 32, 48, 96, 128, 192, 32, 48, 80, 96, 160
 @pytest.mark.parametrize("L,M", [(1, 1), (17, 5), (1000, 999), (20000, 9600), (32640, 9600), (70001, 61000), (150000, 100001),
                                  (243635, 147635), (391270, 295270), (500000, 400000), (827965, 635965),
                                  (150000, 80000), (300000, 150000), (420000, 200000), (500000, 300000), (800000, 400000)])
@@ -1312,11 +1312,11 @@ def test_k11_sosfilt_bits_and_virtual_bass(gpu_ctx, golden):
 def test_workspace_after_each_pass_matches_the_dataflow_model(gpu_ctx):
     """imp_plan_debug_run_stage: the workspace after pass A and after pass B against the NumPy dataflow model
     (tests/model/fourstep_model.py, the thread-for-thread algebra of the kernels) at N1 = 48 (16 rows per
-    thread, radix 3) and N1 = 72 (8 rows per thread, radix 9: the C2 plan)."""
+    thread, radix 3), N1 = 66 (11 rows per thread, radix 11 x 6: the C2 plan) and N1 = 72 (8 rows per thread, radix 9)."""
     import fourstep_model as fm
     from impulse_hip import ConvPlan
     rng = np.random.default_rng(48)
-    for L, M, n1 in ((300000, 150000, 48), (391270, 295270, 72)):
+    for L, M, n1 in ((300000, 150000, 48), (391270, 295270, 66), (420000, 295270, 72)):
         x = rng.standard_normal((2, L)).astype(np.float32)
         h = rng.standard_normal(M) * np.exp(-np.arange(M) / 30000.0)
         plan = ConvPlan(gpu_ctx, h, L, "same")
@@ -1455,8 +1455,8 @@ def test_full_batch_c4_c5_device_resident(gpu_ctx, B):
 # place inside that XCD's L2.  Optional (measured slower than the three-launch path); parity is held
 # to the same bar.
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("L,M,mode,B,n1", [(391270, 295270, "same", 23, 72), (300000, 400000, "same", 9, 64),
-                                           (300000, 280000, "full", 5, 72), (391270, 295270, "same", 1, 72)])
+@pytest.mark.parametrize("L,M,mode,B,n1", [(420000, 295270, "same", 23, 72), (300000, 400000, "same", 9, 64),
+                                           (300000, 280000, "full", 5, 72), (420000, 295270, "same", 1, 72)])
 def test_xcd_resident_path_matches_oracle_and_three_launch_path(gpu_ctx, L, M, mode, B, n1):
     from impulse_hip import ConvPlan, NativeError
     from oracle.scipy_restated import fft_convolve
@@ -1494,7 +1494,7 @@ def test_xcd_resident_device_buffers_and_pcm(gpu_ctx):
     """Device-resident entry points on the resident path: planar fp32 and the WAV wire format (int32 frames)."""
     from impulse_hip import ConvPlan
     rng = np.random.default_rng(77)
-    L, M, tracks = 391270, 295270, 2
+    L, M, tracks = 420000, 295270, 2                       # a 72-row plan (the 6.15 s / 391 270 case takes 66 rows)
     h = rng.standard_normal(M) * np.exp(-np.arange(M) / 60000.0)
     frames = rng.integers(-2 ** 30, 2 ** 30, size=(L, tracks), dtype=np.int32)
     plan = ConvPlan(gpu_ctx, h, L, "same", ws_channels=4)

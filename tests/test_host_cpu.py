@@ -189,9 +189,9 @@ def test_plan_geometry_wraparound_rule(lib):
     import fourstep_model as fm
     from impulse_hip._native import plan_geometry
     from oracle.scipy_restated import fft_convolve
-    cases = {(391270, 295270): 589824, (827965, 635965): 1179648, (1 << 20, 1 << 20): 1572864,
+    cases = {(391270, 295270): 540672, (420000, 295270): 589824, (827965, 635965): 1179648, (1 << 20, 1 << 20): 1572864,
              (243635, 147635): 327680, (100, 4): 32768, (4, 100): 32768, (1, 1): 32768, (40000, 9600): 65536,
-             (150000, 80000): 196608}                                   # N1 = 72, 144, 192, 40, 4, 4, 4, 8, 24
+             (150000, 80000): 196608}                                   # N1 = 66, 72, 144, 192, 40, 4, 4, 4, 8, 24
     for (L, M), want in cases.items():
         nfft, start, n = plan_geometry(M, L, "same")
         assert nfft == want == fm.pick_nfft(L, M, "same")
@@ -215,7 +215,7 @@ def test_plan_geometry_wraparound_rule(lib):
         assert np.abs(y - ref).max() / np.abs(ref).max() < 1e-12
 
 
-@pytest.mark.parametrize("n1", [4, 8, 16, 24, 40, 48, 72, 80, 96, 128, 144, 160, 192])
+@pytest.mark.parametrize("n1", [4, 8, 16, 24, 40, 48, 66, 72, 80, 96, 128, 144, 160, 192])
 def test_host_spectrum_matches_model(lib, n1):
     """fp64 host FFT (radices 2/3/5) + alpha/beta packing of the library vs the NumPy model."""
     import fourstep_model as fm

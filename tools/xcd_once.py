@@ -14,7 +14,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 three = len(sys.argv) > 3
 ctx = Context(0)
 rng = np.random.default_rng(1)
-L, M = 391270, 295270
+L, M = 420000, 295270
 pitch = (L + 63) // 64 * 64
 h = rng.standard_normal(M) * np.exp(-np.arange(M) / (M / 5.0))
 host = rng.standard_normal((min(B, 64), pitch)).astype(np.float32)

@@ -21,7 +21,7 @@ def rel(a, b):
 def main():
     ctx = Context(0)
     rng = np.random.default_rng(5)
-    for L, M, mode, B in ((391270, 295270, "same", 16), (391270, 295270, "same", 1), (391270, 295270, "same", 23),
+    for L, M, mode, B in ((420000, 295270, "same", 16), (420000, 295270, "same", 1), (420000, 295270, "same", 23),
                           (300000, 400000, "same", 9), (300000, 280000, "full", 5)):
         x = rng.standard_normal((B, L)).astype(np.float32)
         h = rng.standard_normal(M) * np.exp(-np.arange(M) / (M / 5.0))
@@ -39,7 +39,7 @@ def main():
         print(f"   rerun bit-identical: {np.array_equal(y, y2)}", flush=True)
         plan.close()
     if "--time" in sys.argv:
-        L, M = 391270, 295270
+        L, M = 420000, 295270
         pitch = (L + 63) // 64 * 64
         h = rng.standard_normal(M) * np.exp(-np.arange(M) / (M / 5.0))
         for B in (16, 64, 640):
