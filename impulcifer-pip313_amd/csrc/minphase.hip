@@ -213,6 +213,7 @@ std::vector<int> factorise(int n) {
   while (n % 2 == 0) { f.push_back(2); n /= 2; }
   while (n % 3 == 0) { f.push_back(3); n /= 3; }
   while (n % 5 == 0) { f.push_back(5); n /= 5; }
+  while (n % 11 == 0) { f.push_back(11); n /= 11; }      // 66-row convolution plans (filter spectrum preparation)
   if (n != 1) f.clear();
   return f;
 }
@@ -662,7 +663,7 @@ void fft_roots_destroy(imp_ctx* ctx) {
 int spectrum_alpha_beta_device(imp_ctx* ctx, const double* filters, int64_t M, int64_t n_filters, int64_t filter_ld,
                                int64_t Nc, int N1, float4* d_ab) {
   const std::vector<int> fac = factorise((int)Nc);
-  if (fac.empty()) return fail(IMP_ERR_UNSUPPORTED, "spectrum length %lld is not 2^a 3^b 5^c", (long long)Nc);
+  if (fac.empty()) return fail(IMP_ERR_UNSUPPORTED, "spectrum length %lld is not 2^a 3^b 5^c 11^d", (long long)Nc);
   hipStream_t s = ctx->stream;
   cdbl* roots = nullptr;
   auto it = ctx->fft_roots.find((long long)Nc);
