@@ -148,7 +148,8 @@ class ImpulseResponse(_PlotBase):
         return deepcopy(self)
 
     def __deepcopy__(self, memo):
-        other = ImpulseResponse(deepcopy(self.data, memo), self.fs, deepcopy(self.recording, memo))
+        # peek(): copying a device-resident response must not move the original to the host
+        other = ImpulseResponse(self.peek(), self.fs, deepcopy(self.recording, memo))
         for k, v in self.__dict__.items():
             if k not in ("fs", "_row", "_data", "_recording"):
                 other.__dict__[k] = deepcopy(v, memo)

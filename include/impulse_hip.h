@@ -196,7 +196,7 @@ int imp_decay_times(imp_ctx* ctx, const double* x, const int64_t* off, const int
  * window, autoeq :1060-1105), smoothen_heavy_light (:1181-1239), equalize (:1241-1310: gain-limited inversion, the
  * samples around every clip on/off transition replaced by FITPACK's quadratic interpolating spline in log10 f), the
  * gain grid of the FIR design (:651-674) and, chained on the device, the minimum-phase FIR (K6).
- * A handle belongs to one frequency grid (frequency[n] Hz, strictly increasing, 8 <= n <= 1024); curves are host
+ * A handle belongs to one frequency grid (frequency[n] Hz, strictly increasing, 8 <= n <= 2048); curves are host
  * fp64 [B][n] in dB.  Grid-only quantities (log10 f, window coefficients, blend weights) are prepared once per handle
  * on the host in fp64; all per-curve arithmetic runs on the device. */
 typedef struct imp_curves imp_curves;
