@@ -29,6 +29,14 @@ def main(out, tag="r01"):
         for f in files:
             if f.endswith("kernel_stats.csv"):
                 shutil.copy(os.path.join(root, f), os.path.join(prof, f"{tag}_kernel_stats.csv"))
+    for root, _, files in os.walk(os.path.join(out, "trace_serial")):
+        for f in files:
+            if f.endswith("kernel_stats.csv"):
+                shutil.copy(os.path.join(root, f), os.path.join(prof, f"{tag}_kernel_stats_serial.csv"))
+    for name in ("bench_trace.json", "bench_trace_serial.json"):
+        src = os.path.join(out, name)
+        if os.path.exists(src) and os.path.getsize(src):
+            shutil.copy(src, os.path.join(prof, f"{tag}_{name}"))
     traffic, pmc_all = {}, {}
     for w, what in GROUPS.items():
         d = os.path.join(out, f"pmc_{w}")
