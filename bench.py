@@ -182,15 +182,15 @@ def slice_rate(est, rec, L, reps=3):
                 note="end to end: PCM frames in host memory -> float64 responses in host memory, incl. PCIe; 16 IRs per measurement; not the headline metric")
 
 
-def deconv_fir_leg(dev_index, est, rec, L, pitch, reps=200, workers=3):
+def deconv_fir_leg(dev_index, est, rec, L, pitch, reps=400, lanes=3):
     """The metric's "+FIR" on device pointers: 7.1 x 2-ear measurements resident in HBM go through K1 (deconvolution)
-    -> K3 (first-peak search, indices to the host) -> K4 (head crop at peak - 1 ms, 0.68 s long, Hann fades, compacted) ->
-    K5 (per-channel 9 600-tap FIRs whose spectra are cached in the plan); nothing but 16 peak indices per measurement
-    crosses the bus.  `workers` host threads, each with its own context (stream), plans and buffers, work on different
-    measurements at once - the reference's worker threads (core/parallel_utils.py:53-55), here only to keep the GPU busy
-    across the two host round trips of a measurement.  Algorithmic bytes per IR: 4 L in + 4 (n + K - 1) out."""
-    import threading
+    -> K3 (first-peak search) -> K4 (head crop at peak - 1 ms, 0.68 s long, Hann fades, compacted) -> K5 (per-channel
+    9 600-tap FIRs whose spectra are cached in the plan) as ONE stream-ordered chain (imp_chain): the crop offsets are taken
+    from the peak search on the device, nothing crosses the bus.  `lanes` chains on their own contexts (streams) take the
+    measurements round robin so that one measurement's row pass runs beside another's column passes.
+    Algorithmic bytes per IR: 4 L in + 4 (n + K - 1) out."""
     from impulse_hip import Context, ConvPlan
+    from impulse_hip._native import FirChain
     from oracle.estimator import estimate
     from oracle.impulse_response import peak_index
     from oracle.scipy_restated import fft_convolve, hann
@@ -200,61 +200,50 @@ def deconv_fir_leg(dev_index, est, rec, L, pitch, reps=200, workers=3):
     rng = np.random.default_rng(0xF1)
     firs = rng.standard_normal((B, K)) * np.exp(-np.arange(K) / 400.0) * 0.05
     firs[:, 0] += 1.0
-    pn, po = (n + 63) // 64 * 64, (n + K - 1 + 63) // 64 * 64
-    offs = np.arange(B, dtype=np.int64) * pitch
-    lens = np.full(B, L, dtype=np.int64)
-    win = [dict(fade_in=head, fade_out=fade)] * B
-    dst = np.arange(B, dtype=np.int64) * pn
+    po = (n + K - 1 + 63) // 64 * 64
 
-    class Worker:
+    class Lane:
         def __init__(self):
             self.ctx = Context(dev_index)
             self.plan1 = ConvPlan(self.ctx, np.asarray(est.inverse_filter, dtype=np.float64), L, "same", ws_channels=B)
             self.plan5 = ConvPlan(self.ctx, firs, n, "full", ws_channels=B)
-            self.bufs = [self.ctx.malloc(B * pitch * 4), self.ctx.malloc(B * pitch * 4), self.ctx.malloc(B * pn * 4),
-                         self.ctx.malloc(B * po * 4)]
-            self.ctx.h2d(self.bufs[0], rec)
-            self.peaks = None
+            self.chain = FirChain(self.plan1, self.plan5, B, head, head, fade)
+            self.d_x, self.d_out, self.d_pk = self.ctx.malloc(B * pitch * 4), self.ctx.malloc(B * po * 4), self.ctx.malloc(B * 8)
+            self.ctx.h2d(self.d_x, rec)
 
         def once(self):
-            d_x, d_ir, d_crop, d_out = self.bufs
-            self.plan1.execute_device(d_x, B, pitch, d_ir, pitch)
-            idx, _ = self.ctx.peak_index_device(d_ir, offs, lens)
-            starts = np.minimum(np.maximum(idx - head, 0), L - n)
-            self.ctx.apply_window_device(d_ir, offs + starts, d_crop, dst, [n] * B, win)
-            self.plan5.execute_device(d_crop, B, pn, d_out, po)
-            self.peaks = idx
-
-        def run(self, count):
-            for _ in range(count):
-                self.once()
-            self.ctx.synchronize()
+            self.chain.execute_device(self.d_x, pitch, self.d_out, po, self.d_pk)
 
         def close(self):
-            for p in self.bufs:
+            for p in (self.d_x, self.d_out, self.d_pk):
                 self.ctx.free(p)
             self.ctx.close()
 
-    team = [Worker() for _ in range(workers)]
+    team = [Lane() for _ in range(lanes)]
     try:
-        for w in team:
-            w.run(5)
-        threads = [threading.Thread(target=w.run, args=(reps,)) for w in team]
+        for _ in range(10):
+            for ln in team:
+                ln.once()
+        for ln in team:
+            ln.ctx.synchronize()
         t0 = time.perf_counter()
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        dt = (time.perf_counter() - t0) / (reps * workers)
+        for i in range(reps):
+            team[i % lanes].once()
+        for ln in team:
+            ln.ctx.synchronize()
+        dt = (time.perf_counter() - t0) / reps
         t1 = time.perf_counter()
-        team[0].run(50)
-        dt_single = (time.perf_counter() - t1) / 50
+        for _ in range(100):
+            team[0].once()
+        team[0].ctx.synchronize()
+        dt_single = (time.perf_counter() - t1) / 100
         y = np.empty((B, po), dtype=np.float32)
-        team[-1].ctx.d2h(y, team[-1].bufs[3])
-        peaks = team[-1].peaks
+        peaks = np.empty(B, dtype=np.int64)
+        team[-1].ctx.d2h(y, team[-1].d_out)
+        team[-1].ctx.d2h(peaks, team[-1].d_pk)
     finally:
-        for w in team:
-            w.close()
+        for ln in team:
+            ln.close()
     errs, peaks_ok = [], True
     w = np.ones(n)
     w[:head] *= hann(2 * head)[:head]
@@ -267,12 +256,11 @@ def deconv_fir_leg(dev_index, est, rec, L, pitch, reps=200, workers=3):
         ref = fft_convolve(ir[s0:s0 + n] * w, firs[c], "full")
         errs.append(float(np.max(np.abs(y[c, :n + K - 1] - ref)) / np.max(np.abs(ref))))
     alg = B * (4.0 * L + 4.0 * (n + K - 1))
-    return dict(value=B / dt, unit="IR/s", ms_per_measurement=dt * 1e3, channels=B, host_threads=workers,
-                one_thread=dict(value=B / dt_single, ms_per_measurement=dt_single * 1e3),
-                stages="K1 deconvolution -> K3 first peak (16 indices to the host) -> K4 crop (peak - 1 ms, 0.68 s) + Hann fades "
-                       "-> K5 per-channel 9 600-tap FIR (spectra cached in the plan); device pointers throughout; every host "
-                       "thread drives its own context and works on a different measurement (two host round trips each: the "
-                       "peak indices, the crop offsets)",
+    return dict(value=B / dt, unit="IR/s", ms_per_measurement=dt * 1e3, channels=B, chains_in_flight=lanes,
+                one_chain=dict(value=B / dt_single, ms_per_measurement=dt_single * 1e3),
+                stages="K1 deconvolution -> K3 first peak -> K4 crop (peak - 1 ms, 0.68 s) + Hann fades -> K5 per-channel "
+                       "9 600-tap FIR (spectra cached in the plan): one stream-ordered chain per measurement (imp_chain), crop "
+                       "offsets taken from the peak search on the device, no host round trip",
                 algorithmic_bytes_per_measurement=alg, achieved_GBps=alg / dt / 1e9, frac_of_hbm_peak=alg / dt / 1e9 / HBM_PEAK_GBS,
                 parity=dict(peak_indices_exact=bool(peaks_ok), time_max_rel_err=max(errs), tolerance=1e-6, channels_checked=2))
 

@@ -1293,6 +1293,100 @@ extern "C" int imp_peak_index(imp_ctx* ctx, const float* x, const int64_t* off, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Chain K1 -> K3 -> K4 -> K5 on one stream without a host round trip ("deconv + FIR" of the metric)
+// ------------------------------------------------------------------------------------------------
+struct imp_chain {
+  imp_ctx* ctx = nullptr;
+  imp_plan* deconv = nullptr;       // K1: 'same' plan of the recording length
+  imp_plan* fir = nullptr;          // K5: 'full' plan of length n with per-channel (or one shared) filters
+  int64_t B = 0, n = 0, head = 0, fade_in = 0, fade_out = 0, pitch_ir = 0, pitch_crop = 0;
+  double peak_height = 0.12589;
+  float* d_ir = nullptr;            // [B][pitch_ir]
+  float* d_crop = nullptr;          // [B][pitch_crop]
+  imp::RowPeak* d_res = nullptr;
+  int64_t* d_meta = nullptr;        // off[B], len[B]
+};
+
+extern "C" void imp_chain_destroy(imp_chain* c) {
+  if (!c) return;
+  IMP_CTX_LOCK(c->ctx);
+  (void)hipSetDevice(c->ctx->device);
+  (void)hipStreamSynchronize(c->ctx->stream);
+  (void)hipFree(c->d_ir);
+  (void)hipFree(c->d_crop);
+  (void)hipFree(c->d_res);
+  (void)hipFree(c->d_meta);
+  delete c;
+}
+
+extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int64_t head, int64_t fade_in, int64_t fade_out,
+                                double peak_height, imp_chain** out) {
+  if (!deconv || !fir || !out) return fail(IMP_ERR_INVALID, "imp_chain_create: null argument");
+  *out = nullptr;
+  if (deconv->ctx != fir->ctx) return fail(IMP_ERR_INVALID, "imp_chain_create: the two plans belong to different contexts");
+  IMP_CTX_LOCK(deconv->ctx);
+  if (deconv->mode != IMP_MODE_SAME || fir->mode != IMP_MODE_FULL)
+    return fail(IMP_ERR_INVALID, "imp_chain_create: needs a 'same' deconvolution plan and a 'full' FIR plan");
+  if (deconv->lanes != 1 || fir->lanes != 1) return fail(IMP_ERR_INVALID, "imp_chain_create: plans must run in stream order (lanes = 1)");
+  const int64_t n = fir->L;
+  if (B < 1 || B > deconv->ws_channels || B > fir->ws_channels) return fail(IMP_ERR_INVALID, "imp_chain_create: B exceeds a plan's workspace");
+  if (fir->n_filters > 1 && B > fir->n_filters) return fail(IMP_ERR_INVALID, "imp_chain_create: fewer FIRs than channels");
+  if (n > deconv->out_len || head < 0 || fade_in < 0 || fade_out < 0 || fade_in > n || fade_out > n)
+    return fail(IMP_ERR_INVALID, "imp_chain_create: crop of %lld samples with fades %lld / %lld does not fit", (long long)n,
+                (long long)fade_in, (long long)fade_out);
+  int rc = ctx_bind(deconv->ctx);
+  if (rc) return rc;
+  imp_chain* c = new (std::nothrow) imp_chain();
+  if (!c) return fail(IMP_ERR_ALLOC, "out of host memory");
+  c->ctx = deconv->ctx;
+  c->deconv = deconv;
+  c->fir = fir;
+  c->B = B;
+  c->n = n;
+  c->head = head;
+  c->fade_in = fade_in;
+  c->fade_out = fade_out;
+  c->peak_height = peak_height;
+  c->pitch_ir = (deconv->out_len + 63) / 64 * 64;
+  c->pitch_crop = (n + 63) / 64 * 64;
+  std::vector<int64_t> meta((size_t)(2 * B));
+  for (int64_t b = 0; b < B; ++b) {
+    meta[(size_t)b] = b * c->pitch_ir;
+    meta[(size_t)(B + b)] = deconv->out_len;
+  }
+  if (hipMalloc((void**)&c->d_ir, (size_t)(B * c->pitch_ir) * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&c->d_crop, (size_t)(B * c->pitch_crop) * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&c->d_res, (size_t)B * sizeof(imp::RowPeak)) != hipSuccess ||
+      hipMalloc((void**)&c->d_meta, (size_t)(2 * B) * sizeof(int64_t)) != hipSuccess ||
+      hipMemcpy(c->d_meta, meta.data(), meta.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) {
+    imp_chain_destroy(c);
+    return fail(IMP_ERR_ALLOC, "imp_chain_create: device allocation failed");
+  }
+  *out = c;
+  return IMP_OK;
+}
+
+extern "C" int imp_chain_execute_device(imp_chain* c, const float* d_x, int64_t chan_stride_in, int64_t elem_stride_in,
+                                        float* d_out, int64_t chan_stride_out, long long* d_peaks_out) {
+  if (!c || !d_x || !d_out) return fail(IMP_ERR_INVALID, "imp_chain_execute_device: null argument");
+  IMP_CTX_LOCK(c->ctx);
+  int rc = imp_conv_execute_device(c->deconv, d_x, c->B, chan_stride_in, elem_stride_in, c->d_ir, c->pitch_ir);
+  if (rc) return rc;
+  hipStream_t s = c->ctx->stream;
+  const int64_t L = c->deconv->out_len;
+  hipLaunchKernelGGL(imp::row_peak_init_kernel, dim3((unsigned)((c->B + 255) / 256)), dim3(256), 0, s, c->d_res, (int)c->B);
+  const int bpr = (int)std::max<int64_t>(1, std::min<int64_t>(256, (L + 4095) / 4096));
+  dim3 grid((unsigned)bpr, (unsigned)c->B), block(256);
+  hipLaunchKernelGGL(imp::row_maxabs_kernel, grid, block, 0, s, c->d_ir, c->d_meta, c->d_meta + c->B, c->d_res);
+  hipLaunchKernelGGL(imp::row_first_peak_kernel, grid, block, 0, s, c->d_ir, c->d_meta, c->d_meta + c->B, c->d_res, c->peak_height);
+  const int cpr = (int)std::max<int64_t>(1, std::min<int64_t>(64, (c->n + 1023) / 1024));
+  hipLaunchKernelGGL(imp::crop_at_peak_kernel, dim3((unsigned)cpr, (unsigned)c->B), block, 0, s, c->d_ir, c->d_meta,
+                     c->d_meta + c->B, c->d_res, c->d_crop, c->pitch_crop, c->n, c->head, c->fade_in, c->fade_out, d_peaks_out);
+  HIP_TRY(hipGetLastError());
+  return imp_conv_execute_device(c->fir, c->d_crop, c->B, c->pitch_crop, 1, d_out, chan_stride_out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K7 segment sets
 // ------------------------------------------------------------------------------------------------
 struct imp_segset {

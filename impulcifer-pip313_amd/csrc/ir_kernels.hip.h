@@ -90,6 +90,50 @@ __global__ __launch_bounds__(256) void row_first_peak_kernel(const float* __rest
   }
 }
 
+__device__ __forceinline__ double hann_sym_fwd(int64_t i, int64_t N) {     // scipy hann(N, sym=True)[i]
+  if (N <= 1) return 1.0;
+  return 0.5 - 0.5 * cospi(2.0 * (double)i / (double)(N - 1));
+}
+
+// start of a device-side search on rows of equal pitch: res[b] = "nothing found yet"
+__global__ __launch_bounds__(256) void row_peak_init_kernel(RowPeak* __restrict__ res, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  res[b].maxabs_bits = 0u;
+  res[b].pad = 0u;
+  res[b].first_peak = ~0ull;
+  res[b].first_max = ~0ull;
+}
+
+// Crop every row at its own first peak WITHOUT a host round trip: row b (src + off[b], len[b] samples) is read from
+// start = clamp(peak - head, 0, len - n) and n samples are written to dst + b * dst_pitch with a Hann fade-in of
+// `fade_in` and fade-out of `fade_out` samples (core/impulse_response.py:82-90 crop_head + the fades of
+// core/hrir.py:591-612, :642-651 at a fixed length).  peak = ImpulseResponse.peak_index as K3 found it (res[b]).
+__global__ __launch_bounds__(256) void crop_at_peak_kernel(const float* __restrict__ src, const int64_t* __restrict__ off,
+                                                           const int64_t* __restrict__ len, const RowPeak* __restrict__ res,
+                                                           float* __restrict__ dst, int64_t dst_pitch, int64_t n, int64_t head,
+                                                           int64_t fade_in, int64_t fade_out, long long* __restrict__ peaks_out) {
+  const int b = blockIdx.y;
+  const float m = __uint_as_float(res[b].maxabs_bits);
+  long long pk;
+  if (len[b] == 0 || !(m >= 1e-20f)) pk = 0;
+  else if (res[b].first_peak != ~0ull) pk = (long long)res[b].first_peak;
+  else pk = (long long)res[b].first_max;
+  if (peaks_out && blockIdx.x == 0 && threadIdx.x == 0) peaks_out[b] = pk;
+  long long start = pk - head;
+  if (start > len[b] - n) start = len[b] - n;
+  if (start < 0) start = 0;
+  const float* in = src + off[b] + start;
+  const int64_t avail = len[b] - start;
+  float* out = dst + (int64_t)b * dst_pitch;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double g = 1.0;
+    if (i < fade_in) g *= hann_sym_fwd(i, 2 * fade_in);
+    if (fade_out > 0 && i >= n - fade_out) g *= hann_sym_fwd(fade_out + (i - (n - fade_out)), 2 * fade_out);
+    out[i] = i < avail ? (float)((double)in[i] * g) : 0.f;
+  }
+}
+
 // layout-compatible with imp_window_params (include/impulse_hip.h)
 struct WindowParams {
   float gain;

@@ -73,6 +73,9 @@ SIGNATURES = {
     "imp_conv_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64]),
     "imp_conv_execute_device_pcm": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _vp, _i64]),
     "imp_plan_set_overlap": (C.c_int, [_vp, C.c_int]),
+    "imp_chain_create": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, C.c_double, C.POINTER(_vp)]),
+    "imp_chain_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "imp_chain_destroy": (None, [_vp]),
     "imp_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "imp_comm_create": (C.c_int, [_vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(_vp)]),
     "imp_comm_destroy": (None, [_vp]),
@@ -485,6 +488,37 @@ class SegSet:
         if getattr(self, "_h", None):
             if getattr(self.ctx, "_h", None):
                 self._lib.imp_segset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+class FirChain:
+    """K1 -> K3 -> K4 -> K5 in stream order, no host round trip (imp_chain): recordings on the device in, equalised
+    cropped responses on the device out."""
+
+    def __init__(self, deconv_plan, fir_plan, B, head, fade_in, fade_out, peak_height=0.12589):
+        self.ctx = deconv_plan.ctx
+        self._lib = self.ctx._lib
+        self._plans = (deconv_plan, fir_plan)            # keep them alive
+        h = _vp()
+        _check(self._lib.imp_chain_create(deconv_plan.handle, fir_plan.handle, int(B), int(head), int(fade_in),
+                                          int(fade_out), float(peak_height), C.byref(h)))
+        self._h = h
+        self.ctx._plans.add(self)
+
+    def execute_device(self, d_x, chan_stride_in, d_out, chan_stride_out, d_peaks=0, elem_stride_in=1):
+        _check(self._lib.imp_chain_execute_device(self._h, _vp(int(d_x)), int(chan_stride_in), int(elem_stride_in),
+                                                  _vp(int(d_out)), int(chan_stride_out), _vp(int(d_peaks)) if d_peaks else None))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if getattr(self.ctx, "_h", None):
+                self._lib.imp_chain_destroy(self._h)
             self._h = None
 
     def __del__(self):

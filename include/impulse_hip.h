@@ -314,6 +314,22 @@ int imp_rows_to_pcm_device(imp_ctx* ctx, const float* d_rows, const int64_t* off
 int imp_magnitude_db_sum_device(imp_ctx* ctx, const float* d_rows, const int64_t* off, const int64_t* len,
                                 const int64_t* group, int64_t n_rows, int64_t n_groups, int64_t n, double* db_out);
 
+/* ---- K1 -> K3 -> K4 -> K5 as one stream-ordered chain ("deconvolution + FIR") -------------------------------
+ * recording (device) -> estimate() (core/impulse_response_estimator.py:149-151) -> first peak
+ * (core/impulse_response.py:32-70) -> crop at peak - head, fir->L samples, Hann fade-in / fade-out
+ * (core/impulse_response.py:82-90, core/hrir.py:591-612, 642-651 at a fixed length) -> per-channel FIR
+ * (core/impulse_response.py:110-119), with NO host round trip: the crop offsets are taken from the peak search on the
+ * device.  `deconv` is a 'same' plan, `fir` a 'full' plan of length n (its filters may be refilled with
+ * imp_plan_set_filters between calls); both must be in stream order (lanes = 1) and outlive the chain.
+ * imp_chain_execute_device is asynchronous on the context stream; d_out receives B rows of n + K - 1 samples,
+ * d_peaks_out (device, may be NULL) the B peak indices. */
+typedef struct imp_chain imp_chain;
+int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int64_t head, int64_t fade_in, int64_t fade_out,
+                     double peak_height, imp_chain** out);
+int imp_chain_execute_device(imp_chain* chain, const float* d_x, int64_t chan_stride_in, int64_t elem_stride_in,
+                             float* d_out, int64_t chan_stride_out, long long* d_peaks_out);
+void imp_chain_destroy(imp_chain* chain);
+
 /* ---- the one collective: RCCL broadcast of the prepared filter spectrum -----------------------------
  * Channels shard across GPUs with no data-path collective; the only shared datum is the inverse-sweep spectrum rank 0
  * prepares.  The library does that broadcast itself over RCCL (xGMI inside a node), so the host side needs no

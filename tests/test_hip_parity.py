@@ -1935,3 +1935,61 @@ def test_write_wav_from_device_rows_equals_host_codec(gpu_ctx, tmp_path, bits):
         twin.write_wav(b, track_order=order, bit_depth=bits)
         assert open(a, "rb").read() == open(b, "rb").read()
     assert all(ir._row is not None for pair in h.irs.values() for ir in pair.values())      # still on the device
+
+
+def test_fir_chain_without_host_round_trip(gpu_ctx):
+    """imp_chain: recording -> estimate -> first peak -> crop at peak - head (+ fades) -> per-channel FIR as one
+    stream-ordered chain; the crop offsets come from the peak search on the device.  Against the oracle, incl. a silent
+    channel (peak 0), a peak too close to the end (window clamped) and a refill of the FIRs."""
+    from impulse_hip import ConvPlan
+    from impulse_hip._native import FirChain
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from oracle.estimator import estimate
+    from oracle.impulse_response import peak_index
+    from oracle.scipy_restated import fft_convolve, hann
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+    N, fs = len(e), 48000
+    L, n, K, head, fade, B = N + 2 * fs, 20000, 3000, 48, 400, 5
+    rng = np.random.default_rng(21)
+    rec = np.zeros((B, L), dtype=np.float32)
+    delays = [100, 777, 0, 60000, 95000]                       # channel 2 stays silent; channel 4 peaks near the end
+    for c, d in enumerate(delays):
+        if c != 2:
+            rec[c, d:d + N] += (0.5 * e.test_signal).astype(np.float32)[: L - d]
+            rec[c, d + 300:d + 300 + N] += (0.1 * e.test_signal).astype(np.float32)[: L - d - 300]
+    firs = rng.standard_normal((B, K)) * np.exp(-np.arange(K) / 200.0)
+    plan1 = ConvPlan(gpu_ctx, np.asarray(e.inverse_filter), L, "same", ws_channels=B)
+    plan5 = ConvPlan(gpu_ctx, firs, n, "full", ws_channels=B)
+    chain = FirChain(plan1, plan5, B, head, head, fade)
+    po = n + K - 1 + 5
+    d_x, d_out, d_pk = gpu_ctx.malloc(rec.nbytes), gpu_ctx.malloc(B * po * 4), gpu_ctx.malloc(B * 8)
+    gpu_ctx.h2d(d_x, rec)
+    w = np.ones(n)
+    w[:head] *= hann(2 * head)[:head]
+    w[n - fade:] *= hann(2 * fade)[fade:]
+    try:
+        for taps in (firs, firs[::-1].copy()):
+            plan5.set_filters(taps)
+            chain.execute_device(d_x, L, d_out, po, d_pk)
+            gpu_ctx.synchronize()
+            y = np.empty((B, po), dtype=np.float32)
+            pk = np.empty(B, dtype=np.int64)
+            gpu_ctx.d2h(y, d_out)
+            gpu_ctx.d2h(pk, d_pk)
+            for c in range(B):
+                ir = estimate(rec[c].astype(np.float64), e.inverse_filter)
+                want_pk = peak_index(ir)
+                assert int(pk[c]) == want_pk
+                s0 = min(max(want_pk - head, 0), L - n)
+                ref = fft_convolve(ir[s0:s0 + n] * w, taps[c], "full")
+                if c == 2:
+                    assert not np.any(y[c, :n + K - 1])
+                else:
+                    assert rel(y[c, :n + K - 1], ref) <= TIME_TOL
+        assert delays[4] + N // 2 - head > L - n                  # the clamp was exercised
+    finally:
+        chain.close()
+        plan1.close()
+        plan5.close()
+        for p in (d_x, d_out, d_pk):
+            gpu_ctx.free(p)
