@@ -1952,11 +1952,12 @@ def test_fir_chain_without_host_round_trip(gpu_ctx):
     L, n, K, head, fade, B = N + 2 * fs, 20000, 3000, 48, 400, 5
     rng = np.random.default_rng(21)
     rec = np.zeros((B, L), dtype=np.float32)
-    delays = [100, 777, 0, 60000, 95000]                       # channel 2 stays silent; channel 4 peaks near the end
+    delays = [100, 777, 0, 60000, 155000]                      # channel 2 stays silent; channel 4 peaks near the end
     for c, d in enumerate(delays):
         if c != 2:
             rec[c, d:d + N] += (0.5 * e.test_signal).astype(np.float32)[: L - d]
             rec[c, d + 300:d + 300 + N] += (0.1 * e.test_signal).astype(np.float32)[: L - d - 300]
+    rec[4] += (rng.standard_normal(L) * 1e-4).astype(np.float32)
     firs = rng.standard_normal((B, K)) * np.exp(-np.arange(K) / 200.0)
     plan1 = ConvPlan(gpu_ctx, np.asarray(e.inverse_filter), L, "same", ws_channels=B)
     plan5 = ConvPlan(gpu_ctx, firs, n, "full", ws_channels=B)
