@@ -73,6 +73,19 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define IMP_STREAM_AUX 2
 #endif
 constexpr int kStreamAux = IMP_STREAM_AUX;
+// Cache policy of the workspace traffic (written by one kernel, read once by the next): experiments only, default 0
+#ifndef IMP_AUX_ROWS_LD
+#define IMP_AUX_ROWS_LD 0
+#endif
+#ifndef IMP_AUX_ROWS_ST
+#define IMP_AUX_ROWS_ST 0
+#endif
+#ifndef IMP_AUX_COLS_LD
+#define IMP_AUX_COLS_LD 0
+#endif
+#ifndef IMP_AUX_COLS_ST
+#define IMP_AUX_COLS_ST 0
+#endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -184,7 +197,7 @@ struct LoadWorkspace {
   __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[F]) const {
     const __amdgpu_buffer_rsrc_t r = make_rsrc(ws + (long long)b * n1_total * kN2, (unsigned)n1_total * kN2 * 8u);
 #pragma unroll
-    for (int j = 0; j < F; ++j) v[j] = bload_cf(r, e0 * 8u, (unsigned)(j * STEP) * 8u);
+    for (int j = 0; j < F; ++j) v[j] = bload_cf<IMP_AUX_COLS_LD>(r, e0 * 8u, (unsigned)(j * STEP) * 8u);
   }
 };
 
@@ -197,7 +210,7 @@ struct StoreWorkspace {
     return make_rsrc(ws + (long long)b * n1_total * kN2, (unsigned)n1_total * kN2 * 8u);
   }
   __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, unsigned e, unsigned step_elems, cf v) const {
-    bstore_cf(v, r, e * 8u, step_elems * 8u);
+    bstore_cf<IMP_AUX_COLS_ST>(v, r, e * 8u, step_elems * 8u);
   }
 };
 
@@ -673,7 +686,7 @@ __device__ __forceinline__ void rows_pair(const RowsArgs& args, const Twiddles& 
   fft16<+1>(v);                                            // over ka -> j
   IMP_MARK(8);
 #pragma unroll
-  for (int j = 0; j < 16; ++j) bstore_cf(v[j], r_row, vo8, j * 256 * 8);
+  for (int j = 0; j < 16; ++j) bstore_cf<IMP_AUX_ROWS_ST>(v[j], r_row, vo8, j * 256 * 8);
   IMP_MARK_MEM(9);
   IMP_MARK_WALL(13);
 #ifdef IMP_PHASE_TRACE
@@ -686,7 +699,7 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   int b, pair;
   xcd_work_item(args.nchan, pair, b);
   if (pair >= args.npairs) return;              // the grid is padded to a multiple of 8 pairs (whole workgroup exits)
-  rows_pair<0, 0>(args, tw, b, b, pair, reinterpret_cast<cf*>(smem_raw), (int)threadIdx.x);
+  rows_pair<IMP_AUX_ROWS_LD, 0>(args, tw, b, b, pair, reinterpret_cast<cf*>(smem_raw), (int)threadIdx.x);
 }
 
 }  // namespace imp

@@ -6,7 +6,6 @@ hot loop, core/hrir.py:307-355) goes through libimpulse_hip.so and has a batched
 reference lacks: ``estimate_batch`` deconvolves every column/track of a recording in one launch
 group.  There is no CPU fallback: without the library or a gfx950 device, estimate raises.
 """
-import os
 import threading
 
 import numpy as np
