@@ -201,7 +201,8 @@ struct LoadWorkspace {
   }
 };
 
-// Storers: bind(b) gives the channel's buffer; put(r, e, step_elems, v) writes complex point e + step_elems
+// Storers: bind(b) gives the channel's buffer; put(r, b, e, step_elems, v) writes complex point e + step_elems;
+// begin(tid, threads) / end(b, tile, tiles, n1, tid, threads) bracket a workgroup's puts (used by StoreRealCropMax)
 // (e per thread, step_elems a compile-time multiple of 4096).
 struct StoreWorkspace {
   cf* __restrict__ ws;
@@ -209,7 +210,9 @@ struct StoreWorkspace {
   __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind(int b) const {
     return make_rsrc(ws + (long long)b * n1_total * kN2, (unsigned)n1_total * kN2 * 8u);
   }
-  __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, unsigned e, unsigned step_elems, cf v) const {
+  __device__ __forceinline__ void begin(int, int) const {}
+  __device__ __forceinline__ void end(int, int, int, int, int, int) const {}
+  __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, int /*b*/, unsigned e, unsigned step_elems, cf v) const {
     bstore_cf<IMP_AUX_COLS_ST>(v, r, e * 8u, step_elems * 8u);
   }
 };
@@ -225,7 +228,9 @@ struct StoreRealCrop {
   __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind(int b) const {
     return make_rsrc(base + (long long)b * chan_stride, (unsigned)len * 4u);
   }
-  __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, unsigned e, unsigned step_elems, cf v) const {
+  __device__ __forceinline__ void begin(int, int) const {}
+  __device__ __forceinline__ void end(int, int, int, int, int, int) const {}
+  __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, int /*b*/, unsigned e, unsigned step_elems, cf v) const {
     // the whole offset goes through the VGPR: a negative voffset stays out of range whatever soffset adds
     const unsigned off = (2u * (e + step_elems) - (unsigned)start) * 4u;
     if (start & 1) {
@@ -256,7 +261,9 @@ struct StoreRealCropAdd {
   __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind(int b) const {
     return make_rsrc(base + (long long)b * chan_stride, (unsigned)len * 4u);
   }
-  __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, unsigned e, unsigned step_elems, cf v) const {
+  __device__ __forceinline__ void begin(int, int) const {}
+  __device__ __forceinline__ void end(int, int, int, int, int, int) const {}
+  __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, int /*b*/, unsigned e, unsigned step_elems, cf v) const {
     const unsigned off = (2u * (e + step_elems) - (unsigned)start) * 4u;
     unsigned off_im = off + 4u;
     asm volatile("" : "+v"(off_im));            // two dword accesses: the straddling point splits at either edge
@@ -337,6 +344,7 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
   const unsigned n2 = (unsigned)(tile * TC + c);
   const __amdgpu_buffer_rsrc_t r_full = make_rsrc(tw.full, (unsigned)n1_total * kN2 * 8u);
   const __amdgpu_buffer_rsrc_t r_out = st.bind(b);
+  st.begin(tid, T);
 
   constexpr int GG = (R2 > 1) ? G : 16, KB = (R2 > 1) ? R2 : 1;
   // pass A: four-step twiddles of this thread's outputs, fetched with the inputs (see cols_mixed_kernel)
@@ -369,9 +377,10 @@ __global__ __launch_bounds__(ColsCfg<R2>::T) void cols_kernel(Load ld, Store st,
     for (int kb = 0; kb < KB; ++kb) {
       cf z = v[i * KB + kb];
       if constexpr (DIR < 0) z = cmul(z, twd[i][kb]);
-      st.put(r_out, e, (unsigned)(kb * 16 * kN2), z);
+      st.put(r_out, b, e, (unsigned)(kb * 16 * kN2), z);
     }
   }
+  st.end(b, tile, kN2 / TC, n1_total, tid, T);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -410,6 +419,7 @@ __global__ __launch_bounds__((MixCfg<F, R2>::T)) void cols_mixed_kernel(Load ld,
   const unsigned n2 = (unsigned)(tile * TC + c);
   const __amdgpu_buffer_rsrc_t r_full = make_rsrc(tw.full, (unsigned)n1_total * kN2 * 8u);
   const __amdgpu_buffer_rsrc_t r_out = st.bind(b);
+  st.begin(tid, T);
 
   // pass A: the four-step twiddles of this thread's outputs are fetched with the inputs, not after the
   // exchange where their latency would sit in front of the stores
@@ -443,10 +453,11 @@ __global__ __launch_bounds__((MixCfg<F, R2>::T)) void cols_mixed_kernel(Load ld,
       for (int kb = 0; kb < R2; ++kb) {                    // output row k1 = ka + F kb
         cf z = y[kb];
         if constexpr (DIR < 0) z = cmul(z, twd[i][kb]);
-        st.put(r_out, e, (unsigned)(kb * F * kN2), z);
+        st.put(r_out, b, e, (unsigned)(kb * F * kN2), z);
       }
     }
   }
+  st.end(b, tile, kN2 / TC, n1_total, tid, T);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -462,6 +473,7 @@ __global__ __launch_bounds__(256) void cols_small_kernel(Load ld, Store st, Twid
   const unsigned n2 = (unsigned)(tile * 256 + threadIdx.x);
   const __amdgpu_buffer_rsrc_t r_full = make_rsrc(tw.full, (unsigned)n1_total * kN2 * 8u);
   const __amdgpu_buffer_rsrc_t r_out = st.bind(b);
+  st.begin((int)threadIdx.x, 256);
   cf twd[F];
 #pragma unroll
   for (int k = 0; k < F; ++k) twd[k] = bload_cf(r_full, n2 * 8u, (unsigned)(k * kN2) * 8u);
@@ -477,8 +489,9 @@ __global__ __launch_bounds__(256) void cols_small_kernel(Load ld, Store st, Twid
   for (int k = 0; k < F; ++k) {
     cf z = v[k];
     if constexpr (DIR < 0) z = cmul(z, twd[k]);
-    st.put(r_out, n2, (unsigned)(k * kN2), z);
+    st.put(r_out, b, n2, (unsigned)(k * kN2), z);
   }
+  st.end(b, tile, kN2 / 256, n1_total, (int)threadIdx.x, 256);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -404,6 +404,8 @@ struct imp_plan {
   int64_t xlaunches = 0;
   int x_cus = 0;
   int64_t xunchecked = 0;            // resident launches since the abort word was last read
+  // set by imp_chain around a launch: pass C also leaves K3's chunk maxima (ir_kernels.hip.h StoreRealCropMax)
+  unsigned* tile_max = nullptr;     // [channels][column tiles][N1]
   // timing
   int timing = 0;                    // 0 = off, n = record every n-th launch group
   int64_t group_counter = 0;
@@ -450,6 +452,14 @@ static int launch_cols_small(imp_plan* p, int64_t nchan, Load ld, Store st) {
                      (int)p->N1);
   HIP_TRY(hipGetLastError());
   return IMP_OK;
+}
+
+// column tiles per row of the kernel launch_cols_any picks for this plan (kN2 / its TC)
+static int plan_col_tiles(const imp_plan* p) {
+  if (p->R2 == 1 && (p->F == 4 || p->F == 8)) return imp::kN2 / 256;
+  const bool pow2 = p->F == 16 && (p->R2 == 1 || p->R2 == 2 || p->R2 == 4 || p->R2 == 8 || p->R2 == 16);
+  const int tc = pow2 ? (p->R2 >= 16 ? 32 : 64) : (p->F * p->R2 >= 192 ? 32 : 64);
+  return imp::kN2 / tc;
 }
 
 template <int DIR, class Load, class Store>
@@ -853,7 +863,9 @@ static int run_group_with(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64
   if (last_stage < 2) return IMP_OK;
   imp::LoadWorkspace ldw{p->cur_ws, p->N1};
   imp::StoreRealCrop stc{d_y, chan_stride_out, p->out_start, p->out_len};
-  if ((rc = launch_cols_any<+1>(p, nchan, ldw, stc))) return rc;
+  if (p->tile_max) rc = launch_cols_any<+1>(p, nchan, ldw, imp::StoreRealCropMax{stc, p->tile_max});
+  else rc = launch_cols_any<+1>(p, nchan, ldw, stc);
+  if (rc) return rc;
   if ((rc = timing_event(p, 3))) return rc;
   return IMP_OK;
 }
@@ -1207,35 +1219,32 @@ extern "C" int imp_plan_debug_run_stage(imp_plan* p, const float* x, int64_t B, 
 // ------------------------------------------------------------------------------------------------
 static int peak_index_impl(imp_ctx* ctx, const float* d_x, const int64_t* off, const int64_t* len, int64_t B,
                            double peak_height, int64_t* idx_out, float* maxabs_out) {
+  // the search works on |x| against one positive threshold (the reference's callers pass 0.12589 = -18 dB)
+  if (!(peak_height > 0.0)) return fail(IMP_ERR_INVALID, "peak_height must be positive (got %g)", peak_height);
   if (B == 0) return IMP_OK;
-  // scratch: off[B], len[B], res[B] (RowPeak)
+  int64_t maxlen = 0;
+  for (int64_t b = 0; b < B; ++b) maxlen = std::max(maxlen, len[b]);
+  const int64_t chunks = std::max<int64_t>(1, (maxlen + imp::kPeakChunk - 1) / imp::kPeakChunk);
+  // scratch: off[B], len[B], res[B] (RowPeak), chunk maxima [B][chunks]
   const size_t meta = (size_t)B * sizeof(int64_t);
   const size_t res_bytes = (size_t)B * sizeof(imp::RowPeak);
   void* scr = nullptr;
-  int rc = ctx_scratch(ctx, 2 * meta + res_bytes, &scr);
+  int rc = ctx_scratch(ctx, 2 * meta + res_bytes + (size_t)(B * chunks) * sizeof(unsigned), &scr);
   if (rc) return rc;
   int64_t* d_off = (int64_t*)scr;
   int64_t* d_len = d_off + B;
   imp::RowPeak* d_res = (imp::RowPeak*)(d_len + B);
+  unsigned* d_chunk = (unsigned*)(d_res + B);
   hipStream_t s = ctx->stream;
   HIP_TRY(hipMemcpyAsync(d_off, off, meta, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_len, len, meta, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(imp::row_chunk_max_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, s, d_x, d_off, d_len,
+                     (int64_t)0, d_chunk, chunks);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)B), dim3(imp::kPeakThreads), 0, s, d_x, d_off, d_len,
+                     (int64_t)0, (const unsigned*)nullptr, 0, (const unsigned*)d_chunk, chunks, d_res, peak_height, (long long*)nullptr);
+  HIP_TRY(hipGetLastError());
   std::vector<imp::RowPeak> h((size_t)B);
-  for (auto& r : h) {
-    r.maxabs_bits = 0u;
-    r.pad = 0u;
-    r.first_peak = ~0ull;
-    r.first_max = ~0ull;
-  }
-  HIP_TRY(hipMemcpyAsync(d_res, h.data(), res_bytes, hipMemcpyHostToDevice, s));
-  int64_t maxlen = 0;
-  for (int64_t b = 0; b < B; ++b) maxlen = std::max(maxlen, len[b]);
-  const int bpr = (int)std::max<int64_t>(1, std::min<int64_t>(256, (maxlen + 4095) / 4096));
-  dim3 grid((unsigned)bpr, (unsigned)B), block(256);
-  hipLaunchKernelGGL(imp::row_maxabs_kernel, grid, block, 0, s, d_x, d_off, d_len, d_res);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(imp::row_first_peak_kernel, grid, block, 0, s, d_x, d_off, d_len, d_res, peak_height);
-  HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(h.data(), d_res, res_bytes, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   for (int64_t b = 0; b < B; ++b) {
@@ -1299,10 +1308,11 @@ struct imp_chain {
   imp_ctx* ctx = nullptr;
   imp_plan* deconv = nullptr;       // K1: 'same' plan of the recording length
   imp_plan* fir = nullptr;          // K5: 'full' plan of length n with per-channel (or one shared) filters
-  int64_t B = 0, n = 0, head = 0, fade_in = 0, fade_out = 0, pitch_ir = 0, pitch_crop = 0;
+  int64_t B = 0, n = 0, head = 0, fade_in = 0, fade_out = 0, pitch_ir = 0;
   double peak_height = 0.12589;
-  float* d_ir = nullptr;            // [B][pitch_ir]
-  float* d_crop = nullptr;          // [B][pitch_crop]
+  float* d_ir = nullptr;            // [B][pitch_ir]: the deconvolved columns
+  unsigned* d_tile = nullptr;       // [B][column tiles][N1 of the deconvolution]: max|y| per tile and row, left by pass C
+  int tiles = 0;
   imp::RowPeak* d_res = nullptr;
   int64_t* d_meta = nullptr;        // off[B], len[B]
 };
@@ -1313,7 +1323,7 @@ extern "C" void imp_chain_destroy(imp_chain* c) {
   (void)hipSetDevice(c->ctx->device);
   (void)hipStreamSynchronize(c->ctx->stream);
   (void)hipFree(c->d_ir);
-  (void)hipFree(c->d_crop);
+  (void)hipFree(c->d_tile);
   (void)hipFree(c->d_res);
   (void)hipFree(c->d_meta);
   delete c;
@@ -1327,7 +1337,10 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
   IMP_CTX_LOCK(deconv->ctx);
   if (deconv->mode != IMP_MODE_SAME || fir->mode != IMP_MODE_FULL)
     return fail(IMP_ERR_INVALID, "imp_chain_create: needs a 'same' deconvolution plan and a 'full' FIR plan");
+  if (!(peak_height > 0.0)) return fail(IMP_ERR_INVALID, "imp_chain_create: peak_height must be positive (got %g)", peak_height);
   if (deconv->lanes != 1 || fir->lanes != 1) return fail(IMP_ERR_INVALID, "imp_chain_create: plans must run in stream order (lanes = 1)");
+  if (deconv->ola || fir->ola || deconv->resident || fir->resident)
+    return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: overlap-add and XCD-resident plans cannot be chained");
   const int64_t n = fir->L;
   if (B < 1 || B > deconv->ws_channels || B > fir->ws_channels) return fail(IMP_ERR_INVALID, "imp_chain_create: B exceeds a plan's workspace");
   if (fir->n_filters > 1 && B > fir->n_filters) return fail(IMP_ERR_INVALID, "imp_chain_create: fewer FIRs than channels");
@@ -1348,14 +1361,19 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
   c->fade_out = fade_out;
   c->peak_height = peak_height;
   c->pitch_ir = (deconv->out_len + 63) / 64 * 64;
-  c->pitch_crop = (n + 63) / 64 * 64;
   std::vector<int64_t> meta((size_t)(2 * B));
   for (int64_t b = 0; b < B; ++b) {
     meta[(size_t)b] = b * c->pitch_ir;
     meta[(size_t)(B + b)] = deconv->out_len;
   }
+  if (deconv->N1 > imp::kMaxPlanRows) {
+    delete c;
+    return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: deconvolution plan of %d rows", deconv->N1);
+  }
+  c->tiles = plan_col_tiles(deconv);
+  const size_t chunk_bytes = (size_t)(B * deconv->N1) * sizeof(unsigned);
   if (hipMalloc((void**)&c->d_ir, (size_t)(B * c->pitch_ir) * sizeof(float)) != hipSuccess ||
-      hipMalloc((void**)&c->d_crop, (size_t)(B * c->pitch_crop) * sizeof(float)) != hipSuccess ||
+      hipMalloc((void**)&c->d_tile, chunk_bytes * (size_t)c->tiles) != hipSuccess ||
       hipMalloc((void**)&c->d_res, (size_t)B * sizeof(imp::RowPeak)) != hipSuccess ||
       hipMalloc((void**)&c->d_meta, (size_t)(2 * B) * sizeof(int64_t)) != hipSuccess ||
       hipMemcpy(c->d_meta, meta.data(), meta.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) {
@@ -1366,24 +1384,29 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
   return IMP_OK;
 }
 
+// Five launches in stream order: pass A, pass B, pass C (+ chunk maxima), the peak search, then K5 whose pass A reads the
+// cropped, faded responses straight out of the deconvolved columns (LoadCropAtPeak), pass B, pass C.
 extern "C" int imp_chain_execute_device(imp_chain* c, const float* d_x, int64_t chan_stride_in, int64_t elem_stride_in,
                                         float* d_out, int64_t chan_stride_out, long long* d_peaks_out) {
   if (!c || !d_x || !d_out) return fail(IMP_ERR_INVALID, "imp_chain_execute_device: null argument");
   IMP_CTX_LOCK(c->ctx);
-  int rc = imp_conv_execute_device(c->deconv, d_x, c->B, chan_stride_in, elem_stride_in, c->d_ir, c->pitch_ir);
+  if (chan_stride_out < c->fir->out_len)
+    return fail(IMP_ERR_INVALID, "chan_stride_out %lld < out_len %lld", (long long)chan_stride_out, (long long)c->fir->out_len);
+  if (c->deconv->lanes != 1 || c->fir->lanes != 1 || c->deconv->resident || c->fir->resident)
+    return fail(IMP_ERR_INVALID, "imp_chain_execute_device: a plan was switched to overlapped or resident execution");
+  int rc = ctx_bind(c->ctx);
   if (rc) return rc;
   hipStream_t s = c->ctx->stream;
-  const int64_t L = c->deconv->out_len;
-  hipLaunchKernelGGL(imp::row_peak_init_kernel, dim3((unsigned)((c->B + 255) / 256)), dim3(256), 0, s, c->d_res, (int)c->B);
-  const int bpr = (int)std::max<int64_t>(1, std::min<int64_t>(256, (L + 4095) / 4096));
-  dim3 grid((unsigned)bpr, (unsigned)c->B), block(256);
-  hipLaunchKernelGGL(imp::row_maxabs_kernel, grid, block, 0, s, c->d_ir, c->d_meta, c->d_meta + c->B, c->d_res);
-  hipLaunchKernelGGL(imp::row_first_peak_kernel, grid, block, 0, s, c->d_ir, c->d_meta, c->d_meta + c->B, c->d_res, c->peak_height);
-  const int cpr = (int)std::max<int64_t>(1, std::min<int64_t>(64, (c->n + 1023) / 1024));
-  hipLaunchKernelGGL(imp::crop_at_peak_kernel, dim3((unsigned)cpr, (unsigned)c->B), block, 0, s, c->d_ir, c->d_meta,
-                     c->d_meta + c->B, c->d_res, c->d_crop, c->pitch_crop, c->n, c->head, c->fade_in, c->fade_out, d_peaks_out);
+  c->deconv->tile_max = c->d_tile;
+  rc = imp_conv_execute_device(c->deconv, d_x, c->B, chan_stride_in, elem_stride_in, c->d_ir, c->pitch_ir);
+  c->deconv->tile_max = nullptr;
+  if (rc) return rc;
+  hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)c->B), dim3(imp::kPeakThreads), 0, s, c->d_ir, c->d_meta,
+                     c->d_meta + c->B, c->deconv->out_start, (const unsigned*)c->d_tile, c->tiles, (const unsigned*)nullptr,
+                     (int64_t)c->deconv->N1, c->d_res, c->peak_height, d_peaks_out);
   HIP_TRY(hipGetLastError());
-  return imp_conv_execute_device(c->fir, c->d_crop, c->B, c->pitch_crop, 1, d_out, chan_stride_out);
+  imp::LoadCropAtPeak ld{c->d_ir, c->pitch_ir, c->deconv->out_len, c->d_res, c->n, c->head, c->fade_in, c->fade_out};
+  return run_group_with(c->fir, ld, c->B, d_out, chan_stride_out, 0, 2);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -7,86 +7,264 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "conv_kernels.hip.h"
+
 namespace imp {
 
 struct RowPeak {
   unsigned int maxabs_bits;         // bits of max|x| (non-negative floats order like unsigned ints)
   unsigned int pad;
   unsigned long long first_peak;    // smallest index passing the find_peaks rule, ~0 if none
-  unsigned long long first_max;     // smallest index with |x| == max|x|
+  unsigned long long first_max;     // smallest index with |x| == max|x|; looked for only when there is no peak
 };
 
-// grid = (blocks_per_row, B)
-__global__ __launch_bounds__(256) void row_maxabs_kernel(const float* __restrict__ x,
-                                                         const int64_t* __restrict__ off,
-                                                         const int64_t* __restrict__ len,
-                                                         RowPeak* __restrict__ res) {
-  const int b = blockIdx.y;
-  const int64_t n = len[b];
-  const float* row = x + off[b];
-  float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    m = fmaxf(m, fabsf(row[i]));
-  // wave64 reduction
+// ---------------------------------------------------------------------------------------------
+// K3 in two steps.  Step 1 leaves one number per CHUNK of kPeakChunk samples: the bits of max|x| over the chunk.  It is
+// either row_chunk_max_kernel below (one read of the rows) or, when the rows come out of K1, the epilogue of pass C
+// (StoreRealCropMax further down: a chunk is then one four-step row, 8 192 samples of the un-cropped result, `shift` is
+// the crop start, and the maxima arrive per column tile).  Step 2 (row_first_peak_chunked_kernel, one workgroup per row)
+// reduces the chunk maxima to the row maximum and then reads only the chunks that CAN hold the answer: the find_peaks
+// height test is monotone in |x|, so the first peak starts in the first chunk whose maximum passes it.
+// Chunk c of row b covers the samples i with (i + shift) / kPeakChunk == c.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPeakChunk = 8192;
+#ifdef IMP_PEAK_DIAG
+#define IMP_PEAK_T(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) peak_ts[k] = clock64(); } while (0)
+#else
+#define IMP_PEAK_T(k) do { } while (0)
+#endif
+constexpr int kPeakThreads = 1024;
+constexpr int kMaxPlanRows = 256;      // four-step rows (N1) a chained plan may have
+
+__device__ __forceinline__ int64_t peak_chunks(int64_t n, int64_t shift) {
+  return n > 0 ? (n + shift + kPeakChunk - 1) / kPeakChunk : 0;
+}
+
+// block-wide reductions over NW waves; the result is returned to every thread
+template <int NW>
+__device__ __forceinline__ float block_max_f32(float m, float* wm /*[NW], 16-byte aligned*/) {
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-  __shared__ float wm[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (lane == 0) wm[wv] = m;
+  __syncthreads();                                                        // wm may still be read from an earlier call
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-    // NaN-free inputs assumed (as the reference: np.max would propagate NaN and find_peaks none)
-    atomicMax(&res[b].maxabs_bits, __float_as_uint(m));
+  float r = wm[0];
+#pragma unroll
+  for (int k = 1; k < NW; ++k) r = fmaxf(r, wm[k]);
+  return r;
+}
+
+template <int NW>
+__device__ __forceinline__ unsigned long long block_min_u64(unsigned long long v, unsigned long long* wm /*[NW]*/) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    const unsigned long long o = __shfl_xor(v, s, 64);
+    v = o < v ? o : v;
   }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long r = wm[0];
+#pragma unroll
+  for (int k = 1; k < NW; ++k) r = wm[k] < r ? wm[k] : r;
+  return r;
+}
+
+// grid = (max chunks per row, B), 256 threads
+__global__ __launch_bounds__(256) void row_chunk_max_kernel(const float* __restrict__ x, const int64_t* __restrict__ off,
+                                                            const int64_t* __restrict__ len, int64_t shift,
+                                                            unsigned* __restrict__ chunk_max, int64_t pitch) {
+  const int b = blockIdx.y;
+  const int64_t n = len[b], c = blockIdx.x;
+  if (c >= peak_chunks(n, shift)) return;
+  const int64_t lo = c * kPeakChunk - shift > 0 ? c * kPeakChunk - shift : 0;
+  const int64_t hi = (c + 1) * kPeakChunk - shift < n ? (c + 1) * kPeakChunk - shift : n;
+  const float* row = x + off[b];
+  float m = 0.f;
+  int64_t i = lo + threadIdx.x;
+  for (; i + 7 * 256 < hi; i += 8 * 256) {                    // eight loads in flight per thread
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = row[i + k * 256];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(v[k]));
+  }
+  for (; i < hi; i += 256) m = fmaxf(m, fabsf(row[i]));
+  __shared__ __attribute__((aligned(16))) float wm[4];
+  m = block_max_f32<4>(m, wm);
+  // NaN-free inputs assumed (as the reference: np.max would propagate NaN and find_peaks none)
+  if (threadIdx.x == 0) chunk_max[(int64_t)b * pitch + c] = __float_as_uint(m);
 }
 
 // SciPy _local_maxima_1d on +x and -x, height filter x[peak]/max >= h (inclusive), min index.
 //  - sample i starts a candidate iff v[i-1] < v[i]
 //  - plateau: run of equal samples i..j; it is a peak iff j+1 < n and v[j+1] < v[j];
 //    reported index = (i + j) / 2; first and last samples are never peaks
-__global__ __launch_bounds__(256) void row_first_peak_kernel(const float* __restrict__ x,
-                                                             const int64_t* __restrict__ off,
-                                                             const int64_t* __restrict__ len,
-                                                             RowPeak* __restrict__ res, double height) {
-  const int b = blockIdx.y;
+// Plateaus are disjoint and ordered, so the candidate that STARTS first also reports the smallest index: the search can
+// stop at the first chunk that yields one.  A chunk is staged in LDS (with one sample either side) by loads that are all
+// in flight at once; only a plateau that runs past the chunk goes back to memory.
+// grid = B, kPeakThreads threads.
+// tiles > 0: step 1 was pass C - the chunk maxima are max over the tiles of tile_max[b][tile][r] (r < pitch) and
+// chunk_max is not read.
+// peaks_out (optional, device): ImpulseResponse.peak_index of every row.
+__global__ __launch_bounds__(kPeakThreads) void row_first_peak_chunked_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ off, const int64_t* __restrict__ len, int64_t shift,
+    const unsigned* __restrict__ tile_max, int tiles, const unsigned* __restrict__ chunk_max, int64_t pitch,
+    RowPeak* __restrict__ res, double height, long long* __restrict__ peaks_out) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+#ifdef IMP_PEAK_DIAG
+  long long peak_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  IMP_PEAK_T(0);
   const int64_t n = len[b];
   const float* row = x + off[b];
-  const float maxabs = __uint_as_float(res[b].maxabs_bits);
-  if (!(maxabs >= 1e-20f)) return;
-  const double dmax = (double)maxabs;
-  unsigned long long best = ~0ull, bestmax = ~0ull;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float xi = row[i];
-    if (fabsf(xi) == maxabs && (unsigned long long)i < bestmax) bestmax = (unsigned long long)i;
-    if (i == 0 || i >= n - 1) continue;
-    if ((unsigned long long)i >= best) continue;
-    const float xm = row[i - 1];
-    // polarity: +x peak needs xm < xi ; -x peak needs xm > xi
-    const bool up = xm < xi, dn = xm > xi;
-    if (!up && !dn) continue;
-    // data / max >= height, evaluated in fp64 exactly like the reference does on float64 data
-    const double v = (up ? (double)xi : -(double)xi) / dmax;
-    if (!(v >= height)) continue;
-    int64_t j = i;
-    while (j + 1 < n && row[j + 1] == xi) ++j;
-    if (j + 1 >= n) continue;
-    const float xn = row[j + 1];
-    if (up ? (xn < xi) : (xn > xi)) {
-      const unsigned long long pk = (unsigned long long)((i + j) / 2);
-      if (pk < best) best = pk;
+  const int64_t nch = peak_chunks(n, shift);
+  constexpr int NW = kPeakThreads / 64;
+  __shared__ __attribute__((aligned(16))) float wmf[NW];
+  __shared__ __attribute__((aligned(16))) unsigned long long wmu[NW];
+  __shared__ float sx[kPeakChunk + 2];
+  // the chunk maxima are consulted several times: keep them in LDS (rows of up to 16 M samples; longer ones stay in memory)
+  constexpr int kLdsChunks = 2048;
+  __shared__ unsigned srows[kLdsChunks];
+  const unsigned* cm = chunk_max + (int64_t)b * pitch;
+  if (tiles > 0) {
+    // lanes along the rows (coalesced), waves along the tiles; nch <= pitch <= kMaxPlanRows here
+    for (int r = tid; r < kMaxPlanRows; r += kPeakThreads) srows[r] = 0u;
+    __syncthreads();
+    const unsigned* tm = tile_max + (int64_t)b * tiles * pitch;
+    const int lane = tid & 63, w = tid >> 6;
+    for (int64_t r = lane; r < nch; r += 64) {
+      unsigned m = 0u;
+#pragma unroll 4
+      for (int t = w; t < tiles; t += kPeakThreads / 64) {
+        const unsigned v = tm[(int64_t)t * pitch + r];
+        m = v > m ? v : m;
+      }
+      if (m) atomicMax(&srows[r], m);
+    }
+    __syncthreads();
+    cm = srows;
+  } else if (nch <= kLdsChunks) {
+    for (int64_t c = tid; c < nch; c += kPeakThreads) srows[c] = cm[c];
+    __syncthreads();
+    cm = srows;
+  }
+  IMP_PEAK_T(1);
+  float mf = 0.f;
+  for (int64_t c = tid; c < nch; c += kPeakThreads) mf = fmaxf(mf, __uint_as_float(cm[c]));
+  const float maxabs = block_max_f32<NW>(mf, wmf);
+  RowPeak out;
+  out.maxabs_bits = __float_as_uint(maxabs);
+  out.pad = 0u;
+  out.first_peak = ~0ull;
+  out.first_max = ~0ull;
+  if (maxabs >= 1e-20f) {
+    // The reference tests data / max >= height on float64 data.  Division by a positive number is monotone, so on fp32
+    // samples that is |x| >= thr with thr the smallest float passing the fp64 test: found once (by one thread: an fp64
+    // division costs a wave ~400 cycles), no division per sample.
+    __shared__ float s_thr;
+    if (tid == 0) {
+      const double dmax = (double)maxabs;
+      float t = (float)(height * dmax);
+      if (!(t >= 0.f)) t = 0.f;
+      for (int k = 0; k < 4 && t > 0.f && (double)__uint_as_float(__float_as_uint(t) - 1u) / dmax >= height; ++k)
+        t = __uint_as_float(__float_as_uint(t) - 1u);
+      for (int k = 0; k < 4 && !((double)t / dmax >= height); ++k) t = __uint_as_float(__float_as_uint(t) + 1u);
+      s_thr = t;
+    }
+    __syncthreads();
+    const float thr = s_thr;
+    IMP_PEAK_T(2);
+    unsigned long long c_q = ~0ull;                             // first chunk that can hold a peak
+    for (int64_t c = tid; c < nch; c += kPeakThreads)
+      if (__uint_as_float(cm[c]) >= thr && (unsigned long long)c < c_q) c_q = (unsigned long long)c;
+    c_q = block_min_u64<NW>(c_q, wmu);
+    constexpr int U = (kPeakChunk + kPeakThreads - 1) / kPeakThreads;      // samples per thread and chunk
+    int64_t lo = 0, hi = 0;
+    auto stage = [&](int64_t c) {                              // sx[k] = row[lo - 1 + k], zero outside the row
+      lo = c * kPeakChunk - shift > 0 ? c * kPeakChunk - shift : 0;
+      hi = (c + 1) * kPeakChunk - shift < n ? (c + 1) * kPeakChunk - shift : n;
+      const int64_t cnt = hi - lo + 2;
+      float t[U + 1];
+#pragma unroll
+      for (int u = 0; u <= U; ++u) {                           // all loads in flight before the first LDS write
+        const int64_t k = tid + (int64_t)u * kPeakThreads, i = lo - 1 + k;
+        t[u] = (k < cnt && i >= 0 && i < n) ? row[i] : 0.f;
+      }
+      __syncthreads();                                         // the previous chunk is no longer read
+#pragma unroll
+      for (int u = 0; u <= U; ++u) {
+        const int64_t k = tid + (int64_t)u * kPeakThreads;
+        if (k < cnt) sx[k] = t[u];
+      }
+      __syncthreads();
+    };
+    IMP_PEAK_T(3);
+    for (int64_t c = c_q == ~0ull ? nch : (int64_t)c_q; c < nch; ++c) {          // every bound here is block-uniform
+      if (!(__uint_as_float(cm[c]) >= thr)) continue;
+      stage(c);
+      IMP_PEAK_T(4);
+      float xs[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = lo + tid + (int64_t)u * kPeakThreads;
+        xs[u] = i < hi ? sx[i - lo + 1] : 0.f;
+      }
+      unsigned long long best = ~0ull;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = lo + tid + (int64_t)u * kPeakThreads;
+        const float xi = xs[u];
+        if (best != ~0ull || !(fabsf(xi) >= thr) || i >= hi || i == 0 || i >= n - 1) continue;   // the rare test first
+        const float xm = sx[i - lo];
+        // polarity: +x peak needs xm < xi ; -x peak needs xm > xi
+        const bool up = xm < xi, dn = xm > xi;
+        if (!up && !dn) continue;
+        if (!((up ? xi : -xi) >= thr)) continue;
+        int64_t j = i;
+        while (j + 1 < n && (j + 1 <= hi ? sx[j + 1 - lo + 1] : row[j + 1]) == xi) ++j;
+        if (j + 1 >= n) continue;
+        const float xn = j + 1 <= hi ? sx[j + 1 - lo + 1] : row[j + 1];
+        // this thread's later samples can only report later peaks: `best` set ends its search
+        if (up ? (xn < xi) : (xn > xi)) best = (unsigned long long)((i + j) / 2);
+      }
+      best = block_min_u64<NW>(best, wmu);
+      if (best != ~0ull) {
+        out.first_peak = best;
+        break;
+      }
+    }
+    IMP_PEAK_T(5);
+    if (out.first_peak == ~0ull) {
+      // no peak anywhere (a monotone row, say): the answer is the first sample at the maximum (argmax fallback)
+      unsigned long long c_max = ~0ull;
+      for (int64_t c = tid; c < nch; c += kPeakThreads)
+        if (__uint_as_float(cm[c]) == maxabs && (unsigned long long)c < c_max) c_max = (unsigned long long)c;
+      c_max = block_min_u64<NW>(c_max, wmu);
+      stage((int64_t)c_max);
+      unsigned long long best = ~0ull;
+      for (int64_t i = lo + tid; i < hi; i += kPeakThreads)
+        if (fabsf(sx[i - lo + 1]) == maxabs) {
+          best = (unsigned long long)i;
+          break;
+        }
+      out.first_max = block_min_u64<NW>(best, wmu);
     }
   }
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) {
-    unsigned long long o = __shfl_xor(best, s, 64);
-    best = o < best ? o : best;
-    unsigned long long om = __shfl_xor(bestmax, s, 64);
-    bestmax = om < bestmax ? om : bestmax;
-  }
-  if ((threadIdx.x & 63) == 0) {
-    if (best != ~0ull) atomicMin(&res[b].first_peak, best);
-    if (bestmax != ~0ull) atomicMin(&res[b].first_max, bestmax);
+  IMP_PEAK_T(6);
+#ifdef IMP_PEAK_DIAG
+  if (tid == 0 && b == 0)
+    printf("peak phases (clk): entry->fold %lld, max+thr %lld, cq %lld, stage %lld, search %lld, fallback %lld\n", peak_ts[1] - peak_ts[0],
+           peak_ts[2] - peak_ts[1], peak_ts[3] - peak_ts[2], peak_ts[4] - peak_ts[3], peak_ts[5] - peak_ts[4], peak_ts[6] - peak_ts[5]);
+#endif
+  if (tid == 0) {
+    res[b] = out;
+    if (peaks_out) {
+      long long pk;
+      if (n == 0 || !(maxabs >= 1e-20f)) pk = 0;                                   // EPSILON rule, impulse_response.py:56-58
+      else pk = (long long)(out.first_peak != ~0ull ? out.first_peak : out.first_max);   // argmax fallback, :66-67
+      peaks_out[b] = pk;
+    }
   }
 }
 
@@ -95,44 +273,94 @@ __device__ __forceinline__ double hann_sym_fwd(int64_t i, int64_t N) {     // sc
   return 0.5 - 0.5 * cospi(2.0 * (double)i / (double)(N - 1));
 }
 
-// start of a device-side search on rows of equal pitch: res[b] = "nothing found yet"
-__global__ __launch_bounds__(256) void row_peak_init_kernel(RowPeak* __restrict__ res, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  res[b].maxabs_bits = 0u;
-  res[b].pad = 0u;
-  res[b].first_peak = ~0ull;
-  res[b].first_max = ~0ull;
+// ---------------------------------------------------------------------------------------------
+// K1 -> K3 -> K4 -> K5 without leaving the device (imp_chain): two functors that put K3's first step and K4 into the
+// column passes either side of them.
+// ---------------------------------------------------------------------------------------------
+
+// Pass C store of K1 that also leaves the maxima K3 starts from: max|y| over the KEPT samples of every four-step row
+// within the workgroup's column tile (point p = e + step lies in row p >> 12; its samples are 2p - start and
+// 2p + 1 - start).  A wave holds 64 consecutive columns of one row, or 2 x 32 columns of two rows (ColsCfg with TC = 32):
+// the maximum is taken over each half wave with DPP moves, lanes 31 / 63 fold it into a per-row LDS word, and end()
+// writes the workgroup's n1 words as one coalesced store to tile_max[b][tile][row].  Plain stores, every word written by
+// exactly one workgroup: nothing to zero, no global atomics (one atomicMax per half wave and put made pass C 3x slower).
+__device__ __forceinline__ unsigned* crop_max_lds() {
+  __shared__ unsigned rows[kMaxPlanRows];
+  return rows;
 }
 
-// Crop every row at its own first peak WITHOUT a host round trip: row b (src + off[b], len[b] samples) is read from
-// start = clamp(peak - head, 0, len - n) and n samples are written to dst + b * dst_pitch with a Hann fade-in of
-// `fade_in` and fade-out of `fade_out` samples (core/impulse_response.py:82-90 crop_head + the fades of
-// core/hrir.py:591-612, :642-651 at a fixed length).  peak = ImpulseResponse.peak_index as K3 found it (res[b]).
-__global__ __launch_bounds__(256) void crop_at_peak_kernel(const float* __restrict__ src, const int64_t* __restrict__ off,
-                                                           const int64_t* __restrict__ len, const RowPeak* __restrict__ res,
-                                                           float* __restrict__ dst, int64_t dst_pitch, int64_t n, int64_t head,
-                                                           int64_t fade_in, int64_t fade_out, long long* __restrict__ peaks_out) {
-  const int b = blockIdx.y;
-  const float m = __uint_as_float(res[b].maxabs_bits);
-  long long pk;
-  if (len[b] == 0 || !(m >= 1e-20f)) pk = 0;
-  else if (res[b].first_peak != ~0ull) pk = (long long)res[b].first_peak;
-  else pk = (long long)res[b].first_max;
-  if (peaks_out && blockIdx.x == 0 && threadIdx.x == 0) peaks_out[b] = pk;
-  long long start = pk - head;
-  if (start > len[b] - n) start = len[b] - n;
-  if (start < 0) start = 0;
-  const float* in = src + off[b] + start;
-  const int64_t avail = len[b] - start;
-  float* out = dst + (int64_t)b * dst_pitch;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+struct StoreRealCropMax {
+  StoreRealCrop crop;
+  unsigned* __restrict__ tile_max;   // [B][tiles][n1]
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind(int b) const { return crop.bind(b); }
+  __device__ __forceinline__ void begin(int tid, int threads) const {
+    unsigned* rows = crop_max_lds();
+    for (int r = tid; r < kMaxPlanRows; r += threads) rows[r] = 0u;
+    __syncthreads();
+  }
+  __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, int b, unsigned e, unsigned step_elems, cf v) const {
+    crop.put(r, b, e, step_elems, v);
+    const unsigned p = e + step_elems;
+    const unsigned i_re = 2u * p - (unsigned)crop.start;          // wraps out of range below the window
+    float m = i_re < (unsigned)crop.len ? fabsf(v.x) : 0.f;
+    if (i_re + 1u < (unsigned)crop.len) m = fmaxf(m, fabsf(v.y));
+    int mi = __float_as_int(m);
+    // max over each row of 16 lanes (quad swaps, half mirror, mirror), then row 0 -> 1 and row 2 -> 3 (row_bcast:15)
+    mi = __float_as_int(fmaxf(__int_as_float(mi), __int_as_float(__builtin_amdgcn_update_dpp(0, mi, 0xB1, 0xF, 0xF, true))));
+    mi = __float_as_int(fmaxf(__int_as_float(mi), __int_as_float(__builtin_amdgcn_update_dpp(0, mi, 0x4E, 0xF, 0xF, true))));
+    mi = __float_as_int(fmaxf(__int_as_float(mi), __int_as_float(__builtin_amdgcn_update_dpp(0, mi, 0x141, 0xF, 0xF, true))));
+    mi = __float_as_int(fmaxf(__int_as_float(mi), __int_as_float(__builtin_amdgcn_update_dpp(0, mi, 0x140, 0xF, 0xF, true))));
+    mi = __float_as_int(fmaxf(__int_as_float(mi), __int_as_float(__builtin_amdgcn_update_dpp(0, mi, 0x142, 0xA, 0xF, true))));
+    if ((threadIdx.x & 31) == 31 && mi != 0) atomicMax(crop_max_lds() + (p >> 12), (unsigned)mi);
+  }
+  __device__ __forceinline__ void end(int b, int tile, int tiles, int n1, int tid, int threads) const {
+    __syncthreads();
+    const unsigned* rows = crop_max_lds();
+    unsigned* out = tile_max + ((long long)b * tiles + tile) * n1;
+    for (int r = tid; r < n1; r += threads) out[r] = rows[r];
+  }
+};
+
+// Pass A load of K5 that IS K4: channel b is read from start = clamp(peak - head, 0, row_len - n) of its row, n samples
+// long, with a Hann fade-in of `fade_in` and fade-out of `fade_out` samples (core/impulse_response.py:82-90 crop_head +
+// the fades of core/hrir.py:591-612, :642-651 at a fixed length).  peak = ImpulseResponse.peak_index as K3 left it in
+// res[b].  Samples past the row's end read as zero (the buffer's range check), as does the transform's padding.
+struct LoadCropAtPeak {
+  const float* __restrict__ base;   // row 0, sample 0
+  long long chan_stride;            // samples between rows
+  long long row_len;                // samples per row
+  const RowPeak* __restrict__ res;
+  long long n, head, fade_in, fade_out;
+  __host__ __device__ LoadCropAtPeak shifted(long long, long long) const { return *this; }   // overlap-add plans are refused
+  __device__ __forceinline__ float shaped(float x, long long i) const {
     double g = 1.0;
     if (i < fade_in) g *= hann_sym_fwd(i, 2 * fade_in);
-    if (fade_out > 0 && i >= n - fade_out) g *= hann_sym_fwd(fade_out + (i - (n - fade_out)), 2 * fade_out);
-    out[i] = i < avail ? (float)((double)in[i] * g) : 0.f;
+    if (fade_out > 0 && i >= n - fade_out && i < n) g *= hann_sym_fwd(fade_out + (i - (n - fade_out)), 2 * fade_out);
+    return (float)((double)x * g);
   }
-}
+  template <int STEP, int F>
+  __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[F]) const {
+    const RowPeak rp = res[b];
+    long long pk;
+    if (row_len == 0 || !(__uint_as_float(rp.maxabs_bits) >= 1e-20f)) pk = 0;
+    else pk = (long long)(rp.first_peak != ~0ull ? rp.first_peak : rp.first_max);
+    long long start = pk - head;
+    if (start > row_len - n) start = row_len - n;
+    if (start < 0) start = 0;
+    const long long avail = row_len - start;
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(base + (long long)b * chan_stride + start, (unsigned)(avail < n ? avail : n) * 4u);
+#pragma unroll
+    for (int j = 0; j < F; ++j) {
+      const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, e0 * 8u, (unsigned)(j * STEP) * 8u, 0);
+      v[j] = make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
+      const long long i = 2ll * ((long long)e0 + (long long)j * STEP);
+      if (i < fade_in || i + 1 >= n - fade_out) {              // only the two ends pay for the window
+        v[j].x = shaped(v[j].x, i);
+        v[j].y = shaped(v[j].y, i + 1);
+      }
+    }
+  }
+};
 
 // layout-compatible with imp_window_params (include/impulse_hip.h)
 struct WindowParams {

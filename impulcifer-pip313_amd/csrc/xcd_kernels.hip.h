@@ -194,13 +194,13 @@ __device__ __forceinline__ void xcd_tile_inverse(const StoreRealCrop& st, const 
       const unsigned e = (unsigned)ka * kN2 + n2;
 #pragma unroll
       for (int kb = 0; kb < R2; ++kb) {
-        if constexpr (R2 > 1) st.put(r_out, e, (unsigned)(kb * F * kN2), y[kb]);
+        if constexpr (R2 > 1) st.put(r_out, chan, e, (unsigned)(kb * F * kN2), y[kb]);
       }
     }
   }
   if constexpr (R2 == 1) {
 #pragma unroll
-    for (int a = 0; a < F; ++a) st.put(r_out, n2, (unsigned)(a * kN2), v[a]);
+    for (int a = 0; a < F; ++a) st.put(r_out, chan, n2, (unsigned)(a * kN2), v[a]);
   }
 }
 

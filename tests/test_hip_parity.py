@@ -318,6 +318,47 @@ def test_peak_index_matches_oracle_on_long_rows(gpu_ctx):
         assert m == np.max(np.abs(r))
 
 
+def test_peak_index_around_the_chunk_boundaries(gpu_ctx):
+    """K3 reads only the 8192-sample chunks that can hold the first peak: peaks on a chunk edge, plateaus that run across
+    an edge, a rising slope whose crest lies in a later chunk, rows without any peak (argmax fallback), negative peaks and
+    rows that end right after an edge - all against the oracle."""
+    from oracle.impulse_response import peak_index
+    rng = np.random.default_rng(77)
+    rows = []
+
+    def base(n, level=1e-3):
+        return (rng.standard_normal(n) * level).astype(np.float32)
+
+    for at in (8191, 8192, 8193, 16383, 16384):                  # a lone spike on / next to an edge
+        x = base(30000)
+        x[at] = 1.0 if at % 2 else -1.0
+        rows.append(x)
+    x = base(30000)                                               # plateau across the edge: index = middle of the run
+    x[8188:8197] = 0.7
+    x[20000] = 1.0
+    rows.append(x)
+    x = base(30000)                                               # slope starts in chunk 0, crest in chunk 1
+    x[8100:8300] += np.linspace(0.0, 1.0, 200, dtype=np.float32)
+    x[8300:8400] += np.linspace(1.0, 0.0, 100, dtype=np.float32)
+    rows.append(x)
+    rows.append(np.linspace(0.0, 1.0, 20000, dtype=np.float32))   # no peak at all: first index of the maximum
+    rows.append(-np.linspace(0.0, 1.0, 8193, dtype=np.float32))
+    x = np.zeros(16385, dtype=np.float32)                         # the maximum is the very last sample (never a peak)
+    x[-1] = 1.0
+    x[5000] = 0.5
+    rows.append(x)
+    x = base(8192 * 3)                                            # qualifying chunk without a peak start, then the peak
+    x[8192:16384] = 0.5                                           # one long plateau = chunk 1, falls at 16384
+    x[20000] = -1.0
+    rows.append(x)
+    rows.append(np.zeros(9000, dtype=np.float32))                 # silence: index 0
+    rows.append(base(5))
+    idx, mx = gpu_ctx.peak_index(rows)
+    for k, (r, i, m) in enumerate(zip(rows, idx, mx)):
+        assert int(i) == peak_index(r.astype(np.float64)), k
+        assert m == np.max(np.abs(r)), k
+
+
 def _decaying_sine(fs, duration_s, rt60, freq=1000.0, floor_db=-90.0, seed=0):
     r = np.random.default_rng(seed)
     n = int(duration_s * fs)
