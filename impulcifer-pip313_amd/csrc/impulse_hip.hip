@@ -154,6 +154,7 @@ extern "C" int imp_ctx_create(int device_id, imp_ctx** out) {
     delete ctx;
     return fail(IMP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
   }
+  if (const char* mb = std::getenv("IMPULSE_HIP_POOL_MB")) ctx->free_cap = (size_t)std::max(0ll, std::atoll(mb)) << 20;
   int rc = ctx_row_tables(ctx);
   if (rc) {
     hipStreamDestroy(ctx->stream);
@@ -177,6 +178,7 @@ extern "C" int imp_ctx_set_stream(imp_ctx* ctx, void* hip_stream) {
 }
 
 static int resident_check(imp_plan* p);      // defined with the plan
+static void pool_release(imp_ctx* ctx);      // defined with imp_malloc
 
 extern "C" int imp_ctx_synchronize(imp_ctx* ctx) {
   if (!ctx) return fail(IMP_ERR_INVALID, "null ctx");
@@ -202,6 +204,8 @@ extern "C" void imp_ctx_destroy(imp_ctx* ctx) {
   if (ctx->tw_t2) (void)hipFree(ctx->tw_t2);
   if (ctx->tw_t4) (void)hipFree(ctx->tw_t4);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  pool_release(ctx);
+  for (auto& kv : ctx->live_blocks) (void)hipFree(kv.first);      // blocks the caller never handed back
   minphase_plans_destroy(ctx);
   fft_roots_destroy(ctx);
   magnitude_plans_destroy(ctx);
@@ -213,23 +217,57 @@ extern "C" void imp_ctx_destroy(imp_ctx* ctx) {
   delete ctx;
 }
 
+static void pool_release(imp_ctx* ctx) {
+  for (auto& kv : ctx->free_blocks) (void)hipFree(kv.second);
+  ctx->free_blocks.clear();
+  ctx->free_bytes = 0;
+}
+
 extern "C" int imp_malloc(imp_ctx* ctx, size_t bytes, void** dptr) {
   if (!ctx || !dptr) return fail(IMP_ERR_INVALID, "imp_malloc: null argument");
+  IMP_CTX_LOCK(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   *dptr = nullptr;
   if (bytes == 0) return IMP_OK;
+  // a kept block of this size, or up to a quarter larger
+  auto it = ctx->free_blocks.lower_bound(bytes);
+  if (it != ctx->free_blocks.end() && it->first <= bytes + bytes / 4) {
+    *dptr = it->second;
+    ctx->live_blocks[it->second] = it->first;
+    ctx->free_bytes -= it->first;
+    ctx->free_blocks.erase(it);
+    return IMP_OK;
+  }
   hipError_t e = hipMalloc(dptr, bytes);
+  if (e != hipSuccess && !ctx->free_blocks.empty()) {        // give the kept blocks back and try once more
+    (void)hipGetLastError();
+    pool_release(ctx);
+    e = hipMalloc(dptr, bytes);
+  }
   if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  ctx->live_blocks[*dptr] = bytes;
   return IMP_OK;
 }
 
 extern "C" int imp_free(imp_ctx* ctx, void* dptr) {
   if (!ctx) return fail(IMP_ERR_INVALID, "null ctx");
   if (!dptr) return IMP_OK;
+  IMP_CTX_LOCK(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
+  // nothing in flight may still use the block, whoever gets it next (hipFree would have drained the device too)
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (auto st : ctx->side_streams) HIP_TRY(hipStreamSynchronize(st));
+  auto it = ctx->live_blocks.find(dptr);
+  if (it == ctx->live_blocks.end()) return fail(IMP_ERR_INVALID, "imp_free: %p did not come from imp_malloc on this context", dptr);
+  const size_t bytes = it->second;
+  ctx->live_blocks.erase(it);
+  if (ctx->free_bytes + bytes <= ctx->free_cap) {
+    ctx->free_blocks.emplace(bytes, dptr);
+    ctx->free_bytes += bytes;
+    return IMP_OK;
+  }
   HIP_TRY(hipFree(dptr));
   return IMP_OK;
 }
@@ -1595,7 +1633,7 @@ extern "C" int imp_segset_range_means(imp_segset* s, const int64_t* q_seg, const
   HIP_TRY(hipMemcpyAsync(d_seg, q_seg, (size_t)Q * sizeof(int64_t), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_a, q_a, (size_t)Q * sizeof(int64_t), hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d_b, q_b, (size_t)Q * sizeof(int64_t), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(imp::seg_range_mean_kernel, dim3((unsigned)((Q + 63) / 64)), dim3(64), 0, st, s->e, s->off, d_seg, d_a,
+  hipLaunchKernelGGL(imp::seg_range_mean_kernel, dim3((unsigned)Q), dim3(256), 0, st, s->e, s->off, d_seg, d_a,
                      d_b, (long long)Q, d_m);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(mean_out, d_m, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -58,6 +58,12 @@ struct imp_ctx {
   std::set<const void*> lds_opt_in;
   // plans with XCD-resident launches whose abort word has not been looked at since (imp_ctx_synchronize does)
   std::set<struct imp_plan*> resident_plans;
+  // imp_malloc / imp_free: blocks handed back are kept for the next request of about that size (hipFree costs ~0.4 ms
+  // and drains the device; the per-measurement row blocks of the slice come and go at fixed sizes)
+  std::map<void*, size_t> live_blocks;          // size of every block imp_malloc handed out
+  std::multimap<size_t, void*> free_blocks;     // by size
+  size_t free_bytes = 0;
+  size_t free_cap = (size_t)2 << 30;            // IMPULSE_HIP_POOL_MB
 };
 
 // opt a kernel into `bytes` of dynamic LDS on the context's device, once per context

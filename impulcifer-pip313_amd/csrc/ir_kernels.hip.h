@@ -559,79 +559,123 @@ __global__ __launch_bounds__(256) void seg_square_kernel(double* __restrict__ x,
   }
 }
 
-__device__ inline double np_block_sum(const double* a, int n) {      // n <= 128
-  if (n < 8) {
-    double r = 0.0;
-    for (int i = 0; i < n; ++i) r += a[i];
-    return r;
-  }
-  double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
-  int i = 8;
-  for (; i < n - (n % 8); i += 8) {
-    r0 += a[i];
-    r1 += a[i + 1];
-    r2 += a[i + 2];
-    r3 += a[i + 3];
-    r4 += a[i + 4];
-    r5 += a[i + 5];
-    r6 += a[i + 6];
-    r7 += a[i + 7];
-  }
-  double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-  for (; i < n; ++i) res += a[i];
-  return res;
-}
+// mean_out[q] = np.mean(e[seg][a:b]); an empty range gives NaN like NumPy.  One workgroup of 256 threads per query.
+// np.add.reduce hands its inner loop the run in pieces of the ufunc buffer size (8192 elements) and adds the pieces'
+// pairwise sums left to right (observed on NumPy 2.2: tests pin it against np.mean).  The pairwise sum of a piece is a
+// fixed binary tree: a run longer than 128 splits at n/2 rounded down to a multiple of 8, a shorter one is summed on 8
+// interleaved accumulators r_j = a[j] + a[j+8] + ..., combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the n % 8 tail.  The tree is laid out level by level in LDS (wave 0), its leaves are summed by
+// groups of 8 lanes - one accumulator each, the loads of a group contiguous - and the levels are folded back bottom-up
+// with the left operand first, so every addition is the one NumPy performs.
+constexpr int kSumNodes = 256;     // nodes per level of a piece's tree (<= 8192 / 57 leaves)
+constexpr int kSumLevels = 8;      // 8192 -> 128 takes six splits
 
-// NumPy's pairwise sum of a[0..n), recursion unrolled onto an explicit stack (depth <= 40 for any int64 n)
-__device__ inline double np_pairwise_sum(const double* a, long long n) {
-  struct Frame { const double* p; long long n; int state; double left; };
-  Frame st[48];
-  int sp = 0;
-  st[0] = Frame{a, n, 0, 0.0};
-  double ret = 0.0;
-  while (sp >= 0) {
-    Frame& f = st[sp];
-    if (f.n <= 128) {
-      ret = np_block_sum(f.p, (int)f.n);
-      --sp;
-      continue;
-    }
-    long long n2 = f.n / 2;
-    n2 -= n2 % 8;
-    if (f.state == 0) {                   // descend left
-      f.state = 1;
-      st[++sp] = Frame{f.p, n2, 0, 0.0};
-    } else if (f.state == 1) {            // left done -> descend right
-      f.left = ret;
-      f.state = 2;
-      st[++sp] = Frame{f.p + n2, f.n - n2, 0, 0.0};
-    } else {                              // both done
-      ret = f.left + ret;
-      --sp;
-    }
-  }
-  return ret;
-}
-
-// mean_out[q] = np.mean(e[seg][a:b]); an empty range gives NaN like NumPy
-__global__ __launch_bounds__(64) void seg_range_mean_kernel(const double* __restrict__ e, const int64_t* __restrict__ off,
-                                                            const int64_t* __restrict__ q_seg,
-                                                            const int64_t* __restrict__ q_a,
-                                                            const int64_t* __restrict__ q_b, long long Q,
-                                                            double* __restrict__ mean_out) {
-  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= Q) return;
+__global__ __launch_bounds__(256) void seg_range_mean_kernel(const double* __restrict__ e, const int64_t* __restrict__ off,
+                                                             const int64_t* __restrict__ q_seg,
+                                                             const int64_t* __restrict__ q_a,
+                                                             const int64_t* __restrict__ q_b, long long Q,
+                                                             double* __restrict__ mean_out) {
+  const long long q = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const long long n = q_b[q] - q_a[q];
   if (n <= 0) {
-    mean_out[q] = __longlong_as_double(0x7ff8000000000000ll);
+    if (tid == 0) mean_out[q] = __longlong_as_double(0x7ff8000000000000ll);
     return;
   }
-  // np.add.reduce hands its inner loop the run in pieces of the ufunc buffer size (8192 elements) and
-  // adds the pieces' pairwise sums left to right (observed on NumPy 2.2: tests pin it against np.mean)
   const double* a = e + off[q_seg[q]] + q_a[q];
-  double acc = np_pairwise_sum(a, n < 8192 ? n : 8192);
-  for (long long i = 8192; i < n; i += 8192) acc += np_pairwise_sum(a + i, (n - i) < 8192 ? (n - i) : 8192);
-  mean_out[q] = acc / (double)n;
+  __shared__ unsigned short s_off[kSumLevels][kSumNodes], s_len[kSumLevels][kSumNodes], s_child[kSumLevels][kSumNodes];
+  __shared__ double s_sum[2][kSumNodes];
+  __shared__ int s_levels, s_count[kSumLevels];
+  double acc = 0.0;
+  for (long long p0 = 0; p0 < n; p0 += 8192) {
+    const int m = (int)((n - p0) < 8192 ? (n - p0) : 8192);
+    const double* piece = a + p0;
+    __syncthreads();                                       // the previous piece's tables are no longer read
+    if (tid < 64) {                                        // wave 0 lays the tree out
+      if (lane == 0) {
+        s_off[0][0] = 0;
+        s_len[0][0] = (unsigned short)m;
+      }
+      int cnt = 1, lev = 0;
+      for (;; ++lev) {
+        if (lane == 0) s_count[lev] = cnt;
+        bool any = false;
+        int carry = 0;
+        for (int base = 0; base < cnt; base += 64) {
+          const int k = base + lane;
+          const bool valid = k < cnt;
+          const int len = valid ? s_len[lev][k] : 0, o = valid ? s_off[lev][k] : 0;
+          const bool split = len > 128;
+          const int kids = valid ? (split ? 2 : 1) : 0;
+          int incl = kids;                                 // inclusive scan over the wave
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+          }
+          const int pos = carry + incl - kids;
+          any = any || __any(split);
+          if (valid && lev + 1 < kSumLevels) {
+            s_child[lev][k] = (unsigned short)(pos | (split ? 0x8000 : 0));
+            if (split) {
+              int n2 = len / 2;
+              n2 -= n2 % 8;
+              s_off[lev + 1][pos] = (unsigned short)o;
+              s_len[lev + 1][pos] = (unsigned short)n2;
+              s_off[lev + 1][pos + 1] = (unsigned short)(o + n2);
+              s_len[lev + 1][pos + 1] = (unsigned short)(len - n2);
+            } else {
+              s_off[lev + 1][pos] = (unsigned short)o;
+              s_len[lev + 1][pos] = (unsigned short)len;
+            }
+          }
+          carry += __shfl(incl, 63, 64);
+        }
+        if (!any || lev + 1 >= kSumLevels) break;
+        cnt = carry;
+      }
+      if (lane == 0) s_levels = lev;                       // the leaves are the nodes of level `lev`
+    }
+    __syncthreads();
+    const int lev = s_levels, leaves = s_count[lev];
+    // leaf sums: 8 lanes per leaf, lane j owns accumulator r_j = a[j] + a[j + 8] + ... in order
+    for (int leaf = tid >> 3; leaf < leaves; leaf += 32) {
+      const int j = tid & 7, len = s_len[lev][leaf];
+      const double* p = piece + s_off[lev][leaf];
+      double res;
+      if (len < 8) {
+        res = 0.0;
+        for (int i = 0; i < len; ++i) res += p[i];         // every lane of the group computes the same serial sum
+      } else {
+        const int body = len - (len % 8);
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = (j + 8 * u) < body ? p[j + 8 * u] : 0.0;     // all loads in flight
+        double r = v[0];
+#pragma unroll
+        for (int u = 1; u < 16; ++u)
+          if (j + 8 * u < body) r += v[u];
+        r += __shfl_xor(r, 1, 64);                         // (r0 + r1), (r2 + r3), ...
+        r += __shfl_xor(r, 2, 64);                         // (r0 + r1) + (r2 + r3), ...
+        r += __shfl_xor(r, 4, 64);                         // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
+        res = r;
+        for (int i = body; i < len; ++i) res += p[i];
+      }
+      if (j == 0) s_sum[0][leaf] = res;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int l = lev - 1; l >= 0; --l) {                   // fold the levels back: parent = left + right
+      for (int k = tid; k < s_count[l]; k += 256) {
+        const unsigned short c = s_child[l][k];
+        const int pos = c & 0x7fff;
+        s_sum[cur ^ 1][k] = (c & 0x8000) ? s_sum[cur][pos] + s_sum[cur][pos + 1] : s_sum[cur][pos];
+      }
+      cur ^= 1;
+      __syncthreads();
+    }
+    if (tid == 0) acc = p0 == 0 ? s_sum[cur][0] : acc + s_sum[cur][0];
+  }
+  if (tid == 0) mean_out[q] = acc / (double)n;
 }
 
 // ---------------------------------------------------------------------------------------------

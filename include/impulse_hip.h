@@ -51,7 +51,10 @@ int imp_ctx_set_stream(imp_ctx* ctx, void* hip_stream);
 int imp_ctx_synchronize(imp_ctx* ctx);
 void imp_ctx_destroy(imp_ctx* ctx);
 
-/* device memory helpers (so a NumPy-only host needs no other HIP binding) */
+/* device memory helpers (so a NumPy-only host needs no other HIP binding).  imp_free takes only pointers imp_malloc of
+ * the same context returned; it waits for the context's streams and then KEEPS the block for the next request of about
+ * that size (hipFree costs ~0.4 ms and drains the device), up to IMPULSE_HIP_POOL_MB (default 2048; 0 = give every
+ * block back at once).  imp_ctx_destroy releases what is kept and what was never handed back. */
 int imp_malloc(imp_ctx* ctx, size_t bytes, void** dptr);
 int imp_free(imp_ctx* ctx, void* dptr);
 int imp_memcpy_h2d(imp_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);

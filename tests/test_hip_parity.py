@@ -318,6 +318,30 @@ def test_peak_index_matches_oracle_on_long_rows(gpu_ctx):
         assert m == np.max(np.abs(r))
 
 
+def test_device_blocks_are_kept_and_reused(gpu_ctx):
+    """imp_free keeps a block for the next request of about its size (no hipFree per measurement); a pointer that did not
+    come from imp_malloc is refused."""
+    from impulse_hip._native import NativeError
+    a = gpu_ctx.malloc(3 << 20)
+    keep = gpu_ctx.malloc(3 << 20)
+    assert keep != a
+    gpu_ctx.free(a)
+    b = gpu_ctx.malloc((3 << 20) - 4096)                       # a little smaller: the kept block serves it
+    assert b == a
+    gpu_ctx.free(b)
+    c = gpu_ctx.malloc(1 << 20)                                # much smaller: a block of its own
+    assert c not in (a, keep)
+    x = np.arange(1 << 18, dtype=np.float32)
+    gpu_ctx.h2d(c, x)
+    y = np.empty_like(x)
+    gpu_ctx.d2h(y, c)
+    assert np.array_equal(x, y)
+    for p in (c, keep):
+        gpu_ctx.free(p)
+    with pytest.raises(NativeError, match="did not come from imp_malloc"):
+        gpu_ctx.free(0x7f0000001000)
+
+
 def test_peak_index_around_the_chunk_boundaries(gpu_ctx):
     """K3 reads only the 8192-sample chunks that can hold the first peak: peaks on a chunk edge, plateaus that run across
     an edge, a rising slope whose crest lies in a later chunk, rows without any peak (argmax fallback), negative peaks and
