@@ -254,7 +254,9 @@ int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_off, const 
  * core/impulse_response.py:32-70 ImpulseResponse.peak_index (twin core/decay.py:12-41):
  * normalise by max|x| of the searched range, scipy.signal.find_peaks(+x and -x, height), minimum
  * index; no peak -> argmax|x|; max|x| < 1e-20 -> 0.  Indices are relative to each row's start.
- * The height test is done in fp64 (x/max >= peak_height) so it is exact for fp32 data.
+ * The reference's fp64 test x/max >= peak_height is turned, once per row, into the smallest fp32 threshold with the
+ * same outcome (division by a positive number is monotone), so it stays exact for fp32 data.  peak_height must be
+ * positive (the reference's callers pass 0.12589 = -18 dB).
  * x: host, B rows at x + off[b], lengths len[b].
  */
 int imp_peak_index(imp_ctx* ctx, const float* x, const int64_t* off, const int64_t* len, int64_t B,
@@ -325,7 +327,9 @@ int imp_magnitude_db_sum_device(imp_ctx* ctx, const float* d_rows, const int64_t
  * device.  `deconv` is a 'same' plan, `fir` a 'full' plan of length n (its filters may be refilled with
  * imp_plan_set_filters between calls); both must be in stream order (lanes = 1) and outlive the chain.
  * imp_chain_execute_device is asynchronous on the context stream; d_out receives B rows of n + K - 1 samples,
- * d_peaks_out (device, may be NULL) the B peak indices. */
+ * d_peaks_out (device, may be NULL) the B peak indices.  Seven launches: the deconvolution's last pass also leaves the
+ * row maxima the peak search starts from, and the FIR's first pass reads the cropped, faded responses in place.
+ * Overlap-add and XCD-resident plans cannot be chained. */
 typedef struct imp_chain imp_chain;
 int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int64_t head, int64_t fade_in, int64_t fade_out,
                      double peak_height, imp_chain** out);
