@@ -2059,3 +2059,57 @@ def test_fir_chain_without_host_round_trip(gpu_ctx):
         plan5.close()
         for p in (d_x, d_out, d_pk):
             gpu_ctx.free(p)
+
+
+@pytest.mark.parametrize("L,M,rows", [(52000, 20001, 8), (100000, 50001, 16), (150000, 60001, 24), (1100000, 300001, 160),
+                                      (1400000, 300001, 192), (1800000, 300001, 256)])
+def test_fir_chain_on_every_column_kernel_family(gpu_ctx, L, M, rows):
+    """imp_chain's fused steps live in the column passes: the row maxima in pass C of the deconvolution (short plans,
+    power-of-two plans with 64- and 32-column tiles, mixed-radix plans with 64- and 32-column tiles) and the crop in pass A
+    of the FIR.  Arbitrary (non-sweep) signals, against the oracle."""
+    from impulse_hip import ConvPlan
+    from impulse_hip._native import FirChain
+    from oracle.impulse_response import peak_index
+    from oracle.scipy_restated import fft_convolve, hann
+    rng = np.random.default_rng(rows)
+    B, n, K, head, fade = 2, 20000, 3000, 48, 400
+    h = rng.standard_normal(M) * 1e-3 * np.exp(-np.arange(M) / (M / 8.0))
+    h[M // 2] += 1.0
+    x = (rng.standard_normal((B, L)) * 1e-4).astype(np.float32)
+    for c, at in enumerate((int(0.37 * L), L - 9000)):              # the second one peaks too close to the end: clamped crop
+        x[c, at] += 1.0
+        x[c, at + 211] -= 0.6
+        x[c, at - 3000] += 0.05                                     # pre-echo below -18 dB: not the first peak
+    firs = rng.standard_normal((B, K)) * np.exp(-np.arange(K) / 200.0)
+    plan1 = ConvPlan(gpu_ctx, h, L, "same", ws_channels=B)
+    assert plan1.n1 == rows
+    plan5 = ConvPlan(gpu_ctx, firs, n, "full", ws_channels=B)
+    chain = FirChain(plan1, plan5, B, head, head, fade)
+    po = n + K - 1 + 3
+    d_x, d_out, d_pk = gpu_ctx.malloc(x.nbytes), gpu_ctx.malloc(B * po * 4), gpu_ctx.malloc(B * 8)
+    gpu_ctx.h2d(d_x, x)
+    w = np.ones(n)
+    w[:head] *= hann(2 * head)[:head]
+    w[n - fade:] *= hann(2 * fade)[fade:]
+    try:
+        for _ in range(2):                                          # twice: nothing is left over from the first run
+            chain.execute_device(d_x, L, d_out, po, d_pk)
+        gpu_ctx.synchronize()
+        y = np.empty((B, po), dtype=np.float32)
+        pk = np.empty(B, dtype=np.int64)
+        gpu_ctx.d2h(y, d_out)
+        gpu_ctx.d2h(pk, d_pk)
+        for c in range(B):
+            ir = fft_convolve(x[c].astype(np.float64), h, "same")
+            want_pk = peak_index(ir)
+            assert int(pk[c]) == want_pk
+            s0 = min(max(want_pk - head, 0), L - n)
+            ref = fft_convolve(ir[s0:s0 + n] * w, firs[c], "full")
+            assert rel(y[c, :n + K - 1], ref) <= TIME_TOL
+        assert peak_index(fft_convolve(x[1].astype(np.float64), h, "same")) - head > L - n      # the clamp was exercised
+    finally:
+        chain.close()
+        plan1.close()
+        plan5.close()
+        for ptr in (d_x, d_out, d_pk):
+            gpu_ctx.free(ptr)
