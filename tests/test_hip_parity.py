@@ -2113,3 +2113,45 @@ def test_fir_chain_on_every_column_kernel_family(gpu_ctx, L, M, rows):
         plan5.close()
         for ptr in (d_x, d_out, d_pk):
             gpu_ctx.free(ptr)
+
+
+def test_chain_and_peak_search_refuse_what_they_cannot_do(gpu_ctx):
+    """Loud errors instead of wrong answers: a non-positive peak height (the search works on |x| against one positive
+    threshold), plans that run overlapped, overlap-add plans, the wrong plan modes, a crop longer than the response."""
+    from impulse_hip import ConvPlan
+    from impulse_hip._native import FirChain, NativeError
+    rng = np.random.default_rng(3)
+    with pytest.raises(NativeError, match="peak_height must be positive"):
+        gpu_ctx.peak_index([rng.standard_normal(100).astype(np.float32)], peak_height=0.0)
+    same = ConvPlan(gpu_ctx, rng.standard_normal(500), 40000, "same", ws_channels=4)
+    full = ConvPlan(gpu_ctx, rng.standard_normal((2, 300)), 9000, "full", ws_channels=4)
+    long_full = ConvPlan(gpu_ctx, rng.standard_normal(300), 50000, "full", ws_channels=4)
+    ola = ConvPlan(gpu_ctx, rng.standard_normal(300), 3 << 20, "same", ws_channels=1)
+    try:
+        with pytest.raises(NativeError, match="peak_height must be positive"):
+            FirChain(same, full, 2, 48, 48, 100, peak_height=-0.1)
+        with pytest.raises(NativeError, match="'same' deconvolution plan and a 'full' FIR plan"):
+            FirChain(full, same, 2, 48, 48, 100)
+        with pytest.raises(NativeError, match="does not fit"):
+            FirChain(same, long_full, 1, 48, 48, 100)              # crop of 50 000 out of 40 000 samples
+        with pytest.raises(NativeError, match="fewer FIRs than channels"):
+            FirChain(same, full, 3, 48, 48, 100)
+        with pytest.raises(NativeError, match="cannot be chained"):
+            FirChain(ola, full, 1, 48, 48, 100)
+        same.set_overlap(2)
+        with pytest.raises(NativeError, match="stream order"):
+            FirChain(same, full, 2, 48, 48, 100)
+        same.set_overlap(1)
+        chain = FirChain(same, full, 2, 48, 48, 100)
+        d_x, d_out = gpu_ctx.malloc(2 * 40000 * 4), gpu_ctx.malloc(2 * 9300 * 4)
+        with pytest.raises(NativeError, match="chan_stride_out"):
+            chain.execute_device(d_x, 40000, d_out, 9000)           # rows of 9 299 samples do not fit a pitch of 9 000
+        same.set_overlap(2)
+        with pytest.raises(NativeError, match="switched to overlapped"):
+            chain.execute_device(d_x, 40000, d_out, 9300)
+        chain.close()
+        gpu_ctx.free(d_x)
+        gpu_ctx.free(d_out)
+    finally:
+        for pl in (same, full, long_full, ola):
+            pl.close()
