@@ -47,7 +47,12 @@ WORKLOADS = {
 }
 # channels per launch group when groups overlap on 3 lanes (measured sweeps): the
 # groups in flight together must still fit the 256 MiB Infinity Cache with their inputs and outputs
-GROUP_CHANNELS = {"c2": 16, "c3": 9, "c4": 8, "c5": 8}
+GROUP_CHANNELS = {"c2": 32, "c3": 9, "c4": 8, "c5": 8}
+# Resident measurements that travel through K1 as ONE launch group (their rows are contiguous in HBM).  At C2 two 7.1
+# measurements = 32 channels per group: with three groups in flight the workspaces (96 x 2.2 MB) still fit the 256 MiB
+# Infinity Cache, and every launch carries twice the workgroups (tools/k1_rate.py: 16 ch x 3 lanes 413 k, 32 x 3 443 k,
+# 48 x 3 359 k IR/s - past 32 the workspaces spill to HBM).  --measurements-per-group 1 is the round-1 shape.
+MEASUREMENTS_PER_GROUP = {"c2": 2, "c3": 1, "c4": 1, "c5": 1}
 
 
 def parse_args(argv=None):
@@ -67,6 +72,8 @@ def parse_args(argv=None):
                          "event records from perturbing the throughput being measured)")
     ap.add_argument("--input-sets", type=int, default=0,
                     help="input batches in rotation = measurements per step (0: enough for 1 GiB, at most 40)")
+    ap.add_argument("--measurements-per-group", type=int, default=0,
+                    help="resident measurements per K1 launch group (default: 2 at C2, 1 elsewhere)")
     ap.add_argument("--strong", action="store_true", help="add the strong_c5 block at N = 1 too")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong_c5 block at N > 1")
     ap.add_argument("--strong-channels", type=int, default=1024)
@@ -594,6 +601,7 @@ def main(argv=None):
     fs, dur, B, desc = WORKLOADS[args.workload]
     est = make_estimator(args.workload)
     strong = args.workload in ("c4", "c5")
+    mpg, B_meas = 1, B
     if strong:
         lo, hi = shard_channels(B, world, rank)
         total_channels, B = B, hi - lo
@@ -603,12 +611,16 @@ def main(argv=None):
         rec = np.tile(base, (reps, 1))[:B]
         delays = (dl * reps)[:B]
     else:
+        mpg = max(1, args.measurements_per_group or MEASUREMENTS_PER_GROUP[args.workload])
+        B_meas, B = B, B * mpg                       # a resident block = mpg measurements, rows contiguous
         rec, L, pitch, delays = synth_recordings(est, B, seed0=0xC2 + 1000 * rank)
         total_channels = B * world
     M = len(est)
 
     ctx = Context(dev_index)
-    ws_channels = args.ws_channels or max(1, args.lanes) * GROUP_CHANNELS[args.workload]
+    # C2: a resident block (mpg measurements) is one launch group; C3 cuts its 26 channels into groups of 9
+    group_channels = B if args.workload == "c2" else GROUP_CHANNELS[args.workload]
+    ws_channels = args.ws_channels or max(1, args.lanes) * group_channels
     if rank == 0:
         plan = ConvPlan(ctx, np.asarray(est.inverse_filter, dtype=np.float64), L, "same", ws_channels=ws_channels)
     else:
@@ -760,13 +772,13 @@ def main(argv=None):
         whole_slice = None
         if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
             try:
-                whole_slice = slice_rate(est, rec, L)
+                whole_slice = slice_rate(est, rec[:B_meas], L)
             except Exception as exc:                          # noqa: BLE001 - secondary figure only
                 whole_slice = dict(error=repr(exc))
         fir_leg = None
         if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
             try:
-                fir_leg = deconv_fir_leg(dev_index, est, rec, L, pitch)
+                fir_leg = deconv_fir_leg(dev_index, est, rec[:B_meas], L, pitch)
                 peaks_ok &= fir_leg["parity"]["peak_indices_exact"] and fir_leg["parity"]["time_max_rel_err"] <= 1e-6
             except Exception as exc:                          # noqa: BLE001 - secondary figure only
                 fir_leg = dict(error=repr(exc))
@@ -778,8 +790,10 @@ def main(argv=None):
             "config": {"workload": desc, "stage": "K1 ONLY: batched sweep deconvolution incl. 'same' crop "
                        "(inverse-filter spectrum prepared once, outside the timed region); the FIR stages are not in the "
                        "timed region (`deconv_fir` = K1 -> peak -> crop -> K5 FIR on device pointers; `slice` = the whole hot-path slice end to end)",
-                       "step": f"one pass over {n_sets} resident measurements of {B} channels per GPU",
-                       "channels_per_gpu_per_measurement": B, "measurements_per_step": n_sets,
+                       "step": f"one pass over {n_sets * mpg} resident measurements of {B_meas} channels per GPU, "
+                               f"{mpg} measurement(s) = {B} channels per K1 launch group",
+                       "channels_per_gpu_per_measurement": B_meas, "measurements_per_step": n_sets * mpg,
+                       "measurements_per_launch_group": mpg, "channels_per_launch_group": B // groups_per_measurement,
                        "sweep_samples": M, "column_samples": L,
                        "layout": f"planar fp32, row pitch {pitch} samples (multiple of {PITCH_ALIGN}); output rows start "
                                  f"{wl.skew} samples into 256-byte aligned buffers so the cropped stores fall on cache lines",

@@ -1425,6 +1425,9 @@ def test_bench_contract_line(gpu_ctx):
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     assert d["ms_per_step"] * d["steps"] >= 10.0 and abs(d["timed_region_s"] * 1e3 - d["ms_per_step"] * 10) < 1e-6
     assert abs(d["value"] - d["irs_per_step"] * d["steps"] / d["timed_region_s"]) <= 1e-6 * d["value"]
+    cfg = d["config"]
+    assert cfg["channels_per_gpu_per_measurement"] == 16 and cfg["measurements_per_launch_group"] == 2
+    assert cfg["channels_per_launch_group"] == 32 and d["irs_per_step"] == 16 * cfg["measurements_per_step"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1

@@ -12,18 +12,23 @@ sys.path.insert(0, HERE)
 import pmc_summary  # noqa: E402
 import profile_summary  # noqa: E402
 
-GROUPS = {"c2": "16 channels at circular length 540672", "c3": "9 channels at circular length 1179648",
+GROUPS = {"c2": "32 channels (two 7.1 measurements) at circular length 540672", "c3": "9 channels at circular length 1179648",
           "c5": "8 channels at circular length 1572864"}
 
 
 def main(out, tag="r01"):
     prof = os.path.join(ROOT, "profiles")
+    line = json.load(open(os.path.join(out, "bench_trace.json")))
+    cfg = line["config"]
+    groups_per_step = cfg["measurements_per_step"] // cfg.get("measurements_per_launch_group", 1)
+    n_timed, n_iso = line["steps"] * groups_per_step, max(4, min(40, groups_per_step))
     kt = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 2 "
                      "--no-cpu-baseline  (tools/run_profiles.sh)",
-          "note": "bench.py runs 2 warm-up steps, 10 timed steps (a step = 40 resident measurements = 40 launch groups, 3 "
-                  "groups in flight) and 40 strictly serial launch groups for the isolated roofline; the kernel_stats.csv "
-                  "averages over ALL launches of each kernel, this file splits out the timed region and the serial tail",
-          "kernels": profile_summary.main(os.path.join(out, "trace"), 400)}
+          "note": f"bench.py runs 2 warm-up steps, {line['steps']} timed steps (a step = {cfg['measurements_per_step']} resident "
+                  f"measurements = {groups_per_step} launch groups of {cfg.get('channels_per_launch_group')} channels, 3 groups in "
+                  f"flight) and {n_iso} strictly serial launch groups for the isolated roofline; the kernel_stats.csv averages "
+                  "over ALL launches of each kernel, this file splits out the timed region and the serial tail",
+          "kernels": profile_summary.main(os.path.join(out, "trace"), n_timed, n_iso)}
     json.dump(kt, open(os.path.join(prof, f"{tag}_kernel_trace_summary.json"), "w"), indent=1)
     for root, _, files in os.walk(os.path.join(out, "trace")):
         for f in files:
