@@ -1,4 +1,4 @@
-"""The deconvolution + FIR chain alone (bench.py's `deconv_fir` leg): python tools/chain_rate.py [lanes=3] [reps=400]
+"""The deconvolution + FIR chain alone (bench.py's `deconv_fir` leg): python tools/chain_rate.py [lanes=3] [reps=400] [channels=16]
 Meant to be run under `rocprofv3 --kernel-trace --stats` to see what each stage of the chain costs."""
 import os
 import sys
@@ -11,6 +11,7 @@ import bench  # noqa: E402
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 est = bench.make_estimator("c2")
-rec, L, pitch, _ = bench.synth_recordings(est, 16, 0xC2)
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+rec, L, pitch, _ = bench.synth_recordings(est, B, 0xC2)
 out = bench.deconv_fir_leg(0, est, rec, L, pitch, reps=reps, lanes=lanes)
 print({k: out[k] for k in ("value", "ms_per_measurement", "one_chain", "parity")}, flush=True)
