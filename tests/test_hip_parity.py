@@ -2064,9 +2064,14 @@ def test_fir_chain_without_host_round_trip(gpu_ctx):
             gpu_ctx.free(p)
 
 
-@pytest.mark.parametrize("L,M,rows", [(52000, 20001, 8), (100000, 50001, 16), (150000, 60001, 24), (1100000, 300001, 160),
-                                      (1400000, 300001, 192), (1800000, 300001, 256)])
-def test_fir_chain_on_every_column_kernel_family(gpu_ctx, L, M, rows):
+@pytest.mark.parametrize("L,M,rows,n,K", [(52000, 20001, 8, 20000, 3000), (100000, 50001, 16, 20000, 3000),
+                                          (150000, 60001, 24, 20000, 3000), (1100000, 300001, 160, 20000, 3000),
+                                          (1400000, 300001, 192, 20000, 3000), (1800000, 300001, 256, 20000, 3000),
+                                          # longer crops and FIRs: K5's pass A (the fused crop) on a power-of-two plan of
+                                          # 16 rows, a mixed-radix one of 24 and a 32-column-tile one of 192
+                                          (400000, 100001, 64, 90000, 30001), (400000, 100001, 64, 150000, 40001),
+                                          (1800000, 300001, 256, 1300000, 200001)])
+def test_fir_chain_on_every_column_kernel_family(gpu_ctx, L, M, rows, n, K):
     """imp_chain's fused steps live in the column passes: the row maxima in pass C of the deconvolution (short plans,
     power-of-two plans with 64- and 32-column tiles, mixed-radix plans with 64- and 32-column tiles) and the crop in pass A
     of the FIR.  Arbitrary (non-sweep) signals, against the oracle."""
@@ -2075,11 +2080,11 @@ def test_fir_chain_on_every_column_kernel_family(gpu_ctx, L, M, rows):
     from oracle.impulse_response import peak_index
     from oracle.scipy_restated import fft_convolve, hann
     rng = np.random.default_rng(rows)
-    B, n, K, head, fade = 2, 20000, 3000, 48, 400
+    B, head, fade = 2, 48, 400
     h = rng.standard_normal(M) * 1e-3 * np.exp(-np.arange(M) / (M / 8.0))
     h[M // 2] += 1.0
     x = (rng.standard_normal((B, L)) * 1e-4).astype(np.float32)
-    for c, at in enumerate((int(0.37 * L), L - 9000)):              # the second one peaks too close to the end: clamped crop
+    for c, at in enumerate((int(0.37 * L) if n < L // 2 else 4000, L - 9000)):   # the second one peaks too close to the end: clamped crop
         x[c, at] += 1.0
         x[c, at + 211] -= 0.6
         x[c, at - 3000] += 0.05                                     # pre-echo below -18 dB: not the first peak
