@@ -532,7 +532,12 @@ static int launch_cols_any(imp_plan* p, int64_t nchan, Load ld, Store st) {
 static constexpr size_t kRowsLds = sizeof(cf) * 2 * 16 * imp::kRowPad;
 
 static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan, int64_t part = 0) {
-  int rc_attr = ctx_kernel_lds(p->ctx, reinterpret_cast<const void*>(imp::rows_kernel), kRowsLds);
+  // experiment switch: a larger LDS request leaves ONE row pair per CU instead of two
+  static const size_t rows_lds = [] {
+    const char* e = std::getenv("IMPULSE_HIP_ROWS_LDS");
+    return e ? std::max((size_t)std::atoll(e), (size_t)kRowsLds) : (size_t)kRowsLds;
+  }();
+  int rc_attr = ctx_kernel_lds(p->ctx, reinterpret_cast<const void*>(imp::rows_kernel), rows_lds);
   if (rc_attr) return rc_attr;
   imp::RowsArgs a;
   a.ws = p->cur_ws;
@@ -545,7 +550,7 @@ static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan, int64_t p
   imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
   // the XCD-aware work mapping deals pairs in eights: pad, the surplus workgroups exit at once
   dim3 grid((unsigned)(nchan * ((a.npairs + 7) / 8 * 8))), block(512);
-  hipLaunchKernelGGL(imp::rows_kernel, grid, block, kRowsLds, p->cur_stream, a, tw);
+  hipLaunchKernelGGL(imp::rows_kernel, grid, block, rows_lds, p->cur_stream, a, tw);
   HIP_TRY(hipGetLastError());
   return IMP_OK;
 }
