@@ -55,9 +55,19 @@ class _Grid:
 
 
 def _fit_line(x, y):
-    """Least-squares slope/intercept exactly as scipy.stats.linregress forms them."""
-    xm, ym = np.mean(x), np.mean(y)
-    c = np.cov(x, y, bias=1)
+    """Least-squares slope/intercept exactly as scipy.stats.linregress forms them: slope = cov(x, y) / var(x) from
+    np.cov(x, y, bias=1).  The knee search calls this ~20 times per response, so np.cov's own primitive sequence (row
+    means, centring in place, dot(X, X.T.conj()), scaling by the reciprocal count) is issued directly: the same
+    operations on the same layout - bit-identical, a quarter of the call overhead."""
+    n = len(x)
+    X = np.empty((2, n), dtype=np.float64)
+    X[0] = x
+    X[1] = y
+    avg = X.mean(axis=1)
+    xm, ym = avg[0], avg[1]
+    X -= avg[:, None]
+    c = np.dot(X, X.T.conj())
+    c *= np.true_divide(1, n)
     slope = c[0, 1] / c[0, 0]
     return slope, ym - slope * xm
 

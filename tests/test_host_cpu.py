@@ -392,3 +392,21 @@ def test_unique_id_file_rendezvous(tmp_path):
     assert got == {1: want, 2: want, 3: want}
     with pytest.raises(TimeoutError):
         share_unique_id(1, str(tmp_path / "never"), timeout_s=0.05)
+
+
+def test_line_fit_has_the_bits_of_numpy_cov():
+    """decay._fit_line issues np.cov's own primitive sequence directly (the knee search of every response calls it ~20
+    times): slope and intercept must be bit-identical to the np.mean / np.cov(bias=1) form scipy.stats.linregress uses."""
+    from impulse_hip.decay import _fit_line
+    rng = np.random.default_rng(0)
+    for _ in range(3000):
+        n = int(rng.integers(2, 200))
+        x = np.arange(n) * rng.uniform(0.001, 0.1) + rng.uniform(0, 1)
+        y = -rng.uniform(1, 100) * x + rng.standard_normal(n) * rng.uniform(0, 5) - rng.uniform(0, 80)
+        lo = int(rng.integers(0, max(n - 2, 1)))
+        xs, ys = x[lo:], y[lo:]                                  # views, as the search passes them
+        c = np.cov(xs, ys, bias=1)
+        slope = c[0, 1] / c[0, 0]
+        want = (slope, np.mean(ys) - slope * np.mean(xs))
+        got = _fit_line(xs, ys)
+        assert got[0] == want[0] and got[1] == want[1]
