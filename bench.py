@@ -67,6 +67,9 @@ def parse_args(argv=None):
     ap.add_argument("--lanes", type=int, default=3,
                     help="independent launch groups in flight (imp_plan_set_overlap); 1 = strictly serial kernels")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not collect FETCH_SIZE / WRITE_SIZE with rocprofv3 child runs (roofline.traffic then comes from "
+                         "the committed profiles/ summary)")
     ap.add_argument("--event-stride", type=int, default=32,
                     help="bracket the passes of every n-th launch group with HIP events (sampling keeps the "
                          "event records from perturbing the throughput being measured)")
@@ -375,6 +378,50 @@ def load_profile_traffic(workload):
         if t:
             return t, "profiles/" + name
     return None, None
+
+
+def live_pmc_traffic(workload, mpg):
+    """FETCH_SIZE and WRITE_SIZE of the three K1 kernels, collected NOW: two child runs of this very script under
+    `rocprofv3 --pmc` (one counter per pass, as MI355X_MICROARCH.md prescribes; strictly serial launch groups so a
+    counter belongs to one kernel at a time), started after this process has finished its own GPU work.  Returns the
+    same dict as load_profile_traffic, or None when rocprofv3 is missing, this process is itself being profiled, or a
+    child fails - the caller then falls back to the committed summary and says so."""
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof) or any("rocprof" in os.environ.get(k, "").lower()
+                                          for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY")):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    out = tempfile.mkdtemp(prefix="impulse_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(out, counter), "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-pmc", "--lanes", "1", "--no-events", "--input-sets", "4",
+                   "--measurements-per-group", str(mpg)]
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            if res.returncode != 0:
+                sys.stderr.write(f"[bench] rocprofv3 --pmc {counter} child failed (rc {res.returncode}): {res.stderr[-400:]}\n")
+                return None
+        pm = pmc_summary.main(out)
+        keys = ("rows_kernel", "cols_fwd", "cols_inv")
+        if not all(k in pm and "FETCH_SIZE" in pm[k] and "WRITE_SIZE" in pm[k] for k in keys):
+            return None
+        b = lambda k: (2 * pm[k]["FETCH_SIZE"] + pm[k]["WRITE_SIZE"]) * 1024      # noqa: E731 - gfx950: FETCH_SIZE counts half
+        return {"rows_kernel_bytes_per_launch": b("rows_kernel"), "cols_fwd_bytes_per_launch": b("cols_fwd"),
+                "cols_inv_bytes_per_launch": b("cols_inv"), "rows_kernel_fetch_kb_raw": pm["rows_kernel"]["FETCH_SIZE"],
+                "rows_kernel_write_kb": pm["rows_kernel"]["WRITE_SIZE"]}
+    except Exception as exc:                                  # noqa: BLE001 - a reported figure, never fatal
+        sys.stderr.write(f"[bench] live PMC collection failed: {exc!r}\n")
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -716,13 +763,20 @@ def main(argv=None):
             achieved = alg_bytes_per_launch / (avg_ms[dom] * 1e-3) / 1e9
             iso_avg = [m / max(iso_n, 1) for m in iso_ms]
             iso_achieved = alg_bytes_per_launch / (iso_avg[dom] * 1e-3) / 1e9
-            prof, prof_src = load_profile_traffic(args.workload)
+            prof, prof_src, live = None, None, False
+            if world == 1 and not args.no_pmc and not strong:
+                prof = live_pmc_traffic(args.workload, mpg)
+                live = prof is not None
+                prof_src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command, made by this run"
+            if prof is None:
+                prof, prof_src = load_profile_traffic(args.workload)
             roof = dict(bound="hbm", kernel=names[dom], achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS,
                         traffic=(prof or {}).get("rows_kernel_bytes_per_launch"),
+                        traffic_source=("live" if live else "committed summary") if prof else None,
                         traffic_note=(f"L2<->fabric bytes per launch of the dominant kernel (FETCH_SIZE x2 + WRITE_SIZE, "
-                                      f"Infinity-Cache hits INCLUDED, so not HBM bytes) from an earlier rocprofv3 --pmc run of "
-                                      f"this command: {prof_src}") if prof else None,
+                                      f"Infinity-Cache hits INCLUDED, so not HBM bytes); separate --pmc passes, strictly serial "
+                                      f"launch groups; source: {prof_src}") if prof else None,
                         avg_kernel_ms=dict(zip(("pass_a", "pass_b", "pass_c"), avg_ms)),
                         events_sampled=int(launches), launch_groups_in_flight=lanes,
                         note="achieved/frac: algorithmic bytes of one launch group / HIP-event time of the dominant kernel "
@@ -744,9 +798,9 @@ def main(argv=None):
                 rate = moved * groups_per_measurement * n_sets / (elapsed / args.steps) / 1e9
                 roof["l2_fabric_traffic"] = dict(
                     bytes_per_launch_group=moved, rate=rate, unit="GB/s", source=prof_src,
-                    note="bytes passes A+B+C move across the L2<->fabric boundary per launch group (earlier rocprofv3 --pmc "
-                         "run) / this run's time per launch group.  Infinity-Cache hits are counted, so this is a FABRIC "
-                         "rate, not achieved HBM bandwidth; it is not compared with the HBM peak")
+                    note="bytes passes A+B+C move across the L2<->fabric boundary per launch group (rocprofv3 --pmc, see "
+                         "traffic_note) / this run's time per launch group.  Infinity-Cache hits are counted, so this is a "
+                         "FABRIC rate, not achieved HBM bandwidth; it is not compared with the HBM peak")
         cpu = None
         parity = dict(peak_indices_exact=bool(peaks_ok))
         if world == 1 and not args.no_cpu_baseline:

@@ -1432,6 +1432,10 @@ def test_bench_contract_line(gpu_ctx):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
     assert 0 < r["path_frac"] < 1 and 0 < r["isolated"]["frac"] < 1
+    # the counters behind `traffic` are collected by this very run (two rocprofv3 --pmc child runs); the row pass moves
+    # its workspace once each way plus alpha/beta: between 1.2 and 1.7 times the algorithmic bytes of a launch group
+    assert r["traffic_source"] == "live", r["traffic_note"]
+    assert 1.2 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.7
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["sample"]
     assert d["parity"]["peak_indices_exact"] and d["parity"]["spectrum_max_rel_err"] <= 1e-6
