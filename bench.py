@@ -390,8 +390,8 @@ def live_pmc_traffic(workload, mpg):
     import subprocess
     import tempfile
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(rocprof) or any("rocprof" in os.environ.get(k, "").lower()
-                                          for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY")):
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)
+    if not os.path.exists(rocprof) or profiled:
         return None
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_summary
@@ -405,7 +405,7 @@ def live_pmc_traffic(workload, mpg):
                    sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "1",
                    "--no-cpu-baseline", "--no-pmc", "--lanes", "1", "--no-events", "--input-sets", "4",
                    "--measurements-per-group", str(mpg)]
-            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
             if res.returncode != 0:
                 sys.stderr.write(f"[bench] rocprofv3 --pmc {counter} child failed (rc {res.returncode}): {res.stderr[-400:]}\n")
                 return None
