@@ -47,7 +47,7 @@ WORKLOADS = {
 }
 # channels per launch group when groups overlap on 3 lanes (measured sweeps): the
 # groups in flight together must still fit the 256 MiB Infinity Cache with their inputs and outputs
-GROUP_CHANNELS = {"c2": 32, "c3": 9, "c4": 8, "c5": 8}
+GROUP_CHANNELS = {"c2": 32, "c3": 13, "c4": 8, "c5": 8}
 # Resident measurements that travel through K1 as ONE launch group (their rows are contiguous in HBM).  At C2 two 7.1
 # measurements = 32 channels per group: with three groups in flight the workspaces (96 x 2.2 MB) still fit the 256 MiB
 # Infinity Cache, and every launch carries twice the workgroups (tools/k1_rate.py: 16 ch x 3 lanes 413 k, 32 x 3 443 k,
@@ -670,7 +670,8 @@ def main(argv=None):
     M = len(est)
 
     ctx = Context(dev_index)
-    # C2: a resident block (mpg measurements) is one launch group; C3 cuts its 26 channels into groups of 9
+    # C2: a resident block (mpg measurements) is one launch group; C3 cuts its 26 channels into two groups of 13
+    # (tools/k1_rate.py at C3's sizes: 9 ch x 3 lanes 185 k, 13 x 3 198 k, 26 x 2 204 k IR/s)
     group_channels = B if args.workload == "c2" else GROUP_CHANNELS[args.workload]
     ws_channels = args.ws_channels or max(1, args.lanes) * group_channels
     if rank == 0:
@@ -818,7 +819,7 @@ def main(argv=None):
                           whole_column_spectrum_max_rel_err=max(errs_full),
                           whole_column_meets_1e_6=bool(max(errs_full) <= 1e-6),
                           whole_column_pocketfft_fp32_err=floor,
-                          whole_column_note="un-cropped 391 270-sample column: above 1e-6 for every fp32 transform (the "
+                          whole_column_note=f"un-cropped {L}-sample column: above 1e-6 for every fp32 transform (the "
                                             "reference's own pocketfft in single precision is listed beside it); reported, "
                                             "not gated",
                           channels_checked=len(errs))

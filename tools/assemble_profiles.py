@@ -12,7 +12,7 @@ sys.path.insert(0, HERE)
 import pmc_summary  # noqa: E402
 import profile_summary  # noqa: E402
 
-GROUPS = {"c2": "32 channels (two 7.1 measurements) at circular length 540672", "c3": "9 channels at circular length 1179648",
+GROUPS = {"c2": "32 channels (two 7.1 measurements) at circular length 540672", "c3": "13 channels at circular length 1179648",
           "c5": "8 channels at circular length 1572864"}
 
 
