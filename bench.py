@@ -524,8 +524,10 @@ def strong_block(args, torch, dist, device, comm_device, ctx, rank, world, backe
     total = args.strong_channels
     est = make_estimator("c5")
     M = len(est)
-    grp = GROUP_CHANNELS["c5"]
-    lanes = max(1, min(args.lanes, 4))
+    # launch groups of 12 channels on two lanes: 24 workspaces of 6.3 MB in flight (tools/k1_rate.py at 2^20 x 2^20:
+    # 8 ch x 3 lanes 132 k, 12 x 2 139 k, 12 x 3 126 k, 16 x 2 136 k IR/s)
+    grp = 12
+    lanes = max(1, min(args.lanes, 2))
     if rank == 0:
         plan = ConvPlan(ctx, np.asarray(est.inverse_filter, dtype=np.float64), M, "same", ws_channels=lanes * grp)
     else:
@@ -533,6 +535,7 @@ def strong_block(args, torch, dist, device, comm_device, ctx, rank, world, backe
     bcast = 0
     if dist is not None:
         bcast = spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world, "c5")
+    plan.set_overlap(lanes)
     base, L, pitch, dl = synth_recordings(est, 64, seed0=0xC5, column=M)
     d_base = torch.from_numpy(base).to(device)
 
