@@ -80,7 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--strong", action="store_true", help="add the strong_c5 block at N = 1 too")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong_c5 block at N > 1")
     ap.add_argument("--strong-channels", type=int, default=1024)
-    ap.add_argument("--strong-passes", type=int, default=4)
+    ap.add_argument("--strong-passes", type=int, default=8)
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launcher/collective rehearsal WITHOUT a GPU: ranks rendezvous over gloo, shard, broadcast "
                          "a dummy spectrum and reduce a clock; no compute, value = null (CPU test of the N > 1 plumbing)")
