@@ -16,9 +16,10 @@
 // input (tests/test_oracle_golden.py).  In fp32 that bin would be 1e-7 noise and the taps would move
 // by ~1e-4.  The work is tiny (4 transforms of 19 200/38 400 points + one of 2^16/2^17 per channel),
 // so it is laid out for simplicity: a batched Stockham autosort FFT, one launch per radix pass
-// (radix 4/2/3/5, generic O(R^2) butterflies with exact table twiddles), ping-ponging two global
+// (radix 4/2/3/5/11, generic O(R^2) butterflies with exact table twiddles), ping-ponging two global
 // buffers, and a few elementwise kernels.  HBM-bound streaming passes; no LDS, no MFMA.
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <utility>
 
@@ -49,13 +50,18 @@ __global__ __launch_bounds__(256) void stockham_pass(const cdbl* __restrict__ x,
   for (int k = 0; k < R; ++k) a[k] = x[base + q + (long long)s * (p + k * m)];
   const int step_r = N / R;        // w_R = roots[step_r]
   const int step_n = N / n;        // w_n = roots[step_n]
+  cdbl wr[R];                      // the R-th roots once per thread; (j k) % R is a compile-time index below
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    wr[k] = roots[k * step_r];
+    if (dir > 0) wr[k].y = -wr[k].y;
+  }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     cdbl acc = a[0];
 #pragma unroll
     for (int k = 1; k < R; ++k) {
-      cdbl w = roots[((j * k) % R) * step_r];
-      if (dir > 0) w.y = -w.y;
+      const cdbl w = wr[(j * k) % R];
       const cdbl t = zmul(a[k], w);
       acc.x += t.x;
       acc.y += t.y;
@@ -209,6 +215,16 @@ __global__ __launch_bounds__(256) void bluestein_post_db(const cdbl* __restrict_
 
 std::vector<int> factorise(int n) {
   std::vector<int> f;
+  // Every pass is one launch at the launch floor (~6 us at these sizes), so radix 8 / 16 passes were tried
+  // (IMPULSE_HIP_FFT_MAX_RADIX=8|16): the slice's normalisation gets 0.3 ms faster (two rows of 131 072 points), the
+  // per-channel filter spectra of K5 0.4 ms slower (16 rows of 32 768: the O(R^2) butterfly of radix 16 needs 256 VGPRs),
+  // the whole slice 5.2 -> 5.3-5.5 ms.  Radix 4 stays the default.
+  static const int max_radix = [] {
+    const char* e = std::getenv("IMPULSE_HIP_FFT_MAX_RADIX");
+    return e ? std::atoi(e) : 4;
+  }();
+  while (max_radix >= 16 && n % 16 == 0) { f.push_back(16); n /= 16; }
+  while (max_radix >= 8 && n % 8 == 0) { f.push_back(8); n /= 8; }
   while (n % 4 == 0) { f.push_back(4); n /= 4; }
   while (n % 2 == 0) { f.push_back(2); n /= 2; }
   while (n % 3 == 0) { f.push_back(3); n /= 3; }
@@ -274,6 +290,8 @@ static int run_fft(imp_ctx* ctx, const std::vector<int>& fac, const cdbl* roots,
     const int threads = N / r;
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)B), block(256);
     switch (r) {
+      case 16: hipLaunchKernelGGL(stockham_pass<16>, grid, block, 0, ctx->stream, *cur, *other, roots, N, n, s, dir); break;
+      case 8: hipLaunchKernelGGL(stockham_pass<8>, grid, block, 0, ctx->stream, *cur, *other, roots, N, n, s, dir); break;
       case 4: hipLaunchKernelGGL(stockham_pass<4>, grid, block, 0, ctx->stream, *cur, *other, roots, N, n, s, dir); break;
       case 2: hipLaunchKernelGGL(stockham_pass<2>, grid, block, 0, ctx->stream, *cur, *other, roots, N, n, s, dir); break;
       case 3: hipLaunchKernelGGL(stockham_pass<3>, grid, block, 0, ctx->stream, *cur, *other, roots, N, n, s, dir); break;

@@ -66,3 +66,5 @@ tot = sum(acc.values())
 for k, v in acc.items():
     print(f"{k:40s} {v / reps * 1e3:7.3f} ms")
 print(f"{'total':40s} {tot / reps * 1e3:7.3f} ms")
+from impulse_hip.impulse_response import _k5_plans  # noqa: E402
+print("K5 plan shapes (ctx, n, taps, channels):", [k[1:] for k in _k5_plans.plans])
