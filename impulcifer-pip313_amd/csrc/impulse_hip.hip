@@ -223,13 +223,11 @@ static void pool_release(imp_ctx* ctx) {
   ctx->free_bytes = 0;
 }
 
-extern "C" int imp_malloc(imp_ctx* ctx, size_t bytes, void** dptr) {
-  if (!ctx || !dptr) return fail(IMP_ERR_INVALID, "imp_malloc: null argument");
-  IMP_CTX_LOCK(ctx);
-  int rc = ctx_bind(ctx);
-  if (rc) return rc;
+// pooled device blocks: imp_malloc / imp_free and the library's own short-lived buffers (filter-spectrum work arrays,
+// segment sets) share one pool per context
+int ctx_block_get(imp_ctx* ctx, size_t bytes, void** dptr) {
   *dptr = nullptr;
-  if (bytes == 0) return IMP_OK;
+  if (bytes == 0) bytes = 1;
   // a kept block of this size, or up to a quarter larger
   auto it = ctx->free_blocks.lower_bound(bytes);
   if (it != ctx->free_blocks.end() && it->first <= bytes + bytes / 4) {
@@ -245,9 +243,39 @@ extern "C" int imp_malloc(imp_ctx* ctx, size_t bytes, void** dptr) {
     pool_release(ctx);
     e = hipMalloc(dptr, bytes);
   }
-  if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *dptr = nullptr;
+    return fail(IMP_ERR_ALLOC, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+  }
   ctx->live_blocks[*dptr] = bytes;
   return IMP_OK;
+}
+
+// the caller guarantees that nothing in flight still uses the block; returns false for a foreign pointer
+bool ctx_block_put(imp_ctx* ctx, void* dptr) {
+  if (!dptr) return true;
+  auto it = ctx->live_blocks.find(dptr);
+  if (it == ctx->live_blocks.end()) return false;
+  const size_t bytes = it->second;
+  ctx->live_blocks.erase(it);
+  if (ctx->free_bytes + bytes <= ctx->free_cap) {
+    ctx->free_blocks.emplace(bytes, dptr);
+    ctx->free_bytes += bytes;
+  } else {
+    (void)hipFree(dptr);
+  }
+  return true;
+}
+
+extern "C" int imp_malloc(imp_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) return fail(IMP_ERR_INVALID, "imp_malloc: null argument");
+  IMP_CTX_LOCK(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  *dptr = nullptr;
+  if (bytes == 0) return IMP_OK;
+  return ctx_block_get(ctx, bytes, dptr);
 }
 
 extern "C" int imp_free(imp_ctx* ctx, void* dptr) {
@@ -259,16 +287,7 @@ extern "C" int imp_free(imp_ctx* ctx, void* dptr) {
   // nothing in flight may still use the block, whoever gets it next (hipFree would have drained the device too)
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   for (auto st : ctx->side_streams) HIP_TRY(hipStreamSynchronize(st));
-  auto it = ctx->live_blocks.find(dptr);
-  if (it == ctx->live_blocks.end()) return fail(IMP_ERR_INVALID, "imp_free: %p did not come from imp_malloc on this context", dptr);
-  const size_t bytes = it->second;
-  ctx->live_blocks.erase(it);
-  if (ctx->free_bytes + bytes <= ctx->free_cap) {
-    ctx->free_blocks.emplace(bytes, dptr);
-    ctx->free_bytes += bytes;
-    return IMP_OK;
-  }
-  HIP_TRY(hipFree(dptr));
+  if (!ctx_block_put(ctx, dptr)) return fail(IMP_ERR_INVALID, "imp_free: %p did not come from imp_malloc on this context", dptr);
   return IMP_OK;
 }
 
@@ -1471,9 +1490,9 @@ extern "C" void imp_segset_destroy(imp_segset* s) {
   IMP_CTX_LOCK(s->ctx);
   (void)hipSetDevice(s->ctx->device);
   (void)hipStreamSynchronize(s->ctx->stream);
-  (void)hipFree(s->e);
-  (void)hipFree(s->off);
-  (void)hipFree(s->qbuf);
+  (void)ctx_block_put(s->ctx, s->e);
+  (void)ctx_block_put(s->ctx, s->off);
+  (void)ctx_block_put(s->ctx, s->qbuf);
   delete s;
 }
 
@@ -1500,17 +1519,17 @@ extern "C" int imp_segset_create(imp_ctx* ctx, const double* x, const int64_t* o
   unsigned long long* d_max = nullptr;
   auto bail = [&](int code) {
     (void)hipStreamSynchronize(st);
-    (void)hipFree(d_max);
+    (void)ctx_block_put(ctx, d_max);
     imp_segset_destroy(s);
     return code;
   };
-  if (hipMalloc((void**)&s->e, (size_t)std::max<int64_t>(total, 1) * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&s->off, (size_t)std::max<int64_t>(2 * B, 1) * sizeof(int64_t)) != hipSuccess ||
-      hipMalloc((void**)&d_max, (size_t)std::max<int64_t>(B, 1) * sizeof(unsigned long long)) != hipSuccess)
+  if (ctx_block_get(ctx, (size_t)std::max<int64_t>(total, 1) * sizeof(double), (void**)&s->e) ||
+      ctx_block_get(ctx, (size_t)std::max<int64_t>(2 * B, 1) * sizeof(int64_t), (void**)&s->off) ||
+      ctx_block_get(ctx, (size_t)std::max<int64_t>(B, 1) * sizeof(unsigned long long), (void**)&d_max))
     return bail(fail(IMP_ERR_ALLOC, "imp_segset_create: device allocation of %lld samples failed", (long long)total));
   s->len = s->off + B;
   if (B == 0 || total == 0) {
-    (void)hipFree(d_max);
+    (void)ctx_block_put(ctx, d_max);
     *out = s;
     if (maxabs_out)
       for (int64_t b = 0; b < B; ++b) maxabs_out[b] = 0.0;
@@ -1530,7 +1549,7 @@ extern "C" int imp_segset_create(imp_ctx* ctx, const double* x, const int64_t* o
   if (hipMemcpyAsync(h.data(), d_max, (size_t)B * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)
     return bail(fail(IMP_ERR_HIP, "imp_segset_create: readback failed"));
-  (void)hipFree(d_max);
+  (void)ctx_block_put(ctx, d_max);
   d_max = nullptr;
   if (maxabs_out)
     for (int64_t b = 0; b < B; ++b) std::memcpy(&maxabs_out[b], &h[(size_t)b], sizeof(double));
@@ -1564,20 +1583,20 @@ extern "C" int imp_segset_create_device(imp_ctx* ctx, const float* d_x, const in
   int64_t* d_src_off = nullptr;
   auto bail = [&](int code) {
     (void)hipStreamSynchronize(st);
-    (void)hipFree(d_max);
-    (void)hipFree(d_src_off);
+    (void)ctx_block_put(ctx, d_max);
+    (void)ctx_block_put(ctx, d_src_off);
     imp_segset_destroy(s);
     return code;
   };
-  if (hipMalloc((void**)&s->e, (size_t)std::max<int64_t>(total, 1) * sizeof(double)) != hipSuccess ||
-      hipMalloc((void**)&s->off, (size_t)std::max<int64_t>(2 * B, 1) * sizeof(int64_t)) != hipSuccess ||
-      hipMalloc((void**)&d_src_off, (size_t)std::max<int64_t>(B, 1) * sizeof(int64_t)) != hipSuccess ||
-      hipMalloc((void**)&d_max, (size_t)std::max<int64_t>(B, 1) * sizeof(unsigned long long)) != hipSuccess)
+  if (ctx_block_get(ctx, (size_t)std::max<int64_t>(total, 1) * sizeof(double), (void**)&s->e) ||
+      ctx_block_get(ctx, (size_t)std::max<int64_t>(2 * B, 1) * sizeof(int64_t), (void**)&s->off) ||
+      ctx_block_get(ctx, (size_t)std::max<int64_t>(B, 1) * sizeof(int64_t), (void**)&d_src_off) ||
+      ctx_block_get(ctx, (size_t)std::max<int64_t>(B, 1) * sizeof(unsigned long long), (void**)&d_max))
     return bail(fail(IMP_ERR_ALLOC, "imp_segset_create_device: device allocation of %lld samples failed", (long long)total));
   s->len = s->off + B;
   if (B == 0 || total == 0) {
-    (void)hipFree(d_max);
-    (void)hipFree(d_src_off);
+    (void)ctx_block_put(ctx, d_max);
+    (void)ctx_block_put(ctx, d_src_off);
     *out = s;
     if (maxabs_out)
       for (int64_t b = 0; b < B; ++b) maxabs_out[b] = 0.0;
@@ -1598,8 +1617,8 @@ extern "C" int imp_segset_create_device(imp_ctx* ctx, const float* d_x, const in
   if (hipMemcpyAsync(h.data(), d_max, (size_t)B * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)
     return bail(fail(IMP_ERR_HIP, "imp_segset_create_device: readback failed"));
-  (void)hipFree(d_max);
-  (void)hipFree(d_src_off);
+  (void)ctx_block_put(ctx, d_max);
+  (void)ctx_block_put(ctx, d_src_off);
   if (maxabs_out)
     for (int64_t b = 0; b < B; ++b) std::memcpy(&maxabs_out[b], &h[(size_t)b], sizeof(double));
   *out = s;
@@ -1624,11 +1643,12 @@ extern "C" int imp_segset_range_means(imp_segset* s, const int64_t* q_seg, const
   hipStream_t st = s->ctx->stream;
   const size_t need = (size_t)Q * (3 * sizeof(int64_t) + sizeof(double));
   if (s->qcap < need) {
-    (void)hipFree(s->qbuf);
+    (void)hipStreamSynchronize(st);
+    (void)ctx_block_put(s->ctx, s->qbuf);
     s->qbuf = nullptr;
     s->qcap = 0;
     const size_t want = std::max(need, (size_t)1 << 16);
-    HIP_TRY(hipMalloc(&s->qbuf, want));
+    if (ctx_block_get(s->ctx, want, &s->qbuf)) return IMP_ERR_ALLOC;
     s->qcap = want;
   }
   int64_t* d_seg = (int64_t*)s->qbuf;

@@ -66,6 +66,11 @@ struct imp_ctx {
   size_t free_cap = (size_t)2 << 30;            // IMPULSE_HIP_POOL_MB
 };
 
+// pooled device blocks (impulse_hip.hip): get = IMP_OK or IMP_ERR_ALLOC with the message set; put = hand back a block
+// nothing in flight uses any more (false: not a block of this context's pool)
+int ctx_block_get(imp_ctx* ctx, size_t bytes, void** dptr);
+bool ctx_block_put(imp_ctx* ctx, void* dptr);
+
 // opt a kernel into `bytes` of dynamic LDS on the context's device, once per context
 int ctx_kernel_lds(imp_ctx* ctx, const void* kernel, size_t bytes);
 

@@ -571,7 +571,7 @@ static int magnitude_db_core(imp_ctx* ctx, const double* x, const float* d_rows,
   } else {
     int64_t* d_meta = nullptr;
     const size_t meta = (size_t)n_rows * sizeof(int64_t);
-    HIP_TRY(hipMalloc((void**)&d_meta, 3 * meta));
+    if (ctx_block_get(ctx, 3 * meta, (void**)&d_meta)) return IMP_ERR_ALLOC;
     hipError_t e1 = hipMemcpyAsync(d_meta, off, meta, hipMemcpyHostToDevice, s);
     hipError_t e2 = hipMemcpyAsync(d_meta + n_rows, len, meta, hipMemcpyHostToDevice, s);
     hipError_t e3 = hipMemcpyAsync(d_meta + 2 * n_rows, group, meta, hipMemcpyHostToDevice, s);
@@ -580,7 +580,7 @@ static int magnitude_db_core(imp_ctx* ctx, const double* x, const float* d_rows,
                          dim3(256), 0, s, d_rows, d_meta, d_meta + n_rows, d_meta + 2 * n_rows, (int)n_rows, p->x, n);
     hipError_t e4 = hipGetLastError();
     (void)hipStreamSynchronize(s);
-    (void)hipFree(d_meta);
+    (void)ctx_block_put(ctx, d_meta);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess)
       return fail(IMP_ERR_HIP, "imp_magnitude_db_sum_device: row sum failed");
   }
@@ -699,14 +699,14 @@ int spectrum_alpha_beta_device(imp_ctx* ctx, const double* filters, int64_t M, i
   double* d_h = nullptr;
   auto cleanup = [&](int code) {
     (void)hipStreamSynchronize(s);
-    (void)hipFree(a);
-    (void)hipFree(b);
-    (void)hipFree(d_h);
+    (void)ctx_block_put(ctx, a);
+    (void)ctx_block_put(ctx, b);
+    (void)ctx_block_put(ctx, d_h);
     return code;
   };
-  if (hipMalloc((void**)&a, (size_t)chunk * Nc * sizeof(cdbl)) != hipSuccess ||
-      hipMalloc((void**)&b, (size_t)chunk * Nc * sizeof(cdbl)) != hipSuccess ||
-      hipMalloc((void**)&d_h, (size_t)chunk * M * sizeof(double)) != hipSuccess)
+  if (ctx_block_get(ctx, (size_t)chunk * Nc * sizeof(cdbl), (void**)&a) ||
+      ctx_block_get(ctx, (size_t)chunk * Nc * sizeof(cdbl), (void**)&b) ||
+      ctx_block_get(ctx, (size_t)chunk * M * sizeof(double), (void**)&d_h))
     return cleanup(fail(IMP_ERR_ALLOC, "device buffers for the filter spectra (%lld filters of %lld points)",
                         (long long)chunk, (long long)Nc));
   for (int64_t f0 = 0; f0 < n_filters; f0 += chunk) {
