@@ -1349,17 +1349,17 @@ extern "C" int imp_peak_index(imp_ctx* ctx, const float* x, const int64_t* off, 
   if (rc) return rc;
   float* d_x = nullptr;
   if (total > 0) {
-    hipError_t e = hipMalloc((void**)&d_x, (size_t)total * sizeof(float));
-    if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(%lld floats): %s", (long long)total, hipGetErrorString(e));
-    e = hipMemcpyAsync(d_x, x, (size_t)total * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if ((rc = ctx_block_get(ctx, (size_t)total * sizeof(float), (void**)&d_x))) return rc;
+    hipError_t e = hipMemcpyAsync(d_x, x, (size_t)total * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) {
-      (void)hipFree(d_x);
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)ctx_block_put(ctx, d_x);
       return fail(IMP_ERR_HIP, "h2d: %s", hipGetErrorString(e));
     }
   }
   rc = peak_index_impl(ctx, d_x, off, len, B, peak_height, idx_out, maxabs_out);
   (void)hipStreamSynchronize(ctx->stream);
-  if (d_x) (void)hipFree(d_x);
+  (void)ctx_block_put(ctx, d_x);
   return rc;
 }
 
@@ -1824,11 +1824,10 @@ extern "C" int imp_apply_window(imp_ctx* ctx, float* x, const int64_t* off, cons
   if (rc) return rc;
   hipStream_t s = ctx->stream;
   float* d_x = nullptr;
-  hipError_t e = hipMalloc((void**)&d_x, (size_t)total * sizeof(float));
-  if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc: %s", hipGetErrorString(e));
+  if ((rc = ctx_block_get(ctx, (size_t)total * sizeof(float), (void**)&d_x))) return rc;
   auto cleanup = [&](int code) {
     (void)hipStreamSynchronize(s);
-    (void)hipFree(d_x);
+    (void)ctx_block_put(ctx, d_x);
     return code;
   };
   const size_t meta = (size_t)B * sizeof(int64_t);
@@ -1914,14 +1913,14 @@ extern "C" int imp_rows_to_pcm_device(imp_ctx* ctx, const float* d_rows, const i
   const size_t out_bytes = (size_t)n_frames * (size_t)n_tracks * sample;
   const size_t meta = (size_t)(2 * std::max<int64_t>(n_rows, 1) + n_tracks) * sizeof(int64_t);
   char* d_buf = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_buf, meta + out_bytes));
+  if ((rc = ctx_block_get(ctx, meta + out_bytes, (void**)&d_buf))) return rc;
   int64_t* d_off = (int64_t*)d_buf;
   int64_t* d_len = d_off + std::max<int64_t>(n_rows, 1);
   int64_t* d_map = d_len + std::max<int64_t>(n_rows, 1);
   void* d_out = d_buf + meta;
   auto done = [&](int code) {
     (void)hipStreamSynchronize(s);
-    (void)hipFree(d_buf);
+    (void)ctx_block_put(ctx, d_buf);
     return code;
   };
   if ((n_rows && (hipMemcpyAsync(d_off, off, (size_t)n_rows * sizeof(int64_t), hipMemcpyHostToDevice, s) != hipSuccess ||
