@@ -476,12 +476,15 @@ class SegSet:
     def range_means(self, queries):
         """queries: iterable of (segment, a, b) with 0 <= a <= b <= len(segment).  Returns float64 means."""
         q = np.asarray(list(queries), dtype=np.int64).reshape(-1, 3)
-        out = np.zeros(len(q), dtype=np.float64)
-        if len(q) == 0:
-            return out
-        seg, a, b = (np.ascontiguousarray(q[:, i]) for i in range(3))
-        _check(self._lib.imp_segset_range_means(self._h, _ptr_i64(seg), _ptr_i64(a), _ptr_i64(b), len(q),
-                                                out.ctypes.data_as(_pd)))
+        return self.range_means_arrays(q[:, 0], q[:, 1], q[:, 2])
+
+    def range_means_arrays(self, seg, a, b):
+        """np.mean(e[seg[i]][a[i]:b[i]]) for every i (three equally long integer arrays)."""
+        seg, a, b = (np.ascontiguousarray(v, dtype=np.int64) for v in (seg, a, b))
+        out = np.zeros(len(seg), dtype=np.float64)
+        if len(seg):
+            _check(self._lib.imp_segset_range_means(self._h, _ptr_i64(seg), _ptr_i64(a), _ptr_i64(b), len(seg),
+                                                    out.ctypes.data_as(_pd)))
         return out
 
     def close(self):

@@ -81,20 +81,28 @@ def _db(mean):
     return 10 * np.log10(np.maximum(mean, EPSILON))
 
 
+def _ranges(a, b):
+    return np.asarray(a, dtype=np.int64), np.asarray(b, dtype=np.int64)
+
+
 def _lundeby(n_sq, fs):
     """The Lundeby knee search of core/decay.py:103-253 as a coroutine over the squared, peak-normalised
-    segment of n_sq samples: it yields lists of (a, b) ranges and is sent np.mean(sq[a:b]) for each
-    (device K7, NumPy's summation order); everything else is scalar control flow on <= ~200 window levels.
+    segment of n_sq samples: it yields the ranges it needs as a pair of int64 arrays (a, b) and is sent
+    np.mean(sq[a:b]) for each (device K7, NumPy's summation order); everything else is scalar control flow on a few
+    hundred window levels.
     Returns (knee offset in samples, noise floor dB, window size)."""
     grid = _Grid(n_sq, fs)
     wd = 0.03
     n = int(n_sq / fs / wd) if fs > 0 else 0
     if n == 0:
-        (whole,) = yield [(0, n_sq)]
+        (whole,) = yield _ranges([0], [n_sq])
         return n_sq, float(_db(whole)), max(1, n_sq)
     w0 = max(int(n_sq / n), 1)
     tail_from = int(n_sq * 0.9)
-    means = yield [(i * w0, (i + 1) * w0) for i in range(n)] + [(tail_from, n_sq) if tail_from < n_sq else (0, n_sq)]
+    starts = np.arange(n + 1, dtype=np.int64) * w0               # n windows of w0 samples, then the noise tail
+    ends = starts + w0
+    starts[n], ends[n] = (tail_from, n_sq) if tail_from < n_sq else (0, n_sq)
+    means = yield starts, ends
     levels, floor = _db(np.asarray(means[:n])), float(_db(means[n]))
     t_win = np.arange(n) * wd + wd / 2
 
@@ -116,7 +124,8 @@ def _lundeby(n_sq, fs):
     n = int(n_sq / fs / wd) if (fs > 0 and wd > EPSILON) else 1
     n = max(n, 1)
     w = max(int(n_sq / n), 1)
-    means = yield [(i * w, (i + 1) * w) for i in range(n)]
+    starts = np.arange(n, dtype=np.int64) * w
+    means = yield starts, starts + w
     levels = _db(np.asarray(means))
     t_win = np.arange(n) * wd + wd / 2
 
@@ -139,7 +148,7 @@ def _lundeby(n_sq, fs):
         a, b = grid.nearest(t0), grid.nearest(min(t0 + knee_time, total))
         if a >= b:
             break
-        (m,) = yield [(a, b)]
+        (m,) = yield _ranges([a], [b])
         floor = float(_db(m))
         hi = _first_le(levels, floor + 8)
         lo = _first_le(levels, floor + 28)
@@ -196,12 +205,13 @@ def _knee_searches(ctx, lengths, peaks, segset_for, fs):
             pending[k] = next(gen)                         # every search asks at least one question
         while pending:
             order = list(pending)
-            queries = [(runs[k][0], a, b) for k in order for (a, b) in pending[k]]
-            means = segset.range_means(queries)
+            seg = np.concatenate([np.full(len(pending[k][0]), runs[k][0], dtype=np.int64) for k in order])
+            means = segset.range_means_arrays(seg, np.concatenate([pending[k][0] for k in order]),
+                                              np.concatenate([pending[k][1] for k in order]))
             pos = 0
             nxt = {}
             for k in order:
-                cnt = len(pending[k])
+                cnt = len(pending[k][0])
                 try:
                     nxt[k] = runs[k][1].send(means[pos:pos + cnt])
                 except StopIteration as done:
