@@ -405,7 +405,7 @@ def live_pmc_traffic(workload, mpg):
                    sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "1",
                    "--no-cpu-baseline", "--no-pmc", "--lanes", "1", "--no-events", "--input-sets", "4",
                    "--measurements-per-group", str(mpg)]
-            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=60)
             if res.returncode != 0:
                 sys.stderr.write(f"[bench] rocprofv3 --pmc {counter} child failed (rc {res.returncode}): {res.stderr[-400:]}\n")
                 return None
