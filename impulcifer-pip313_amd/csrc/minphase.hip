@@ -16,7 +16,7 @@
 // input (tests/test_oracle_golden.py).  In fp32 that bin would be 1e-7 noise and the taps would move
 // by ~1e-4.  The work is tiny (4 transforms of 19 200/38 400 points + one of 2^16/2^17 per channel),
 // so it is laid out for simplicity: a batched Stockham autosort FFT, one launch per radix pass
-// (radix 4/2/3/5/11, generic O(R^2) butterflies with exact table twiddles), ping-ponging two global
+// (radix 8/4/2/3/5/11, generic O(R^2) butterflies with exact table twiddles), ping-ponging two global
 // buffers, and a few elementwise kernels.  HBM-bound streaming passes; no LDS, no MFMA.
 #include <cmath>
 #include <cstdlib>
@@ -215,13 +215,12 @@ __global__ __launch_bounds__(256) void bluestein_post_db(const cdbl* __restrict_
 
 std::vector<int> factorise(int n) {
   std::vector<int> f;
-  // Every pass is one launch at the launch floor (~6 us at these sizes), so radix 8 / 16 passes were tried
-  // (IMPULSE_HIP_FFT_MAX_RADIX=8|16): the slice's normalisation gets 0.3 ms faster (two rows of 131 072 points), the
-  // per-channel filter spectra of K5 0.4 ms slower (16 rows of 32 768: the O(R^2) butterfly of radix 16 needs 256 VGPRs),
-  // the whole slice 5.2 -> 5.3-5.5 ms.  Radix 4 stays the default.
+  // Every pass is one launch at the launch floor (~6 us at these sizes): radix 8 passes shorten the power-of-two part
+  // (78 VGPRs; the O(R^2) butterfly of radix 16 needs 256 and gains nothing more).  Whole slice, radix 4 / 8 / 16:
+  // 3.47 / 3.38 / 3.45 ms.  IMPULSE_HIP_FFT_MAX_RADIX overrides.
   static const int max_radix = [] {
     const char* e = std::getenv("IMPULSE_HIP_FFT_MAX_RADIX");
-    return e ? std::atoi(e) : 4;
+    return e ? std::atoi(e) : 8;
   }();
   while (max_radix >= 16 && n % 16 == 0) { f.push_back(16); n /= 16; }
   while (max_radix >= 8 && n % 8 == 0) { f.push_back(8); n /= 8; }
