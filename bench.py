@@ -397,8 +397,8 @@ def live_pmc_traffic(workload, mpg):
     import pmc_summary
     out = tempfile.mkdtemp(prefix="impulse_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
-        env.pop(k, None)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "IMPULSE_BENCH_FORCE_DIST"):
+        env.pop(k, None)                                     # the children are plain single-process runs
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(out, counter), "-o", "p", "--",
