@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 PITCH_ALIGN = int(os.environ.get("IMPULSE_BENCH_PITCH_ALIGN", "64"))     # samples
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BROADCAST_VIA = None           # set when the in-library RCCL broadcast had to be replaced
 METRIC = "impulse responses/sec (sweep deconv+FIR), 7.1×2-ear @48kHz, 1/2/4/8 GPU"
 
 WORKLOADS = {
@@ -468,7 +469,22 @@ def spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world, tag
     from impulse_hip._native import comm_unique_id
     box = [comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
-    n = broadcast_plan_spectrum_rccl(plan, ctx, rank, world, unique_id=box[0])
+    n, err = 0, None
+    try:
+        if os.environ.get("IMPULSE_BENCH_FAIL_LIB_BCAST") == "1":           # rehearsal of the fallback below
+            raise RuntimeError("IMPULSE_BENCH_FAIL_LIB_BCAST")
+        n = broadcast_plan_spectrum_rccl(plan, ctx, rank, world, unique_id=box[0])
+    except Exception as exc:                                  # noqa: BLE001 - agreed on below, then reported
+        err = repr(exc)
+    # every rank must take the same road: if the library's communicator failed anywhere (librccl not loadable, say),
+    # all ranks repeat the broadcast through the launcher's process group and the line says so
+    flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        sys.stderr.write(f"[bench] rank {rank}: in-library RCCL broadcast failed ({err}); using torch.distributed\n")
+        global BROADCAST_VIA
+        BROADCAST_VIA = "torch.distributed (the library's own RCCL communicator failed: see stderr)"
+        return broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0, via_host=False)
     dist.barrier()
     return n
 
@@ -862,7 +878,7 @@ def main(argv=None):
                                  f"{wl.skew} samples into 256-byte aligned buffers so the cropped stores fall on cache lines",
                        "nfft": nfft, "launch_groups_in_flight": lanes, "workspace_channels": plan_ws,
                        "sharding": (f"channels x{world}, no data-path collective; "
-                                    f"one {'RCCL (by libimpulse_hip, no torch in the data path)' if backend == 'nccl' else backend + ' (rehearsal)'} broadcast of "
+                                    f"one {(BROADCAST_VIA or 'RCCL (by libimpulse_hip, no torch in the data path)') if backend == 'nccl' else backend + ' (rehearsal)'} broadcast of "
                                     f"{bcast_bytes} B spectrum at plan creation") if dist is not None else
                                    "single rank: no collective"},
             "roofline": roof, "cpu_baseline": cpu, "parity": parity, "slice": whole_slice, "deconv_fir": fir_leg,
