@@ -629,6 +629,8 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args, argv)
 
+    # the host driver only supports dmabuf IPC: RCCL between processes needs this before anything initialises HIP
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
