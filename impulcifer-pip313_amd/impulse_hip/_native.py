@@ -747,11 +747,7 @@ class ConvPlan:
         d_out = ctx.malloc(max(1, len(column_starts) * tracks) * pitch * 4)
         try:
             ctx.h2d(d_in, frames)
-            for j, s0 in enumerate(column_starts):
-                if s0 < 0 or s0 + self.L > n_frames:
-                    raise ValueError("column outside the recording")
-                self.execute_device_pcm(d_in + s0 * tracks * frames.itemsize, bits, tracks, 1, tracks,
-                                        d_out + j * tracks * pitch * 4, pitch)
+            self._launch_pcm_columns(d_in, frames, column_starts, d_out, pitch)
             ctx.synchronize()
             out = np.empty((len(column_starts), tracks, pitch), dtype=np.float32)
             ctx.d2h(out, d_out)
@@ -772,13 +768,28 @@ class ConvPlan:
         d_in = ctx.malloc(frames.nbytes)
         try:
             ctx.h2d(d_in, frames)
-            for j, s0 in enumerate(column_starts):
-                if s0 < 0 or s0 + self.L > n_frames:
-                    raise ValueError("column outside the recording")
-                self.execute_device_pcm(d_in + s0 * tracks * frames.itemsize, bits, tracks, 1, tracks,
-                                        d_out + j * tracks * pitch * 4, pitch)
+            self._launch_pcm_columns(d_in, frames, column_starts, d_out, pitch)
         finally:
             ctx.free(d_in)                                  # synchronises the stream first
+
+    def _launch_pcm_columns(self, d_in, frames, column_starts, d_out, pitch):
+        """Launch groups for the columns of an uploaded PCM block: column j, track t -> row j * tracks + t of d_out.
+        Equally spaced columns (sweep_sequence lays them out so) take ONE launch group per track whose channels are the
+        columns - 2 groups of 8 channels for a 7.1 recording instead of 8 groups of 2."""
+        n_frames, tracks = frames.shape
+        bits = 16 if frames.dtype == np.int16 else 32
+        starts = [int(v) for v in column_starts]
+        if any(s0 < 0 or s0 + self.L > n_frames for s0 in starts):
+            raise ValueError("column outside the recording")
+        step = starts[1] - starts[0] if len(starts) > 1 else 0
+        if len(starts) > 1 and step > 0 and all(b - a == step for a, b in zip(starts, starts[1:])):
+            for t in range(tracks):
+                self.execute_device_pcm(d_in + (starts[0] * tracks + t) * frames.itemsize, bits, len(starts),
+                                        step * tracks, tracks, d_out + t * pitch * 4, tracks * pitch)
+        else:
+            for j, s0 in enumerate(starts):
+                self.execute_device_pcm(d_in + s0 * tracks * frames.itemsize, bits, tracks, 1, tracks,
+                                        d_out + j * tracks * pitch * 4, pitch)
 
     def set_overlap(self, lanes):
         """lanes > 1: successive launch groups of execute_device overlap on that many streams (inputs must
