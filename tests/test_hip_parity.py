@@ -2167,3 +2167,14 @@ def test_chain_and_peak_search_refuse_what_they_cannot_do(gpu_ctx):
     finally:
         for pl in (same, full, long_full, ola):
             pl.close()
+
+
+def test_fir_chain_seeded_fuzz(gpu_ctx):
+    """tools/fuzz_chain.py, 25 cases: random lengths and crop geometry through imp_chain against the oracle (peaks at the
+    start, in the middle, too close to the end, plateaus, silent channels; odd crop starts; plans of 4 ... 96 rows)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_chain", os.path.join(root, "tools", "fuzz_chain.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(25, 5) <= 2e-6
