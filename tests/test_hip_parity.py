@@ -2178,3 +2178,37 @@ def test_fir_chain_seeded_fuzz(gpu_ctx):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(25, 5) <= 2e-6
+
+
+def test_peak_index_seeded_fuzz(gpu_ctx):
+    """K3 against the oracle on 240 random rows in ragged batches: noise, spikes of both signs, coarsely quantised rows (ties
+    and plateaus everywhere, also exactly at the height threshold), ramps without any peak, rows shorter than a chunk and
+    rows of many chunks.  Same fp32 data on both sides: the indices must be equal, not close."""
+    from oracle.impulse_response import peak_index
+    rng = np.random.default_rng(2024)
+    rows = []
+    for k in range(240):
+        n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 9000), rng.integers(9000, 120000)]))
+        kind = k % 6
+        if kind == 0:
+            x = rng.standard_normal(n)
+        elif kind == 1:
+            x = rng.standard_normal(n) * 0.01
+            x[int(rng.integers(0, n))] = rng.choice([-1.0, 1.0])
+        elif kind == 2:
+            x = np.round(rng.standard_normal(n) * 3) / 8.0                  # values on a grid of 1/8: plateaus, exact ties
+        elif kind == 3:
+            x = np.linspace(-1.0, 1.0, n) * rng.choice([-1.0, 1.0])
+        elif kind == 4:
+            x = np.round(np.cumsum(rng.standard_normal(n)) * 2) / 2.0        # slow walk on a grid: long plateaus
+        else:
+            x = np.zeros(n)
+            m = int(rng.integers(0, n))
+            x[m:] = np.round(rng.standard_normal(n - m) * 4) * 0.12589           # multiples of the height threshold itself
+        rows.append(x.astype(np.float32))
+    for lo in range(0, len(rows), 48):                                       # ragged batches of 48 rows
+        batch = rows[lo:lo + 48]
+        idx, mx = gpu_ctx.peak_index(batch)
+        for j, (r, i, m) in enumerate(zip(batch, idx, mx)):
+            assert int(i) == peak_index(r.astype(np.float64)), (lo + j, len(r))
+            assert m == (np.max(np.abs(r)) if len(r) else 0.0)
