@@ -326,6 +326,58 @@ class HRIR(_PlotBase):
                 ir.data *= g
         return gain
 
+    def calculate_reflection_levels(self, direct_sound_duration_ms=2, early_ref_start_ms=20, early_ref_end_ms=50,
+                                    late_ref_start_ms=50, late_ref_end_ms=150, epsilon=1e-12):
+        """Early and late reflection levels relative to the direct sound, per channel (core/hrir.py:1003-1090):
+        {speaker: {side: {"early_db", "late_db"}}}.  One batched peak search (K3) and one set of window means of the squared
+        responses (K7) for all channels, from host arrays or from device rows; the few scalars per channel on the host."""
+        items = self._all_irs()
+        out = {sp: {} for sp, _, _ in items}
+        if not items:
+            return out
+        ctx = _native.default_context()
+        dev = self._device_rows([ir for _, _, ir in items])
+        if dev is not None:
+            from .device_rows import span
+            base, offs, lens = span(dev)
+            peaks, _ = ctx.peak_index_device(base, offs, lens)
+            seg = _native.SegSet.from_device(ctx, base, offs, lens)
+            lengths = [int(v) for v in lens]
+        else:
+            rows = [np.asarray(ir.data, dtype=np.float64) for _, _, ir in items]
+            lengths = [len(r) for r in rows]
+            live = [k for k, n in enumerate(lengths) if n > 0]
+            peaks = np.zeros(len(rows), dtype=np.int64)
+            if live:
+                peaks[live] = ctx.peak_index([rows[k] for k in live])[0]
+            seg = _native.SegSet(ctx, rows)
+        try:
+            windows = ((0.0, direct_sound_duration_ms), (early_ref_start_ms, early_ref_end_ms), (late_ref_start_ms, late_ref_end_ms))
+            q_seg, q_a, q_b = [], [], []
+            for k, n in enumerate(lengths):
+                pk = int(peaks[k])
+                for w, (t0, t1) in enumerate(windows):
+                    a = pk if w == 0 else min(pk + int(t0 * self.fs / 1000), n)
+                    b = min(pk + int(t1 * self.fs / 1000), n)
+                    q_seg.append(k)
+                    q_a.append(min(a, n))
+                    q_b.append(max(b, min(a, n)))
+            means = seg.range_means_arrays(q_seg, q_a, q_b).reshape(-1, 3)           # NaN where a window is empty
+            tops = np.asarray(seg.maxabs, dtype=np.float64)
+        finally:
+            seg.close()
+        for k, (sp, sd, _) in enumerate(items):
+            # the segments hold (x / max|x|)^2 (x^2 when max|x| < 1e-20): back to mean(x^2)
+            scale = tops[k] ** 2 if tops[k] >= 1e-20 else 1.0
+            rms = [np.sqrt(m * scale) if not np.isnan(m) else None for m in means[k]]
+            rms_direct = rms[0] if rms[0] is not None else epsilon
+            rms_direct = rms_direct if rms_direct > epsilon else epsilon
+            rms_early = rms[1] if rms[1] is not None else 0
+            rms_late = rms[2] if rms[2] is not None else 0
+            out[sp][sd] = {"early_db": 20 * np.log10(rms_early / rms_direct + epsilon),
+                           "late_db": 20 * np.log10(rms_late / rms_direct + epsilon)}
+        return out
+
     # ---- cropping ------------------------------------------------------------------------
     def _all_irs(self):
         return [(sp, sd, ir) for sp, pair in self.irs.items() for sd, ir in pair.items()]

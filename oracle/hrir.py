@@ -190,3 +190,32 @@ def equalize_all(irs, fir):
         fir = np.tile(fir, (2, 1))
     return {sp: {sd: fft_convolve(np.asarray(d, dtype=np.float64), fir[0] if sd == "left" else fir[1], "full")
                  for sd, d in pair.items()} for sp, pair in irs.items()}
+
+
+def reflection_levels(irs, fs, direct_sound_duration_ms=2, early_ref_start_ms=20, early_ref_end_ms=50,
+                      late_ref_start_ms=50, late_ref_end_ms=150, epsilon=1e-12):
+    """core/hrir.py:1003-1090 HRIR.calculate_reflection_levels: for every response, RMS of [peak, peak + direct) and of the
+    early / late windows after the peak (all clipped at the end of the data), early_db / late_db = 20 log10(rms / rms_direct
+    + epsilon) with rms_direct floored at epsilon and an empty window counting as zero.
+    irs: {speaker: {side: 1-D array}} -> {speaker: {side: {"early_db", "late_db"}}}"""
+    out = {}
+    for sp, pair in irs.items():
+        out[sp] = {}
+        for sd, data in pair.items():
+            data = np.asarray(data, dtype=np.float64)
+            pk = peak_index(data)
+            n = len(data)
+
+            def at(ms):
+                return pk + int(ms * fs / 1000)
+
+            direct = data[pk:min(at(direct_sound_duration_ms), n)]
+            early = data[min(at(early_ref_start_ms), n):min(at(early_ref_end_ms), n)]
+            late = data[min(at(late_ref_start_ms), n):min(at(late_ref_end_ms), n)]
+            rms_direct = np.sqrt(np.mean(direct ** 2)) if len(direct) > 0 else epsilon
+            rms_early = np.sqrt(np.mean(early ** 2)) if len(early) > 0 else 0
+            rms_late = np.sqrt(np.mean(late ** 2)) if len(late) > 0 else 0
+            rms_direct = rms_direct if rms_direct > epsilon else epsilon
+            out[sp][sd] = {"early_db": 20 * np.log10(rms_early / rms_direct + epsilon),
+                           "late_db": 20 * np.log10(rms_late / rms_direct + epsilon)}
+    return out

@@ -135,3 +135,17 @@ def headphone_file(path, test_signal):
         tracks[i] += _play(test_signal, h, total, 2 * fs + i * col, 0xE8 + i)
         tracks[1 - i] += np.random.default_rng(0xEC + i).standard_normal(total) * 10 ** (-80 / 20)
     write_pcm32(path, fs, tracks)
+
+
+def reflection_set():
+    """speaker -> side -> response for HRIR.calculate_reflection_levels: ordinary room tails, one response so short that
+    the late window is cut by its end and one that ends inside the early window, a silent channel, and one whose first
+    significant peak is not its largest sample."""
+    out = {"FL": {"left": decaying_ir(0x3300, n=12000, rt60=0.25, delay=31), "right": decaying_ir(0x3301, n=12000, rt60=0.30, delay=44)},
+           "FR": {"left": decaying_ir(0x3302, n=5000, rt60=0.20, delay=25),            # late window (2 400 .. 7 200) cut at 5 000
+                  "right": decaying_ir(0x3303, n=1600, rt60=0.15, delay=12)},          # ends inside the early window
+           "FC": {"left": np.zeros(3000), "right": decaying_ir(0x3304, n=9000, rt60=0.22, delay=60)}}
+    pre = decaying_ir(0x3305, n=9000, rt60=0.22, delay=300)
+    pre[180] = float(np.float32(0.3))                                                  # pre-echo above -18 dB: the first peak (fp32-valued like the rest)
+    out["SL"] = {"left": pre, "right": decaying_ir(0x3306, n=9000, rt60=0.18, delay=90)}
+    return out

@@ -2212,3 +2212,46 @@ def test_peak_index_seeded_fuzz(gpu_ctx):
         for j, (r, i, m) in enumerate(zip(batch, idx, mx)):
             assert int(i) == peak_index(r.astype(np.float64)), (lo + j, len(r))
             assert m == (np.max(np.abs(r)) if len(r) else 0.0)
+
+
+def test_reflection_levels_golden_from_host_arrays_and_device_rows(gpu_ctx, golden):
+    """HRIR.calculate_reflection_levels (core/hrir.py:1003-1090) against the reference's own run: windows cut by the end of
+    the data, a silent channel, a pre-echo as first peak; once from host arrays, once from fp32 rows that live on the device
+    (K3 + K7 read them there)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import round2_inputs as r2
+    from impulse_hip.device_rows import DeviceBlock, Row
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.impulse_response import ImpulseResponse
+
+    class Est:
+        fs = r2.FS
+    g = golden("reflection")
+    data = r2.reflection_set()
+    host = HRIR(Est())
+    host.irs = {sp: {sd: ImpulseResponse(v.copy(), r2.FS) for sd, v in pair.items()} for sp, pair in data.items()}
+    dev = HRIR(Est())
+    flat = [(sp, sd, v.astype(np.float32)) for sp, pair in data.items() for sd, v in pair.items()]   # the inputs are fp32-valued
+    pitch = (max(len(v) for _, _, v in flat) + 63) // 64 * 64
+    from impulse_hip import _native
+    dctx = _native.default_context()                              # device rows belong to the context the classes use
+    block = DeviceBlock(dctx, len(flat) * pitch)
+    buf = np.zeros((len(flat), pitch), dtype=np.float32)
+    for i, (_, _, v) in enumerate(flat):
+        buf[i, :len(v)] = v
+    dctx.h2d(block.ptr, buf)
+    dev.irs = {}
+    for i, (sp, sd, v) in enumerate(flat):
+        dev.irs.setdefault(sp, {})[sd] = ImpulseResponse.on_device(Row(block, i * pitch, len(v)), r2.FS)
+    for tag, kw in (("default", {}), ("wide", dict(direct_sound_duration_ms=5, early_ref_start_ms=5, early_ref_end_ms=80,
+                                                   late_ref_start_ms=80, late_ref_end_ms=400))):
+        for h in (host, dev):
+            got = h.calculate_reflection_levels(**kw)
+            assert list(got) == list(data)
+            for sp, pair in got.items():
+                for sd, v in pair.items():
+                    want = g[f"{tag}_{sp}_{sd}"]
+                    assert abs(v["early_db"] - want[0]) <= 1e-9 and abs(v["late_db"] - want[1]) <= 1e-9, (tag, sp, sd)
+    assert all(ir._row is not None for pair in dev.irs.values() for ir in pair.values())      # nothing was pulled to the host
+    assert HRIR(Est()).calculate_reflection_levels() == {}

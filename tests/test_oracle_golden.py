@@ -497,3 +497,22 @@ def test_headphone_compensation_curves(golden, tmp_path):
         np.testing.assert_allclose(raw, g[f"hp_{nm}_error"], rtol=0, atol=1e-9)
         assert not np.any(g[f"hp_{nm}_target"])
     assert tuple(g["hp_responses_shape"]) == (col, 32) and bool(g["hp_missing"][0])
+
+
+def test_reflection_levels_match_the_reference_run(golden):
+    """HRIR.calculate_reflection_levels (core/hrir.py:1003-1090), default and wide windows, on responses whose windows are
+    cut by the end of the data, a silent channel and a response with a pre-echo as first peak."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import round2_inputs as r2
+    from oracle.hrir import reflection_levels
+    g = golden("reflection")
+    irs = r2.reflection_set()
+    for tag, kw in (("default", {}), ("wide", dict(direct_sound_duration_ms=5, early_ref_start_ms=5, early_ref_end_ms=80,
+                                                   late_ref_start_ms=80, late_ref_end_ms=400))):
+        got = reflection_levels(irs, r2.FS, **kw)
+        for sp, pair in got.items():
+            for sd, v in pair.items():
+                want = g[f"{tag}_{sp}_{sd}"]
+                assert v["early_db"] == want[0] and v["late_db"] == want[1], (tag, sp, sd)
