@@ -399,3 +399,42 @@ def test_write_wav_stacks_only_the_requested_tracks_and_subset_copies(gpu_ctx, t
     assert shared.irs["FL"]["left"] is h.irs["FL"]["left"]
     with pytest.raises(ValueError, match="No impulse responses"):
         _hrir({}).write_wav(path)
+
+
+# ---- sweep round trips (reference tests/test_estimator_roundtrip.py:49-104) -------------------------------------------------------------
+@pytest.fixture(scope="module")
+def sweep_system():
+    """a 1 s sweep estimator, where it puts the peak of its own sweep, and a small room: direct sound + ringing tail"""
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    est = ImpulseResponseEstimator(min_duration=1.0, fs=FS)
+    own = est.estimate(est.test_signal)
+    k = np.arange(500)
+    room = np.zeros(500)
+    room[23:] = 0.1 * np.exp(-(k[23:] - 23) / 90.0) * np.sin(2 * np.pi * 2100 * (k[23:] - 23) / FS + 0.4)
+    room[23] = 1.0
+    played = np.convolve(est.test_signal, room)                     # what a microphone would record, noise-free
+    return est, int(np.argmax(np.abs(own))), own, room, est.estimate(played)
+
+
+@pytest.mark.parametrize("delay", [0, 3, 255, 1500])
+def test_estimate_keeps_the_length_and_finds_a_delayed_sweep(gpu_ctx, sweep_system, delay):
+    est, at, _, _, _ = sweep_system
+    rec = np.concatenate([np.zeros(delay), est.test_signal])
+    y = est.estimate(rec)
+    assert len(y) == len(rec) and int(np.argmax(np.abs(y))) == at + delay
+
+
+def test_estimate_of_the_sweep_itself_is_a_clean_unit_pulse(gpu_ctx, sweep_system):
+    _, at, own, _, _ = sweep_system
+    rest = np.concatenate([own[:at - 50], own[at + 50:]])
+    assert abs(abs(own[at]) - 1.0) < 0.05
+    assert 20 * np.log10(abs(own[at]) / np.max(np.abs(rest))) > 40.0
+
+
+def test_estimate_recovers_the_waveform_of_a_small_room(gpu_ctx, sweep_system):
+    _, at, _, room, y = sweep_system
+    got = y[at:at + len(room)]
+    assert int(np.argmax(np.abs(got))) == int(np.argmax(np.abs(room)))
+    assert float(np.dot(got, room) / (np.linalg.norm(got) * np.linalg.norm(room))) > 0.99
+    far = np.concatenate([y[:max(at - 1000, 0)], y[at + len(room) + 1000:]])
+    assert 20 * np.log10(np.max(np.abs(got)) / np.max(np.abs(far))) > 40.0
