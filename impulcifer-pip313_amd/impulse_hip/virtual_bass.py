@@ -16,6 +16,16 @@ def _detect_polarity(ir):
     return 1.0 if ir[np.argmax(np.abs(ir))] >= 0 else -1.0
 
 
+def _shift(ir, n_samples):
+    """Circular shift (core/virtual_bass.py:26-28; kept for the module's surface, the synthesis uses _delay_signal)."""
+    return np.roll(ir, n_samples)
+
+
+def _rfft_magnitude(ir, fs):
+    """(|rfft(ir)|, bin frequencies) (core/virtual_bass.py:46-50)."""
+    return np.abs(np.fft.rfft(ir)), np.fft.rfftfreq(len(ir), 1.0 / fs)
+
+
 def _delay_signal(sig, delay, length):
     """Delay (>= 0) or advance (< 0) with zero padding, never wrapping."""
     out = np.zeros(length, dtype=sig.dtype)

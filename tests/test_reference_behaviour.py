@@ -438,3 +438,74 @@ def test_estimate_recovers_the_waveform_of_a_small_room(gpu_ctx, sweep_system):
     assert float(np.dot(got, room) / (np.linalg.norm(got) * np.linalg.norm(room))) > 0.99
     far = np.concatenate([y[:max(at - 1000, 0)], y[at + len(room) + 1000:]])
     assert 20 * np.log10(np.max(np.abs(got)) / np.max(np.abs(far))) > 40.0
+
+
+# ---- magnitude_response (reference tests/test_magnitude_response_parity.py:17-57) ------------------------------------------------
+@pytest.mark.parametrize("n", [8, 1024, 48000, 9, 1025, 48001])
+def test_magnitude_response_is_the_one_sided_rfft_in_db(gpu_ctx, n):
+    """The reference pins its magnitude_response to 20 log10 |rfft(x)[:ceil(n/2)]| bit for bit against an older form of
+    itself; a different FFT cannot share bits, so here: the frequency axis exactly, the levels to 1e-9 dB (fp64 Bluestein)."""
+    from impulse_hip.audio_io import magnitude_response
+    x = np.random.default_rng(0xA110 + n).standard_normal(n)
+    f, m = magnitude_response(x, FS)
+    half = int(np.ceil(n / 2))
+    assert np.array_equal(f, np.arange(half) * (FS / n)) and m.shape == (half,)
+    assert np.max(np.abs(m - 20 * np.log10(np.abs(np.fft.rfft(x)[:half])))) < 1e-9
+
+
+def test_magnitude_response_of_a_pulse_and_of_a_glide(gpu_ctx):
+    from impulse_hip.audio_io import magnitude_response
+    x = np.zeros(2048)
+    x[0] = 1.0
+    assert np.max(np.abs(magnitude_response(x, FS)[1])) < 1e-9          # a unit pulse is flat at 0 dB
+    t = np.arange(4096) / FS
+    x = np.sin(2 * np.pi * np.linspace(20, 20000, 4096) * t)
+    want = 20 * np.log10(np.abs(np.fft.rfft(x)[:2048]))
+    assert np.max(np.abs(magnitude_response(x, FS)[1] - want)) < 1e-9
+
+
+# ---- virtual bass (reference tests/test_virtual_bass.py:60-215) --------------------------------------------------------------------
+def test_virtual_bass_helpers(gpu_ctx):
+    from impulse_hip.virtual_bass import _detect_polarity, _rfft_magnitude, _shift
+    for pos, neg, want in ((1.0, 0.0, 1.0), (0.0, -1.0, -1.0), (0.8, -0.5, 1.0), (0.3, -0.9, -1.0)):
+        ir = np.zeros(100)
+        ir[10], ir[20] = pos, neg
+        assert _detect_polarity(ir) == want
+    assert np.array_equal(_shift(np.array([1.0, 0, 0, 0]), 1), [0, 1.0, 0, 0])
+    assert np.array_equal(_shift(np.array([0, 1.0, 0, 0]), -1), [1.0, 0, 0, 0])
+    assert np.array_equal(_shift(np.array([1.0, 2.0, 3.0]), 0), [1.0, 2.0, 3.0])
+    d = np.zeros(1024)
+    d[0] = 1.0
+    mag, freqs = _rfft_magnitude(d, FS)
+    assert len(mag) == len(freqs) == 513 and np.allclose(mag, 1.0, atol=1e-10)
+
+
+def _bass_set(speakers, fs=FS):
+    from impulse_hip.impulse_response import ImpulseResponse
+    n = int(fs * 0.05)
+    t = np.arange(n) / fs
+    out = {}
+    for sp in speakers:
+        d = 0.1 * np.sin(2 * np.pi * 100 * t) * np.exp(-t * 50)
+        d[int(fs * 0.001)] += 1.0
+        out[sp] = {"left": ImpulseResponse(d.copy(), fs), "right": ImpulseResponse(d.copy(), fs)}
+    return out
+
+
+def test_virtual_bass_changes_the_responses_and_bails_out_above_nyquist(gpu_ctx):
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.virtual_bass import apply_virtual_bass_to_hrir
+    everyone = ["FL", "FR", "FC", "SL", "SR", "BL", "BR", "WL", "WR", "TFL", "TFR", "TSL", "TSR", "TBL", "TBR"]
+    for speakers, kw in ((["FL"], {}), (["FL"], dict(invert_polarity=False)), (["FL"], dict(invert_polarity=True)),
+                         (["FL", "FR", "FC"], {}), (everyone, {})) + tuple((["FL"], dict(crossover_freq=f)) for f in (50, 100, 200, 300, 500)):
+        h = HRIR(_Est())
+        h.irs = _bass_set(speakers)
+        before = h.irs["FL"]["left"].data.copy()
+        apply_virtual_bass_to_hrir(h, **{"crossover_freq": 250, **kw})
+        after = h.irs["FL"]["left"].data
+        assert np.all(np.isfinite(after)) and not np.array_equal(after, before)
+    h = HRIR(_Est())
+    h.irs = _bass_set(["FL"])
+    before = h.irs["FL"]["left"].data.copy()
+    apply_virtual_bass_to_hrir(h, crossover_freq=25000)              # at or above Nyquist: nothing happens
+    assert np.array_equal(h.irs["FL"]["left"].data, before)
