@@ -509,3 +509,53 @@ def test_virtual_bass_changes_the_responses_and_bails_out_above_nyquist(gpu_ctx)
     before = h.irs["FL"]["left"].data.copy()
     apply_virtual_bass_to_hrir(h, crossover_freq=25000)              # at or above Nyquist: nothing happens
     assert np.array_equal(h.irs["FL"]["left"].data, before)
+
+
+# ---- run-to-run and thread determinism (reference tests/test_brir_thread_determinism.py:62-104) ----------------------------------------
+def test_slice_output_is_byte_identical_across_runs_and_host_threads(gpu_ctx, tmp_path):
+    """The reference requires the generated WAV files to hash the same over repeated runs on its thread-pool path.  Here:
+    the whole hot-path slice (ingest -> crops -> EQ FIRs -> equalize -> normalize -> write_wav) on a synthetic four-speaker
+    recording, three times in sequence and three times from concurrent host threads sharing the default context - every
+    output file byte for byte the same (no float atomics, no launch-order dependence anywhere on the path)."""
+    import hashlib
+    import threading
+    import warnings as w
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.pipeline_slice import run_slice
+    est = ImpulseResponseEstimator(min_duration=1.0, fs=FS)
+    N, L = len(est), len(est) + 2 * FS
+    speakers = ["FL", "FR", "SL", "SR"]
+    rng = np.random.default_rng(31)
+    tracks = np.zeros((2, 2 * FS + L * len(speakers)))
+    for i in range(len(speakers)):
+        for ear in range(2):
+            room = np.zeros(9000)
+            d = 40 + 7 * i + 11 * ear
+            room[d] = 1.0
+            room[d + 1:] += rng.standard_normal(9000 - d - 1) * 0.1 * np.exp(-np.arange(9000 - d - 1) / 1500.0)
+            col = np.convolve(est.test_signal, room)[:L] * 0.4
+            tracks[ear, 2 * FS + i * L: 2 * FS + i * L + len(col)] += col
+    tracks += rng.standard_normal(tracks.shape) * 1e-4
+    frames = np.ascontiguousarray(np.clip(np.rint(tracks.T * 2.0 ** 31), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int32))
+    digests, errors = {}, []
+
+    def one(tag):
+        try:
+            with w.catch_warnings():
+                w.simplefilter("ignore")
+                h, _ = run_slice(est, [((FS, frames), speakers)])
+                path = str(tmp_path / f"{tag}.wav")
+                h.write_wav(path)
+            digests[tag] = hashlib.sha256(open(path, "rb").read()).hexdigest()
+        except Exception as exc:                                   # noqa: BLE001 - reported below
+            errors.append((tag, repr(exc)))
+
+    for k in range(3):
+        one(f"serial{k}")
+    threads = [threading.Thread(target=one, args=(f"thread{k}",)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(digests) == 6 and len(set(digests.values())) == 1, digests
