@@ -1,7 +1,7 @@
 // libimpulse_hip.so - host side of the C ABI declared in include/impulse_hip.h.
 // Built with: hipcc --offload-arch=gfx950 -O3 -shared -fPIC impulse_hip.hip -o libimpulse_hip.so
-// gfx950 only; no torch, no rocFFT/hipFFT, no RCCL linkage (the one broadcast of the filter
-// spectrum is done by the caller on the buffer returned by imp_plan_spectrum).
+// gfx950 only; no torch, no rocFFT/hipFFT.  The one collective of the path - the broadcast of the prepared filter
+// spectrum (imp_plan_spectrum) - is comm.hip's imp_comm_broadcast over RCCL (librccl opened with dlopen on first use).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -430,15 +430,16 @@ __global__ __launch_bounds__(256) void apply_window_copy_kernel(const float* __r
   }
 }
 
-// HRIR.write_wav on device rows: out[i][t] = lrint(row_t[i] * (2^(bits-1) - 1)) wrapped to `bits` (libsndfile's float -> PCM
-// conversion, see audio_io.pcm_quantise), zeros for tracks without a row; interleaved frames, the WAV wire order.
-// row_of_track[t] = row index or -1.  Samples are stored as int32 (bits 24/32) or int16 (bits 16).
+// HRIR.write_wav on device rows (core/hrir.py:426-455 -> core/audio_io.py:82-97 -> soundfile, which turns libsndfile's
+// clipping on): out[i][t] = clip(lrint(row_t[i] * 2^31), -2^31, 2^31 - 1) >> (32 - bits), zeros for tracks without a row;
+// interleaved frames, the WAV wire order.  PCM_32 is pinned by the sweep WAVs the reference ships (tests/golden/
+// sweep_wavs.npz); see audio_io.pcm_quantise.  row_of_track[t] = row index or -1.  Samples are stored as int32 (bits 24/32)
+// or int16 (bits 16).
 __global__ __launch_bounds__(256) void rows_to_pcm_kernel(const float* __restrict__ src, const int64_t* __restrict__ off,
                                                           const int64_t* __restrict__ len,
                                                           const int64_t* __restrict__ row_of_track, int n_tracks,
                                                           int64_t n_frames, int bits, void* __restrict__ out) {
-  const double scale = (double)((1ll << (bits - 1)) - 1);
-  const long long half = 1ll << (bits - 1), span = 1ll << bits;
+  const int shift = 32 - bits;
   const int64_t total = n_frames * n_tracks;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = k / n_tracks;
@@ -446,8 +447,10 @@ __global__ __launch_bounds__(256) void rows_to_pcm_kernel(const float* __restric
     const int64_t r = row_of_track[t];
     long long q = 0;
     if (r >= 0 && i < len[r]) {
-      q = llrint((double)src[off[r] + i] * scale);             // round half to even, like np.rint / lrint
-      q = ((q + half) % span + span) % span - half;            // no clipping: out-of-range values wrap
+      const double v = (double)src[off[r] + i] * 2147483648.0;   // exact: a power-of-two scale
+      // saturate, then round half to even like lrint / np.rint (a NaN sample falls through to llrint, as in libsndfile)
+      q = v >= 2147483647.0 ? 2147483647ll : v <= -2147483648.0 ? -2147483648ll : llrint(v);
+      q >>= shift;                                               // arithmetic shift: the top `bits` bits
     }
     if (bits == 16) reinterpret_cast<short*>(out)[k] = (short)q;
     else reinterpret_cast<int*>(out)[k] = (int)q;

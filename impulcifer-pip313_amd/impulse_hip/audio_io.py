@@ -95,16 +95,21 @@ def read_wav(file_path, expand=False):
 
 
 def pcm_quantise(frames, bit_depth):
-    """float -> PCM integers the way the reference's writer does it.  The reference writes through soundfile /
-    libsndfile with its defaults (core/audio_io.py:82-97): samples are scaled by 2^(bits-1) - 1 (0x7FFF, 0x7FFFFF,
-    0x7FFFFFFF - NOT by 2^(bits-1), the scale its reader divides by), rounded to nearest-even (lrint) and NOT
-    clipped, so anything beyond +-1 wraps around.  libsndfile is not part of the reference tree; its published
-    conversion (src/pcm.c) is restated here and no shipped output file is loud enough to tell the two scales apart
-    (data/demo/room-responses.wav peaks at 0.0033): parity of this step is unpinned."""
-    scale = float(2 ** (bit_depth - 1) - 1)
-    q = np.rint(np.asarray(frames, dtype=np.float64) * scale).astype(np.int64)
-    half = 1 << (bit_depth - 1)
-    return ((q + half) % (1 << bit_depth)) - half
+    """float -> PCM integers the way the reference's writer does it.  The reference writes through
+    soundfile.write (core/audio_io.py:82-97); python-soundfile switches libsndfile's clipping on for every
+    file it opens, which selects libsndfile's ``*_clip_array`` conversions: the sample is scaled to the 32-bit
+    range, ``q32 = clip(lrint(x * 2^31), -2^31, 2^31 - 1)`` (round half to even, saturating), and narrower
+    subtypes keep its top bits, ``q = q32 >> (32 - bits)``.
+
+    PCM_32 is PINNED by the four sweep WAVs the reference ships under data/ (written by its own
+    core/impulse_response_estimator.py:306-322; the sweep peaks at 0.99999999996, so they show both the 2^31
+    scale and the saturation at +2147483647): tests/golden/sweep_wavs.npz.  No 16- or 24-bit file ships, so for
+    those two widths this restates libsndfile's published clip path (src/pcm.c, d2s_clip_array /
+    d2let_clip_array): parity of PCM_16 / PCM_24 is unpinned."""
+    if bit_depth not in (16, 24, 32):
+        raise ValueError('Invalid bit depth. Accepted values are 16, 24 and 32.')
+    q32 = np.clip(np.rint(np.asarray(frames, dtype=np.float64) * 2.0 ** 31), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int64)
+    return q32 >> (32 - bit_depth)
 
 
 def write_wav_frames(file_path, fs, frames, bit_depth):

@@ -309,7 +309,9 @@ int imp_segset_create_device(imp_ctx* ctx, const float* d_x, const int64_t* off,
                              imp_segset** out, double* maxabs_out);
 /* HRIR.write_wav (core/hrir.py:426-455 -> core/audio_io.py:82-97) for responses on the device: the interleaved PCM
  * block [n_frames][n_tracks] of a WAV data chunk, track t taken from row row_of_track[t] (-1: silence; samples beyond a
- * row's end: silence), converted like libsndfile does (scale 2^(bits-1) - 1, round to nearest even, no clipping).
+ * row's end: silence), converted as soundfile / libsndfile's clip path does: clip(lrint(x * 2^31), -2^31, 2^31 - 1)
+ * >> (32 - bits) (round half to even, saturating; PCM_32 pinned by the sweep WAVs the reference ships, tests/golden/
+ * sweep_wavs.npz).
  * pcm_out: host, int16 for bits = 16, int32 for bits = 24 and 32 (24-bit values sign-extended). */
 int imp_rows_to_pcm_device(imp_ctx* ctx, const float* d_rows, const int64_t* off, const int64_t* len, int64_t n_rows,
                            const int64_t* row_of_track, int64_t n_tracks, int64_t n_frames, int bits, void* pcm_out);

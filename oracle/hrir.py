@@ -170,15 +170,17 @@ def write_wav_frames(irs, track_order=None):
 
 
 def pcm_quantise(frames, bit_depth):
-    """libsndfile's float -> PCM conversion as soundfile.write(subtype='PCM_16'|'PCM_24'|'PCM_32') performs it with
-    its defaults (normalisation on, clipping off): lrint(x * (2^(bits-1) - 1)), no clipping (out-of-range values
-    wrap).  libsndfile is a third-party dependency of the reference (via `soundfile`, unpinned) and is not under
-    /root/reference: this restates its published algorithm (src/pcm.c, d2bes/d2let/d2lei_array); the one shipped
-    output file (data/demo/room-responses.wav, peak 0.0033) cannot tell 2^31 - 1 from 2^31: PARITY UNPINNED."""
-    scale = float(2 ** (bit_depth - 1) - 1)
-    q = np.rint(np.asarray(frames, dtype=np.float64) * scale).astype(np.int64)
-    half = 1 << (bit_depth - 1)
-    return ((q + half) % (1 << bit_depth)) - half
+    """libsndfile's float -> PCM conversion as soundfile.write(subtype='PCM_16'|'PCM_24'|'PCM_32') performs it
+    (core/audio_io.py:82-97 -> soundfile; python-soundfile enables libsndfile's clipping on every file it opens, which
+    selects the *_clip_array conversions): q32 = clip(lrint(x * 2^31), -2^31, 2^31 - 1), and a narrower subtype keeps
+    the top bits, q = q32 >> (32 - bits) (an arithmetic shift: floor).
+    PCM_32 is PINNED by reference-held data: the four sweep WAVs under /root/reference/data were written by
+    core/impulse_response_estimator.py:306-322 with this call, peak at 0.99999999996 of full scale, and are reproduced
+    by this rule (tests/golden/sweep_wavs.npz; lrint(x * (2^31 - 1)) reproduces 38 % of their samples).  libsndfile is a
+    third-party dependency of the reference (via `soundfile`, unpinned) and no 16- / 24-bit file ships: for those widths
+    this restates its published clip path (src/pcm.c d2s_clip_array / d2let_clip_array): PARITY UNPINNED."""
+    q32 = np.clip(np.rint(np.asarray(frames, dtype=np.float64) * 2.0 ** 31), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int64)
+    return q32 >> (32 - bit_depth)
 
 
 def equalize_all(irs, fir):

@@ -534,7 +534,7 @@ def test_ingest_recording_matches_oracle_split(gpu_ctx, tmp_path):
     h.open_recording(path, ["FL", "FR"])
     assert list(h.irs) == ["FL", "FR"] and all(set(p) == {"left", "right"} for p in h.irs.values())
     from impulse_hip.audio_io import pcm_quantise
-    pcm = pcm_quantise(tracks, 32) / 2.0 ** 31                      # what PCM_32 stored (libsndfile's write scale)
+    pcm = pcm_quantise(tracks, 32) / 2.0 ** 31                      # what PCM_32 stored
     jobs = ohrir.split_recording(pcm, ["FL", "FR"], N, fs)
     assert [(sp, sd) for sp, sd, _ in jobs] == [("FL", "left"), ("FL", "right"), ("FR", "left"), ("FR", "right")]
     for sp, sd, col in jobs:
@@ -1661,8 +1661,9 @@ def test_hrir_equalize_two_row_fir_and_write_wav_orders(gpu_ctx, golden, tmp_pat
         assert fs == 48000 and ints.shape == (n_frames, n_tracks)
         # track order + samples: the first 64 frames of the matrix the reference handed to soundfile, quantised
         assert np.array_equal(ints[:64], pcm_quantise(g[f"ww_{name}_head"], bits))
-        # the whole file: the oracle's frame matrix (pinned to the reference run in test_oracle_golden.py) through
-        # libsndfile's conversion - a direct sound a hair above 1.0 wraps, exactly as it would in the reference's file
+        # the whole file: the oracle's frame matrix (pinned to the reference run in test_oracle_golden.py) through the
+        # float -> PCM conversion that the reference's own sweep WAVs pin for PCM_32 (scale 2^31, saturating; 16 / 24 bit keep
+        # the top bits: unpinned) - a direct sound a hair above 1.0 saturates at full scale
         from oracle import hrir as ohrir
         assert np.array_equal(ints, ohrir.pcm_quantise(ohrir.write_wav_frames(base, order), bits))
 
@@ -2000,7 +2001,7 @@ def test_write_wav_from_device_rows_equals_host_codec(gpu_ctx, tmp_path, bits):
     h.crop_heads()
     h.crop_tails()
     assert h._device_rows([ir for pair in h.irs.values() for ir in pair.values()]) is not None
-    # push one sample past full scale: the conversion wraps (no clipping), on both paths
+    # (the conversion itself is pinned against the reference's files in test_write_wav_sweep_sequence_from_device_rows...)
     twin = HRIR(e)
     twin.irs = {sp: {sd: ImpulseResponse(ir.peek(), 48000) for sd, ir in pair.items()} for sp, pair in h.irs.items()}
     for order, name in ((HESUVI_TRACK_ORDER, "hesuvi"), (None, "hexa")):
@@ -2009,6 +2010,67 @@ def test_write_wav_from_device_rows_equals_host_codec(gpu_ctx, tmp_path, bits):
         twin.write_wav(b, track_order=order, bit_depth=bits)
         assert open(a, "rb").read() == open(b, "rb").read()
     assert all(ir._row is not None for pair in h.irs.values() for ir in pair.values())      # still on the device
+
+
+def test_write_wav_sweep_sequence_from_device_rows_against_shipped_files(gpu_ctx, golden, tmp_path):
+    """imp_rows_to_pcm_device against REFERENCE-HELD data: sweep_sequence(['FL'], 'stereo') is put on the
+    device as two fp32 rows and written through HRIR.write_wav's device path; the file is compared with
+    data/sweep-seg-FL-stereo-6.15s-48000Hz-32bit-2.93Hz-24000Hz.wav as the reference ships it (tests/golden/sweep_wavs.npz:
+    every 37th frame, the full-scale samples, the bounds of the silence).  Device rows are fp32, the reference writes from
+    float64: a sample x differs by at most |x| 2^-24 2^31 = 128 LSB at full scale (asserted: <= 129), samples below 2^-8 of full
+    scale are exact to 1 LSB, silence is exact, and the file's +2147483647 / -2147483648 samples come out saturated, not wrapped.
+    The same rows through the oracle's (file-pinned) quantiser must agree bit for bit: that is the device-vs-reference-rule
+    check, independent of the product's host codec."""
+    from impulse_hip.device_rows import DeviceBlock, Row
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.impulse_response import ImpulseResponse
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from oracle import hrir as ohrir
+    from scipy.io import wavfile
+    g = golden("sweep_wavs")
+    e = ImpulseResponseEstimator(min_duration=5.0, fs=48000)
+    seq = e.sweep_sequence(["FL"], "stereo")
+    n_frames, n_tracks = (int(v) for v in g["seg_fl_stereo_shape"])
+    assert seq.shape == (n_tracks, n_frames)
+    rows32 = np.ascontiguousarray(seq, dtype=np.float32)
+    block = DeviceBlock(gpu_ctx, rows32.size)
+    gpu_ctx.h2d(block.ptr, rows32)
+    h = HRIR(e)
+    h.irs = {"FL": {"left": ImpulseResponse.on_device(Row(block, 0, n_frames), 48000),
+                    "right": ImpulseResponse.on_device(Row(block, n_frames, n_frames), 48000)}}
+    assert h._device_rows([h.irs["FL"]["left"], h.irs["FL"]["right"]]) is not None
+    path = str(tmp_path / "seg.wav")
+    h.write_wav(path, track_order=["FL-left", "FL-right"], bit_depth=32)
+    assert h.irs["FL"]["left"]._row is not None                                  # written from the device rows
+    fs, got = wavfile.read(path)
+    assert fs == 48000 and got.dtype == np.int32 and got.shape == (n_frames, n_tracks)
+    got = got.astype(np.int64)
+    # (a) the device conversion == the file-pinned oracle rule on the same fp32 samples, every sample
+    assert np.array_equal(got, ohrir.pcm_quantise(rows32.T.astype(np.float64), 32))
+    # (b) against the reference's file
+    want = g["seg_fl_stereo_dec"].astype(np.int64)
+    dec = got[::int(g["stride"])]
+    d = np.abs(dec - want)
+    assert d.max() <= 129 and np.all(d <= np.abs(want) * 2.0 ** -24 + 1.0)
+    assert np.array_equal(dec[:, 1], want[:, 1]) and not want[:, 1].any()         # the silent track
+    small = np.abs(want[:, 0]) < 2 ** 23
+    assert small.sum() > 100 and np.max(d[small, 0]) <= 1
+    nz = np.flatnonzero(got[:, 0])
+    assert [int(nz[0]), int(nz[-1])] == g["seg_fl_stereo_nonzero_bounds"][0].tolist()
+    for (i, t), v in zip(g["seg_fl_stereo_fullscale_idx"], g["seg_fl_stereo_fullscale_val"].astype(np.int64)):
+        assert abs(int(got[i, t]) - int(v)) <= 129
+        if abs(int(v)) >= 2 ** 31 - 1:
+            assert int(got[i, t]) == int(v)                                       # +2147483647 / -2147483648: saturated
+    # (c) 16 / 24 bit from the same rows: the top bits of the 32-bit value (libsndfile's clip path; unpinned widths)
+    for bits in (16, 24):
+        h.write_wav(path, track_order=["FL-left", "FL-right"], bit_depth=bits)
+        if bits == 16:
+            ints = wavfile.read(path)[1].astype(np.int64)
+        else:
+            from impulse_hip.audio_io import read_wav
+            ints = np.rint(read_wav(path)[1].T * 2.0 ** 23).astype(np.int64)
+        assert np.array_equal(ints, got >> (32 - bits))
+    block.close()
 
 
 def test_fir_chain_without_host_round_trip(gpu_ctx):

@@ -122,21 +122,53 @@ def test_sweep_sequence_and_split_roundtrip():
         split_recording(rec, ["FL"], N, fs, silence_length=0.00001)
 
 
+def test_product_sweep_files_against_the_shipped_wavs(golden, tmp_path):
+    """What the reference's `python -m core.impulse_response_estimator --dir_path data --fs 48000 --speakers FL --tracks
+    stereo|mono` wrote into its data/ folder (core/impulse_response_estimator.py:306-322), re-made with the product's
+    estimator, sweep_sequence and host WAV codec: >= 99.9 % of the samples identical, the rest 1 LSB (libm), silence bounds
+    and saturated full-scale samples as in the files (tests/golden/sweep_wavs.npz)."""
+    from impulse_hip.audio_io import write_wav
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from scipy.io import wavfile
+    g = golden("sweep_wavs")
+    e = ImpulseResponseEstimator(min_duration=5.0, fs=48000)
+    assert e.file_name(32) == "6.15s-48000Hz-32bit-2.93Hz-24000Hz"
+    for key, data in (("sweep", e.test_signal), ("seg_fl_mono", e.sweep_sequence(["FL"], "mono")),
+                      ("seg_fl_stereo", e.sweep_sequence(["FL"], "stereo"))):
+        path = str(tmp_path / (key + ".wav"))
+        write_wav(path, e.fs, data, bit_depth=32)
+        fs, q = wavfile.read(path)
+        q = q.reshape(len(q), -1).astype(np.int64)
+        assert fs == 48000 and tuple(q.shape) == tuple(g[key + "_shape"])
+        want = g[key + "_dec"].astype(np.int64)
+        d = np.abs(q[::int(g["stride"])] - want)
+        assert d.max() <= 1 and np.mean(d == 0) >= 0.999
+        for t in range(q.shape[1]):
+            nz = np.flatnonzero(q[:, t])
+            assert ([int(nz[0]), int(nz[-1])] if len(nz) else [-1, -1]) == g[key + "_nonzero_bounds"][t].tolist()
+        for (i, t), v in zip(g[key + "_fullscale_idx"], g[key + "_fullscale_val"].astype(np.int64)):
+            assert abs(int(q[i, t]) - int(v)) <= 1 and (abs(int(v)) < 2 ** 31 - 1 or int(q[i, t]) == int(v))
+        assert q.max() == 2147483647 and q.min() == -2147483648
+
+
 def test_wav_codec_roundtrip(tmp_path):
     from impulse_hip.audio_io import read_wav, write_wav
     rng = np.random.default_rng(4)
     x = rng.uniform(-0.9, 0.9, size=(3, 1000))
-    # libsndfile's asymmetry, which the reference inherits through soundfile: written with scale 2^(b-1) - 1, read
-    # with 1 / 2^(b-1): a round trip has gain 1 - 2^-(b-1) on top of the half-LSB rounding
+    # written as clip(lrint(x 2^31)) >> (32 - bits) (libsndfile's clip path, which soundfile selects; PCM_32 pinned by the
+    # reference's own sweep files, tests/test_oracle_golden.py::test_pcm32_conversion_against_shipped_sweep_wavs), read
+    # with 1 / 2^(bits-1): a 32-bit round trip is within half an LSB, the narrower widths floor to their LSB
     for bits in (16, 24, 32):
         p = str(tmp_path / f"t{bits}.wav")
         write_wav(p, 48000, x, bit_depth=bits)
         fs, y = read_wav(p)
         assert fs == 48000 and y.shape == x.shape
         lsb = 2.0 ** -(bits - 1)
-        assert np.max(np.abs(y - x * (1 - lsb))) <= 0.5 * lsb * (1 + 1e-9)
+        err = y - x
+        assert (np.max(np.abs(err)) <= 0.5 * lsb) if bits == 32 else (err.max() <= 2.0 ** -32 and err.min() >= -lsb)
         from impulse_hip.audio_io import pcm_quantise
         assert np.array_equal(np.rint(y * 2.0 ** (bits - 1)).astype(np.int64), pcm_quantise(x, bits))
+        assert np.array_equal(pcm_quantise(y, bits), pcm_quantise(x, bits))          # re-writing a read file is lossless
         # scipy reads the same integers
         from scipy.io import wavfile
         if bits != 24:
