@@ -273,6 +273,131 @@ struct StoreRealCropAdd {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Pair mode: TWO real channels travel as ONE complex signal z[n] = x_L[n] + i x_R[n].  The filter is real, so
+// (x_L + i x_R) (*) h = y_L + i y_R: no even/odd packing, no real-FFT unpack - the row pass is a pointwise product
+// with H - and a stereo frame of the recording (core/hrir.py:326-341: track i = left ear, i + 1 = right ear) is one
+// 8-byte load.  Channel pair p = channels (2p, 2p + 1) of the launch group; an odd last channel pairs with silence.
+// A column thread's point e is SAMPLE e of both channels (not samples 2e, 2e + 1 of one).
+// ---------------------------------------------------------------------------------------------
+template <class Sample> struct PairSample;
+template <> struct PairSample<float> {
+  static __device__ __forceinline__ float get(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, float) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, kStreamAux));
+  }
+  static __device__ __forceinline__ cf get2(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, float) {
+    const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, kStreamAux);
+    return make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
+  }
+};
+template <> struct PairSample<int> {
+  static __device__ __forceinline__ float get(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, float scale) {
+    return (float)(int)__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, kStreamAux) * scale;
+  }
+  static __device__ __forceinline__ cf get2(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, float scale) {
+    const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, vo, so, kStreamAux);
+    return make_float2((float)(int)x.x * scale, (float)(int)x.y * scale);
+  }
+};
+template <> struct PairSample<short> {
+  static __device__ __forceinline__ float get(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, float scale) {
+    return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(r, vo, so, kStreamAux) * scale;
+  }
+  static __device__ __forceinline__ cf get2(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, float scale) {
+    const unsigned x = __builtin_amdgcn_raw_buffer_load_b32(r, vo, so, kStreamAux);      // one stereo frame of 16-bit PCM
+    return make_float2((float)(short)(x & 0xFFFFu) * scale, (float)(short)(x >> 16) * scale);
+  }
+};
+
+// Sample = float (scale unused), int (PCM_32, scale 2^-31) or short (PCM_16, scale 2^-15).  Sample i of pair q:
+//   left  at base[q * pair_stride + i * elem_stride],   right at base[q * pair_stride + right_off + i * elem_stride]
+// planar rows [B][pitch]: pair_stride = 2 pitch, right_off = pitch, elem_stride = 1; the columns of a binaural WAV
+// (frames [n][2], column q starting at frame s_q = s_0 + q step): pair_stride = 2 step, right_off = 1, elem_stride = 2 -
+// a stereo frame is then ONE load.  An odd channel count leaves the last pair without a right channel (silence).
+template <class Sample>
+struct LoadPair {
+  const Sample* __restrict__ base;
+  long long pair_stride;
+  long long right_off;
+  long long elem_stride;
+  long long len;
+  int nchan;                        // channels in the launch group (pairs = (nchan + 1) / 2)
+  float scale;
+  __host__ __device__ LoadPair shifted(long long first, long long maxlen) const {
+    const long long rest = len - first;
+    return LoadPair{base + first * elem_stride, pair_stride, right_off, elem_stride, rest < maxlen ? rest : maxlen, nchan, scale};
+  }
+  template <int STEP, int F>
+  __device__ __forceinline__ void column(int p, unsigned e0, cf (&v)[F]) const {
+    const Sample* pl = base + (long long)p * pair_stride;
+    const bool has_r = 2 * p + 1 < nchan;                                   // wave-uniform
+    const unsigned es = (unsigned)elem_stride * (unsigned)sizeof(Sample);   // bytes between samples
+    const unsigned span = ((unsigned)(len - 1) * (unsigned)elem_stride + 1u) * (unsigned)sizeof(Sample);
+    const unsigned vo = e0 * es;
+    // whole frames only where they are naturally aligned (odd track counts / odd first tracks take the two-load path)
+    const bool frames = right_off == 1 && has_r && ((unsigned long long)pl % (2 * sizeof(Sample))) == 0 &&
+                        es % (2u * (unsigned)sizeof(Sample)) == 0;
+    if (frames) {
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(pl, len > 0 ? span + (unsigned)sizeof(Sample) : 0u);
+#pragma unroll
+      for (int j = 0; j < F; ++j) v[j] = PairSample<Sample>::get2(r, vo, (unsigned)(j * STEP) * es, scale);
+    } else {
+      const __amdgpu_buffer_rsrc_t rl = make_rsrc(pl, len > 0 ? span : 0u);
+      const __amdgpu_buffer_rsrc_t rr = make_rsrc(pl + right_off, (has_r && len > 0) ? span : 0u);
+#pragma unroll
+      for (int j = 0; j < F; ++j) {
+        v[j].x = PairSample<Sample>::get(rl, vo, (unsigned)(j * STEP) * es, scale);
+        v[j].y = PairSample<Sample>::get(rr, vo, (unsigned)(j * STEP) * es, scale);     // absent channel: empty range -> 0
+      }
+    }
+  }
+};
+
+// y_L[n - start] = re, y_R[n - start] = im, window [start, start + len) of the linear convolution; the crop is the range
+// check (StoreRealCrop), an absent right channel an empty range.  A wave writes 256 contiguous bytes per channel.
+struct StorePairCrop {
+  float* __restrict__ base;
+  long long chan_stride;
+  long long start;
+  long long len;
+  int nchan;
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind(int p) const {
+    return make_rsrc(base + (long long)(2 * p) * chan_stride, (unsigned)len * 4u);
+  }
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind_r(int p) const {
+    return make_rsrc(base + (long long)(2 * p + 1) * chan_stride, (2 * p + 1 < nchan) ? (unsigned)len * 4u : 0u);
+  }
+  __device__ __forceinline__ void begin(int, int) const {}
+  __device__ __forceinline__ void end(int, int, int, int, int, int) const {}
+  __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, int p, unsigned e, unsigned step_elems, cf v) const {
+    const unsigned off = (e + step_elems - (unsigned)start) * 4u;      // below the window: wraps out of range
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), r, off, 0u, kStreamAux);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), bind_r(p), off, 0u, kStreamAux);
+  }
+};
+
+// overlap-add of 'full' pieces in pair mode (StoreRealCropAdd)
+struct StorePairCropAdd {
+  float* __restrict__ base;
+  long long chan_stride;
+  long long start;
+  long long len;
+  int nchan;
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind(int p) const {
+    return make_rsrc(base + (long long)(2 * p) * chan_stride, (unsigned)len * 4u);
+  }
+  __device__ __forceinline__ void begin(int, int) const {}
+  __device__ __forceinline__ void end(int, int, int, int, int, int) const {}
+  __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, int p, unsigned e, unsigned step_elems, cf v) const {
+    const __amdgpu_buffer_rsrc_t rr =
+        make_rsrc(base + (long long)(2 * p + 1) * chan_stride, (2 * p + 1 < nchan) ? (unsigned)len * 4u : 0u);
+    const unsigned off = (e + step_elems - (unsigned)start) * 4u;
+    const float yl = bload_f(r, off, 0u), yr = bload_f(rr, off, 0u);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yl + v.x), r, off, 0u, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yr + v.y), rr, off, 0u, 0);
+  }
+};
+
 // wave-uniform twiddle (SGPR pair): one VOP3P may read one scalar pair, so the multiply needs no copy
 template <int DIR>
 __device__ __forceinline__ cf ctw_uniform(cf a, cf w) {
@@ -713,6 +838,100 @@ __global__ __launch_bounds__(512, 4) void rows_kernel(RowsArgs args, Twiddles tw
   xcd_work_item(args.nchan, pair, b);
   if (pair >= args.npairs) return;              // the grid is padded to a multiple of 8 pairs (whole workgroup exits)
   rows_pair<IMP_AUX_ROWS_LD, 0>(args, tw, b, b, pair, reinterpret_cast<cf*>(smem_raw), (int)threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row pass of pair mode.  One workgroup = 256 threads = ONE row k1 of a channel pair's transform:
+//   fwd FFT4096 -> W[k] = H[k] Z[k] (H = spectrum of the real filter / Nc, in this kernel's register order) -> inv FFT4096
+// No partner row, no alpha/beta: 8 bytes of spectrum per bin instead of 16, half the LDS (34 KiB: four workgroups per
+// CU instead of two) and two workgroup barriers instead of five - between the X1 exchanges every LDS word a 16-lane
+// group touches is private to it.
+// ---------------------------------------------------------------------------------------------
+struct RowsPairArgs {
+  cf* __restrict__ ws;             // [pairs][N1][4096], in place
+  const cf* __restrict__ hs;       // [N1][4096]: H[k1 + N1 k2] / Nc at [k1][kb2*256 + u], k2 = (u>>4) + 16 (u&15) + 256 kb2
+  int n1_total;
+  int npairs;                      // channel pairs in this launch group
+};
+
+__global__ __launch_bounds__(256, 4) void rows_single_kernel(RowsPairArgs args, Twiddles tw) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cf* buf = reinterpret_cast<cf*>(smem_raw);
+  int b, k1;
+  xcd_work_item(args.npairs, k1, b);
+  const int N1 = args.n1_total;
+  if (k1 >= N1) return;                         // the grid is padded to a multiple of 8 rows (whole workgroup exits)
+  const int t = threadIdx.x;
+
+  const __amdgpu_buffer_rsrc_t r_row = make_rsrc(args.ws + ((long long)b * N1 + k1) * kN2, kN2 * sizeof(cf));
+  const __amdgpu_buffer_rsrc_t r_h = make_rsrc(args.hs + (long long)k1 * kN2, kN2 * sizeof(cf));
+  const __amdgpu_buffer_rsrc_t r_t1 = make_rsrc(tw.t1, 16 * 256 * sizeof(cf));
+  const __amdgpu_buffer_rsrc_t r_t2 = make_rsrc(tw.t2, 16 * 16 * sizeof(cf));
+  const __amdgpu_buffer_rsrc_t r_t4 = make_rsrc(tw.t4, 16 * 256 * sizeof(cf));
+
+  const int hi4 = t >> 4, lo4 = t & 15;
+  const unsigned vo8 = (unsigned)t * 8u, vl8 = (unsigned)lo4 * 8u;
+
+  cf v[16], u[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = bload_cf<IMP_AUX_ROWS_LD>(r_row, vo8, j * 256 * 8);
+#pragma unroll
+  for (int a = 1; a < 16; ++a) u[a] = bload_cf(r_t1, vo8, a * 256 * 8);      // stage-1 twiddles
+
+  // ---- forward FFT4096 (as rows_pair) ----
+  fft16<-1>(v);
+#pragma unroll
+  for (int a = 1; a < 16; ++a) v[a] = cmul(v[a], u[a]);
+#pragma unroll
+  for (int a = 0; a < 16; ++a) buf[a * kRowPad + t] = v[a];
+#pragma unroll
+  for (int q = 1; q < 16; ++q) v[q] = bload_cf(r_t2, vl8, q * 16 * 8);       // stage-2 twiddles
+  __syncthreads();
+#pragma unroll
+  for (int j2 = 0; j2 < 16; ++j2) u[j2] = buf[hi4 * kRowPad + 16 * j2 + lo4];
+  fft16<-1>(u);
+#pragma unroll
+  for (int q = 1; q < 16; ++q) u[q] = cmul(u[q], v[q]);
+  wave_lds_fence();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) buf[hi4 * kRowPad + lo4 * 17 + q] = u[q];
+  wave_lds_fence();
+#pragma unroll
+  for (int t2 = 0; t2 < 16; ++t2) v[t2] = buf[hi4 * kRowPad + t2 * 17 + lo4];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) u[q] = bload_cf(r_h, vo8, q * 256 * 8);       // this thread's 16 bins of H, a phase early
+  fft16<-1>(v);                                            // over t2 -> kb2: thread (ka, kb1) holds k2 = ka + 16 kb1 + 256 kb2
+
+  // ---- W = H Z ----
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], u[q]);
+
+  // ---- inverse FFT4096 (mirror) ----
+#pragma unroll
+  for (int q = 1; q < 16; ++q) u[q] = bload_cf(r_t2, vl8, q * 16 * 8);
+  fft16<+1>(v);                                            // over kb2 -> t2
+#pragma unroll
+  for (int q = 1; q < 16; ++q) v[q] = cmulc(v[q], u[q]);
+  wave_lds_fence();                                        // the group's plane row was last read by these same lanes
+#pragma unroll
+  for (int t2 = 0; t2 < 16; ++t2) buf[hi4 * kRowPad + t2 * 17 + lo4] = v[t2];
+  wave_lds_fence();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) u[q] = buf[hi4 * kRowPad + lo4 * 17 + q];
+#pragma unroll
+  for (int j2 = 0; j2 < 16; ++j2) v[j2] = bload_cf(r_t4, vo8, j2 * 256 * 8);  // inverse 2nd twiddle
+  fft16<+1>(u);                                            // over kb1 -> j2
+#pragma unroll
+  for (int j2 = 0; j2 < 16; ++j2) u[j2] = cmulc(u[j2], v[j2]);
+  wave_lds_fence();
+#pragma unroll
+  for (int j2 = 0; j2 < 16; ++j2) buf[hi4 * kRowPad + 16 * j2 + lo4] = u[j2];
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 16; ++a) v[a] = buf[a * kRowPad + t];
+  fft16<+1>(v);                                            // over ka -> j
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bstore_cf<IMP_AUX_ROWS_ST>(v[j], r_row, vo8, j * 256 * 8);
 }
 
 }  // namespace imp

@@ -444,7 +444,10 @@ struct imp_plan {
   cf* cur_ws = nullptr;
   TwSet tw;
   float4* ab = nullptr;    // [n_filters][N1][4096]
-  cf* ws = nullptr;        // [ws_channels][N1][4096]
+  cf* ws = nullptr;        // [ws_channels][N1][4096] (pair mode: [ws_channels / 2][N1][4096])
+  // pair mode (conv_kernels.hip.h): two channels per transform, z = x_L + i x_R; Nc = nfft = circular length in samples
+  bool paired = false;
+  cf* hs = nullptr;        // [N1][4096]: H / Nc in the register order of rows_single_kernel
   // staging for the host-buffer entry points
   float* d_in = nullptr;
   float* d_out = nullptr;
@@ -524,6 +527,7 @@ static int launch_cols_any(imp_plan* p, int64_t nchan, Load ld, Store st) {
   if (p->R2 == 1 && p->F == 4) return launch_cols_small<4, DIR>(p, nchan, ld, st);
   if (p->R2 == 1 && p->F == 8) return launch_cols_small<8, DIR>(p, nchan, ld, st);
   if (p->F == 11 && p->R2 == 6) return launch_cols_mixed<11, 6, DIR>(p, nchan, ld, st);
+  if (p->F == 11 && p->R2 == 12) return launch_cols_mixed<11, 12, DIR>(p, nchan, ld, st);
   if (p->F == 8) {
     switch (p->R2) {
       case 3: return launch_cols_mixed<8, 3, DIR>(p, nchan, ld, st);
@@ -574,7 +578,26 @@ static int launch_rows(imp_plan* p, int64_t nchan, int64_t first_chan, int64_t p
   return IMP_OK;
 }
 
-static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, int mode, int64_t ws_channels) {
+static constexpr size_t kRowsSingleLds = sizeof(cf) * 16 * imp::kRowPad;
+
+static int launch_rows_single(imp_plan* p, int64_t npairs) {
+  int rc_attr = ctx_kernel_lds(p->ctx, reinterpret_cast<const void*>(imp::rows_single_kernel), kRowsSingleLds);
+  if (rc_attr) return rc_attr;
+  imp::RowsPairArgs a;
+  a.ws = p->cur_ws;
+  a.hs = p->hs;
+  a.n1_total = p->N1;
+  a.npairs = (int)npairs;
+  imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
+  // the XCD-aware work mapping deals rows in eights: pad, the surplus workgroups exit at once
+  dim3 grid((unsigned)(npairs * ((p->N1 + 7) / 8 * 8))), block(256);
+  hipLaunchKernelGGL(imp::rows_single_kernel, grid, block, kRowsSingleLds, p->cur_stream, a, tw);
+  HIP_TRY(hipGetLastError());
+  return IMP_OK;
+}
+
+static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, int mode, int64_t ws_channels,
+                         bool paired = false) {
   if (M < 1 || L < 1) return fail(IMP_ERR_INVALID, "M and L must be >= 1 (M=%lld L=%lld)", (long long)M, (long long)L);
   if (n_filters < 1) return fail(IMP_ERR_INVALID, "n_filters must be >= 1");
   if (mode != IMP_MODE_SAME && mode != IMP_MODE_FULL) return fail(IMP_ERR_INVALID, "mode must be IMP_MODE_SAME or IMP_MODE_FULL");
@@ -584,8 +607,14 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   const int64_t full = L + M - 1;
   const int64_t need = (mode == IMP_MODE_SAME) ? std::max(L + M / 2, M) : full;
   // N1 = F * R2 rows of 4096 complex points, ascending; F = rows per thread in the column passes
-  static const struct { int f, r2; } kShapes[] = {{4, 1},  {8, 1},  {16, 1}, {8, 3},  {16, 2}, {8, 5},  {16, 3},  {16, 4},  {11, 6}, {8, 9},
-                                                  {16, 5}, {16, 6}, {16, 8}, {16, 9}, {16, 10}, {16, 12}, {16, 16}};
+  // pair mode: a row holds 4096 samples of both channels (mono: 8192 of one), so a pair plan has twice the rows of the
+  // mono plan for the same lengths; 11 x 12 = 132 rows is the 7.1 / 6.15 s configuration there (mono: 11 x 6 = 66)
+  static const struct { int f, r2; bool pair_only; } kShapes[] = {
+      {4, 1, false},  {8, 1, false},  {16, 1, false}, {8, 3, false},  {16, 2, false},  {8, 5, false},
+      {16, 3, false}, {16, 4, false}, {11, 6, false}, {8, 9, false},  {16, 5, false},  {16, 6, false},
+      {16, 8, false}, {11, 12, true}, {16, 9, false}, {16, 10, false}, {16, 12, false}, {16, 16, false}};
+  const int64_t samples_per_row = paired ? imp::kN2 : 2 * imp::kN2;
+  if (paired && n_filters != 1) return fail(IMP_ERR_INVALID, "pair mode needs ONE filter shared by both channels of a pair");
   int r2 = 0, f1 = 16;
   const char* min_rows_env = std::getenv("IMPULSE_HIP_MIN_ROWS");             // experiments: 16 = the round-1 smallest plan
   const int min_rows = min_rows_env ? atoi(min_rows_env) : 0;
@@ -594,13 +623,18 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   const int64_t need_eff = no_wrap ? full : need;
   for (const auto& sh : kShapes) {
     const int n1 = sh.f * sh.r2;
-    if (n1 >= min_rows && (!pow2_only || (n1 & (n1 - 1)) == 0) && (int64_t)n1 * 2 * imp::kN2 >= need_eff) {
+    if (sh.pair_only && !paired) continue;
+    if (n1 >= min_rows && (!pow2_only || (n1 & (n1 - 1)) == 0) && (int64_t)n1 * samples_per_row >= need_eff) {
       r2 = sh.r2;
       f1 = sh.f;
       break;
     }
   }
   p->ola = false;
+  p->paired = paired;
+  if (!r2 && paired)
+    return fail(IMP_ERR_UNSUPPORTED, "pair mode covers circular lengths up to 2^20 samples (256 rows); this plan needs %lld",
+                (long long)need_eff);
   if (!r2) {
     // Longer than one two-level transform (2^21 points): overlap-add.  The input is cut into blocks and, when
     // the filter itself is longer than 2^20 taps, the filter into partitions; every (block, partition) piece is
@@ -625,7 +659,7 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   p->F = f1;
   p->N1 = f1 * r2;
   p->Nc = (int64_t)p->N1 * imp::kN2;
-  p->nfft = 2 * p->Nc;
+  p->nfft = paired ? p->Nc : 2 * p->Nc;
   if (mode == IMP_MODE_SAME) {
     // scipy.signal._signaltools._centered: start = (full - L) // 2 with full = L + M - 1
     p->out_start = (M - 1) / 2;
@@ -637,8 +671,9 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   if (ws_channels <= 0) {
     // keep the workspace within ~100 MiB so A->B->C hand-offs stay in the 256 MiB Infinity Cache
     // (measured on C5/C3: groups whose workspace + inputs + outputs exceed the cache lose 5-20 %)
-    ws_channels = std::max<int64_t>(1, ((int64_t)100 << 20) / (p->Nc * (int64_t)sizeof(cf)));
+    ws_channels = std::max<int64_t>(1, ((int64_t)100 << 20) / (p->Nc * (int64_t)sizeof(cf))) * (paired ? 2 : 1);
   }
+  if (paired) ws_channels += ws_channels & 1;            // whole pairs
   p->ws_channels = ws_channels;
   return IMP_OK;
 }
@@ -648,9 +683,11 @@ static int plan_alloc(imp_plan* p) {
   if (rc) return rc;
   if ((rc = ctx_twiddles(p->ctx, p->N1, &p->tw))) return rc;
   const size_t plane = (size_t)p->N1 * imp::kN2;
-  hipError_t e = hipMalloc((void**)&p->ab, plane * (size_t)(p->n_filters * p->ola_parts) * sizeof(float4));
+  hipError_t e;
+  if (p->paired) e = hipMalloc((void**)&p->hs, plane * sizeof(cf));
+  else e = hipMalloc((void**)&p->ab, plane * (size_t)(p->n_filters * p->ola_parts) * sizeof(float4));
   if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(spectrum): %s", hipGetErrorString(e));
-  e = hipMalloc((void**)&p->ws, plane * (size_t)p->ws_channels * sizeof(cf));
+  e = hipMalloc((void**)&p->ws, plane * (size_t)(p->paired ? p->ws_channels / 2 : p->ws_channels) * sizeof(cf));
   if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(workspace): %s", hipGetErrorString(e));
   return IMP_OK;
 }
@@ -663,6 +700,7 @@ extern "C" void imp_plan_destroy(imp_plan* p) {
   (void)hipSetDevice(p->ctx->device);
   (void)plan_sync_lanes(p);
   if (p->ab) (void)hipFree(p->ab);
+  if (p->hs) (void)hipFree(p->hs);
   if (p->ws) (void)hipFree(p->ws);
   if (p->d_in) (void)hipFree(p->d_in);
   if (p->d_out) (void)hipFree(p->d_out);
@@ -676,17 +714,79 @@ extern "C" void imp_plan_destroy(imp_plan* p) {
   delete p;
 }
 
-extern "C" int imp_conv_plan_create_empty(imp_ctx* ctx, int64_t M, int64_t n_filters, int64_t L, int mode,
-                                          int64_t ws_channels, imp_plan** out) {
+static int plan_create_empty_impl(imp_ctx* ctx, int64_t M, int64_t n_filters, int64_t L, int mode, int64_t ws_channels,
+                                  bool paired, imp_plan** out) {
   if (!ctx || !out) return fail(IMP_ERR_INVALID, "imp_conv_plan_create_empty: null argument");
   IMP_CTX_LOCK(ctx);
   *out = nullptr;
   imp_plan* p = new (std::nothrow) imp_plan();
   if (!p) return fail(IMP_ERR_ALLOC, "out of host memory");
   p->ctx = ctx;
-  int rc = plan_geometry(p, M, n_filters, L, mode, ws_channels);
+  int rc = plan_geometry(p, M, n_filters, L, mode, ws_channels, paired);
   if (!rc) rc = plan_alloc(p);
   if (rc) {
+    imp_plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return IMP_OK;
+}
+
+extern "C" int imp_conv_plan_create_empty(imp_ctx* ctx, int64_t M, int64_t n_filters, int64_t L, int mode,
+                                          int64_t ws_channels, imp_plan** out) {
+  return plan_create_empty_impl(ctx, M, n_filters, L, mode, ws_channels, false, out);
+}
+
+extern "C" int imp_conv_plan_create_empty_paired(imp_ctx* ctx, int64_t M, int64_t L, int mode, int64_t ws_channels,
+                                                 imp_plan** out) {
+  return plan_create_empty_impl(ctx, M, 1, L, mode, ws_channels, true, out);
+}
+
+// the plan's spectrum planes from host filters (fp64 on the device, rounded once); work in flight must be drained
+static int plan_fill_spectrum(imp_plan* p, const double* filter, int64_t filter_ld) {
+  imp_ctx* ctx = p->ctx;
+  const int64_t M = p->M, n_filters = p->n_filters;
+  const int64_t ld = n_filters > 1 ? filter_ld : M;
+  if (p->paired) return spectrum_pair_device(ctx, filter, M, p->Nc, p->N1, p->hs);
+  const size_t plane = (size_t)p->N1 * imp::kN2;
+  // IMPULSE_HIP_HOST_SPECTRUM=1 keeps the fp64 host preparation (the cross-check path of the tests)
+  const char* host_env = std::getenv("IMPULSE_HIP_HOST_SPECTRUM");
+  if (host_env && host_env[0] == '1' && !p->ola) {
+    std::vector<float4> ab(plane);
+    std::vector<cd> H;
+    for (int64_t f = 0; f < n_filters; ++f) {
+      host_rfft(filter + f * ld, M, p->Nc, H);
+      host_alpha_beta(H, p->Nc, p->N1, ab.data());
+      hipError_t e = hipMemcpyAsync(p->ab + (size_t)f * plane, ab.data(), plane * sizeof(float4),
+                                    hipMemcpyHostToDevice, ctx->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+      if (e != hipSuccess) return fail(IMP_ERR_HIP, "spectrum upload: %s", hipGetErrorString(e));
+    }
+    return IMP_OK;
+  }
+  if (!p->ola) return spectrum_alpha_beta_device(ctx, filter, M, n_filters, ld, p->Nc, p->N1, p->ab);
+  // overlap-add: plane (f, j) = partition j of filter f
+  for (int64_t j = 0; j < p->ola_parts; ++j) {
+    const int64_t m0 = j * p->ola_mp, mj = std::min(p->ola_mp, M - m0);
+    for (int64_t f = 0; f < n_filters; ++f) {
+      int rc = spectrum_alpha_beta_device(ctx, filter + f * ld + m0, mj, 1, mj, p->Nc, p->N1,
+                                          p->ab + (size_t)(f * p->ola_parts + j) * plane);
+      if (rc) return rc;
+    }
+  }
+  return IMP_OK;
+}
+
+static int plan_create_impl(imp_ctx* ctx, const double* filter, int64_t M, int64_t n_filters, int64_t filter_ld, int64_t L,
+                            int mode, int64_t ws_channels, bool paired, imp_plan** out) {
+  if (!ctx || !out) return fail(IMP_ERR_INVALID, "imp_conv_plan_create: null argument");
+  if (!filter) return fail(IMP_ERR_INVALID, "imp_conv_plan_create: null filter");
+  IMP_CTX_LOCK(ctx);
+  if (n_filters > 1 && filter_ld < M) return fail(IMP_ERR_INVALID, "filter_ld < M");
+  imp_plan* p = nullptr;
+  int rc = plan_create_empty_impl(ctx, M, n_filters, L, mode, ws_channels, paired, &p);
+  if (rc) return rc;
+  if ((rc = plan_fill_spectrum(p, filter, filter_ld))) {
     imp_plan_destroy(p);
     return rc;
   }
@@ -697,49 +797,17 @@ extern "C" int imp_conv_plan_create_empty(imp_ctx* ctx, int64_t M, int64_t n_fil
 extern "C" int imp_conv_plan_create(imp_ctx* ctx, const double* filter, int64_t M, int64_t n_filters,
                                     int64_t filter_ld, int64_t L, int mode, int64_t ws_channels,
                                     imp_plan** out) {
-  if (!ctx || !out) return fail(IMP_ERR_INVALID, "imp_conv_plan_create: null argument");
-  if (!filter) return fail(IMP_ERR_INVALID, "imp_conv_plan_create: null filter");
-  IMP_CTX_LOCK(ctx);
-  if (n_filters > 1 && filter_ld < M) return fail(IMP_ERR_INVALID, "filter_ld < M");
-  imp_plan* p = nullptr;
-  int rc = imp_conv_plan_create_empty(ctx, M, n_filters, L, mode, ws_channels, &p);
-  if (rc) return rc;
-  // IMPULSE_HIP_HOST_SPECTRUM=1 keeps the fp64 host preparation (the cross-check path of the tests)
-  const char* host_env = std::getenv("IMPULSE_HIP_HOST_SPECTRUM");
-  if (host_env && host_env[0] == '1' && !p->ola) {
-    const size_t plane = (size_t)p->N1 * imp::kN2;
-    std::vector<float4> ab(plane);
-    std::vector<cd> H;
-    for (int64_t f = 0; f < n_filters; ++f) {
-      host_rfft(filter + f * filter_ld, M, p->Nc, H);
-      host_alpha_beta(H, p->Nc, p->N1, ab.data());
-      hipError_t e = hipMemcpyAsync(p->ab + (size_t)f * plane, ab.data(), plane * sizeof(float4),
-                                    hipMemcpyHostToDevice, ctx->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-      if (e != hipSuccess) {
-        imp_plan_destroy(p);
-        return fail(IMP_ERR_HIP, "spectrum upload: %s", hipGetErrorString(e));
-      }
-    }
-  } else if (p->ola) {
-    // plane (f, j) = partition j of filter f
-    const size_t plane = (size_t)p->N1 * imp::kN2;
-    for (int64_t j = 0; j < p->ola_parts && !rc; ++j) {
-      const int64_t m0 = j * p->ola_mp, mj = std::min(p->ola_mp, M - m0);
-      for (int64_t f = 0; f < n_filters && !rc; ++f)
-        rc = spectrum_alpha_beta_device(ctx, filter + f * (n_filters > 1 ? filter_ld : M) + m0, mj, 1, mj, p->Nc, p->N1,
-                                        p->ab + (size_t)(f * p->ola_parts + j) * plane);
-    }
-    if (rc) {
-      imp_plan_destroy(p);
-      return rc;
-    }
-  } else if ((rc = spectrum_alpha_beta_device(ctx, filter, M, n_filters, n_filters > 1 ? filter_ld : M, p->Nc, p->N1,
-                                               p->ab))) {
-    imp_plan_destroy(p);
-    return rc;
-  }
-  *out = p;
+  return plan_create_impl(ctx, filter, M, n_filters, filter_ld, L, mode, ws_channels, false, out);
+}
+
+extern "C" int imp_conv_plan_create_paired(imp_ctx* ctx, const double* filter, int64_t M, int64_t L, int mode,
+                                           int64_t ws_channels, imp_plan** out) {
+  return plan_create_impl(ctx, filter, M, 1, M, L, mode, ws_channels, true, out);
+}
+
+extern "C" int imp_plan_is_paired(const imp_plan* p, int* paired) {
+  if (!p || !paired) return fail(IMP_ERR_INVALID, "imp_plan_is_paired: null argument");
+  *paired = p->paired ? 1 : 0;
   return IMP_OK;
 }
 
@@ -750,17 +818,7 @@ extern "C" int imp_plan_set_filters(imp_plan* p, const double* filter, int64_t f
   int rc = ctx_bind(p->ctx);
   if (rc) return rc;
   if ((rc = plan_sync_lanes(p))) return rc;
-  const int64_t ld = p->n_filters > 1 ? filter_ld : p->M;
-  if (!p->ola) return spectrum_alpha_beta_device(p->ctx, filter, p->M, p->n_filters, ld, p->Nc, p->N1, p->ab);
-  const size_t plane = (size_t)p->N1 * imp::kN2;
-  for (int64_t j = 0; j < p->ola_parts; ++j) {
-    const int64_t m0 = j * p->ola_mp, mj = std::min(p->ola_mp, p->M - m0);
-    for (int64_t f = 0; f < p->n_filters; ++f)
-      if ((rc = spectrum_alpha_beta_device(p->ctx, filter + f * ld + m0, mj, 1, mj, p->Nc, p->N1,
-                                           p->ab + (size_t)(f * p->ola_parts + j) * plane)))
-        return rc;
-  }
-  return IMP_OK;
+  return plan_fill_spectrum(p, filter, filter_ld);
 }
 
 extern "C" int imp_debug_plan_geometry(int64_t M, int64_t L, int mode, int64_t* nfft, int64_t* out_start,
@@ -771,6 +829,18 @@ extern "C" int imp_debug_plan_geometry(int64_t M, int64_t L, int mode, int64_t* 
   if (nfft) *nfft = tmp.nfft;
   if (out_start) *out_start = tmp.out_start;
   if (out_len) *out_len = tmp.out_len;
+  return IMP_OK;
+}
+
+extern "C" int imp_debug_plan_geometry_paired(int64_t M, int64_t L, int mode, int64_t* nfft, int64_t* out_start,
+                                              int64_t* out_len, int64_t* n1_rows) {
+  imp_plan tmp;
+  int rc = plan_geometry(&tmp, M, 1, L, mode, 2, true);
+  if (rc) return rc;
+  if (nfft) *nfft = tmp.nfft;
+  if (out_start) *out_start = tmp.out_start;
+  if (out_len) *out_len = tmp.out_len;
+  if (n1_rows) *n1_rows = tmp.N1;
   return IMP_OK;
 }
 
@@ -797,6 +867,11 @@ extern "C" int imp_plan_info(const imp_plan* p, int64_t* nfft, int64_t* out_len,
 extern "C" int imp_plan_spectrum(imp_plan* p, void** dptr, size_t* bytes) {
   if (!p || !dptr || !bytes) return fail(IMP_ERR_INVALID, "imp_plan_spectrum: null argument");
   IMP_CTX_LOCK(p->ctx);
+  if (p->paired) {
+    *dptr = p->hs;
+    *bytes = (size_t)p->N1 * imp::kN2 * sizeof(cf);
+    return IMP_OK;
+  }
   *dptr = p->ab;
   // every plane the row pass can read: per-channel filters x overlap-add filter partitions
   *bytes = (size_t)p->N1 * imp::kN2 * (size_t)(p->n_filters * p->ola_parts) * sizeof(float4);
@@ -875,9 +950,40 @@ template <class Load>
 static int run_group_with(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64_t chan_stride_out,
                           int64_t first_chan, int last_stage);
 
+// one launch group in pair mode: channels (2q, 2q + 1) of the group share a transform; ld.nchan = nchan
+template <class Load>
+static int run_group_pair(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64_t chan_stride_out, int last_stage) {
+  int rc;
+  const int64_t lane_channels = p->ws_channels / p->lanes;
+  const int lane = (p->lanes > 1) ? (int)(p->group_counter_lane++ % p->lanes) : 0;
+  p->cur_stream = lane ? p->ctx->side_streams[(size_t)(lane - 1)] : p->ctx->stream;
+  p->cur_ws = p->ws + (int64_t)lane * (lane_channels / 2) * p->N1 * imp::kN2;
+  if (nchan < 1 || nchan > lane_channels || (lane_channels & 1))
+    return fail(IMP_ERR_INVALID, "launch group of %lld channels exceeds the workspace lane (%lld, whole pairs)",
+                (long long)nchan, (long long)lane_channels);
+  const int64_t npairs = (nchan + 1) / 2;
+  imp::StoreWorkspace stw{p->cur_ws, p->N1};
+  if ((rc = timing_event(p, 0))) return rc;
+  if ((rc = launch_cols_any<-1>(p, npairs, ld, stw))) return rc;
+  if ((rc = timing_event(p, 1))) return rc;
+  if (last_stage < 1) return IMP_OK;
+  if ((rc = launch_rows_single(p, npairs))) return rc;
+  if ((rc = timing_event(p, 2))) return rc;
+  if (last_stage < 2) return IMP_OK;
+  imp::LoadWorkspace ldw{p->cur_ws, p->N1};
+  imp::StorePairCrop stc{d_y, chan_stride_out, p->out_start, p->out_len, (int)nchan};
+  if (p->tile_max) rc = launch_cols_any<+1>(p, npairs, ldw, imp::StorePairCropMax{stc, p->tile_max});
+  else rc = launch_cols_any<+1>(p, npairs, ldw, stc);
+  if (rc) return rc;
+  return timing_event(p, 3);
+}
+
 static int run_group(imp_plan* p, const float* d_x, int64_t nchan, int64_t chan_stride_in,
                      int64_t elem_stride_in, float* d_y, int64_t chan_stride_out, int64_t first_chan,
                      int last_stage) {
+  if (p->paired)
+    return run_group_pair(p, imp::LoadPair<float>{d_x, 2 * chan_stride_in, chan_stride_in, elem_stride_in, p->L, (int)nchan, 0.f},
+                          nchan, d_y, chan_stride_out, last_stage);
   imp::LoadRealPacked ld{d_x, chan_stride_in, elem_stride_in, p->L};
   return run_group_with(p, ld, nchan, d_y, chan_stride_out, first_chan, last_stage);
 }
@@ -886,6 +992,7 @@ template <class Load>
 static int run_group_with(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64_t chan_stride_out,
                           int64_t first_chan, int last_stage) {
   int rc;
+  if (p->paired) return fail(IMP_ERR_INVALID, "this loader packs one channel per transform: not a pair-mode plan");
   // lane = stream + private slice of the workspace; successive launch groups go round robin
   const int64_t lane_channels = p->ws_channels / p->lanes;
   const int lane = (p->lanes > 1) ? (int)(p->group_counter_lane++ % p->lanes) : 0;
@@ -949,7 +1056,7 @@ static int check_input_span(const imp_plan* p, int64_t elem_stride, size_t sampl
 // ------------------------------------------------------------------------------------------------
 static void resident_shape(const imp_plan* p, int* F, int* R2) {
   *F = *R2 = 0;
-  if (p->ola) return;
+  if (p->ola || p->paired) return;
   // one channel's workspace must stay in an XCD's 4 MiB L2 beside the digit twiddles and the row tables
   if ((int64_t)p->N1 * imp::kN2 * (int64_t)sizeof(cf) > ((int64_t)2600 << 10)) return;
   switch (p->N1) {
@@ -1146,6 +1253,19 @@ extern "C" int imp_conv_execute_device_pcm(imp_plan* p, const void* d_pcm, int b
                                                        1.0f / 32768.0f}, B, d_y, chan_stride_out, 0);
   }
   const int64_t grp = p->ws_channels / p->lanes;
+  for (int64_t c0 = 0; c0 < B && p->paired; c0 += grp) {
+    const int64_t n = std::min(grp, B - c0);
+    if (bits == 32)
+      rc = run_group_pair(p, imp::LoadPair<int>{(const int*)d_pcm + c0 * chan_stride_in, 2 * chan_stride_in, chan_stride_in,
+                                                elem_stride_in, p->L, (int)n, 1.0f / 2147483648.0f},
+                          n, d_y + c0 * chan_stride_out, chan_stride_out, 2);
+    else
+      rc = run_group_pair(p, imp::LoadPair<short>{(const short*)d_pcm + c0 * chan_stride_in, 2 * chan_stride_in, chan_stride_in,
+                                                  elem_stride_in, p->L, (int)n, 1.0f / 32768.0f},
+                          n, d_y + c0 * chan_stride_out, chan_stride_out, 2);
+    if (rc) return rc;
+  }
+  if (p->paired) return IMP_OK;
   for (int64_t c0 = 0; c0 < B; c0 += grp) {
     const int64_t n = std::min(grp, B - c0);
     if (bits == 32) {
@@ -1162,12 +1282,43 @@ extern "C" int imp_conv_execute_device_pcm(imp_plan* p, const void* d_pcm, int b
   return IMP_OK;
 }
 
+extern "C" int imp_conv_execute_device_pairs(imp_plan* p, const void* d_x, int bits, int64_t n_pairs, int64_t pair_stride,
+                                             int64_t right_offset, int64_t elem_stride, float* d_y, int64_t chan_stride_out) {
+  if (!p || !d_x || !d_y) return fail(IMP_ERR_INVALID, "imp_conv_execute_device_pairs: null argument");
+  IMP_CTX_LOCK(p->ctx);
+  if (!p->paired) return fail(IMP_ERR_INVALID, "imp_conv_execute_device_pairs: not a pair-mode plan (imp_conv_plan_create_paired)");
+  if (bits != 0 && bits != 16 && bits != 32) return fail(IMP_ERR_INVALID, "bits must be 0 (float32), 16 or 32 (PCM)");
+  if (n_pairs < 0 || elem_stride < 1 || right_offset == 0 || (n_pairs > 1 && pair_stride == 0))
+    return fail(IMP_ERR_INVALID, "imp_conv_execute_device_pairs: bad pair geometry");
+  int rc = check_input_span(p, elem_stride, bits == 16 ? 2 : 4);
+  if (rc) return rc;
+  if (chan_stride_out < p->out_len) return fail(IMP_ERR_INVALID, "chan_stride_out < out_len");
+  if ((rc = ctx_bind(p->ctx))) return rc;
+  const int64_t grp = p->ws_channels / p->lanes / 2;                  // pairs per launch group
+  for (int64_t q0 = 0; q0 < n_pairs; q0 += grp) {
+    const int64_t nq = std::min(grp, n_pairs - q0);
+    float* y = d_y + 2 * q0 * chan_stride_out;
+    if (bits == 0)
+      rc = run_group_pair(p, imp::LoadPair<float>{(const float*)d_x + q0 * pair_stride, pair_stride, right_offset, elem_stride,
+                                                  p->L, (int)(2 * nq), 0.f}, 2 * nq, y, chan_stride_out, 2);
+    else if (bits == 32)
+      rc = run_group_pair(p, imp::LoadPair<int>{(const int*)d_x + q0 * pair_stride, pair_stride, right_offset, elem_stride, p->L,
+                                                (int)(2 * nq), 1.0f / 2147483648.0f}, 2 * nq, y, chan_stride_out, 2);
+    else
+      rc = run_group_pair(p, imp::LoadPair<short>{(const short*)d_x + q0 * pair_stride, pair_stride, right_offset, elem_stride,
+                                                  p->L, (int)(2 * nq), 1.0f / 32768.0f}, 2 * nq, y, chan_stride_out, 2);
+    if (rc) return rc;
+  }
+  return IMP_OK;
+}
+
 extern "C" int imp_plan_set_overlap(imp_plan* p, int lanes) {
   if (!p) return fail(IMP_ERR_INVALID, "null plan");
   IMP_CTX_LOCK(p->ctx);
   if (lanes < 1 || lanes > 4) return fail(IMP_ERR_INVALID, "lanes must be in [1, 4]");
-  if (p->ws_channels / lanes < 1) return fail(IMP_ERR_INVALID, "workspace of %lld channels cannot be split %d ways",
-                                              (long long)p->ws_channels, lanes);
+  if (p->ws_channels / lanes < 1 || (p->paired && ((p->ws_channels / lanes) & 1)))
+    return fail(IMP_ERR_INVALID, "workspace of %lld channels cannot be split %d ways%s", (long long)p->ws_channels, lanes,
+                p->paired ? " into whole pairs" : "");
   int rc = ctx_bind(p->ctx);
   if (rc) return rc;
   if ((rc = plan_sync_lanes(p))) return rc;
@@ -1271,7 +1422,8 @@ extern "C" int imp_plan_debug_run_stage(imp_plan* p, const float* x, int64_t B, 
   HIP_TRY(hipMemcpy2DAsync(p->d_in, (size_t)pin * sizeof(float), x, (size_t)ld_in * sizeof(float),
                            (size_t)p->L * sizeof(float), (size_t)B, hipMemcpyHostToDevice, s));
   if ((rc = run_group(p, p->d_in, B, pin, 1, p->d_out, pout, 0, stage))) return rc;
-  HIP_TRY(hipMemcpyAsync(ws_out_host, p->ws, (size_t)B * p->N1 * imp::kN2 * sizeof(cf), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(ws_out_host, p->ws, (size_t)(p->paired ? (B + 1) / 2 : B) * p->N1 * imp::kN2 * sizeof(cf),
+                         hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return IMP_OK;
 }
@@ -1373,8 +1525,9 @@ struct imp_chain {
   int64_t B = 0, n = 0, head = 0, fade_in = 0, fade_out = 0, pitch_ir = 0;
   double peak_height = 0.12589;
   float* d_ir = nullptr;            // [B][pitch_ir]: the deconvolved columns
-  unsigned* d_tile = nullptr;       // [B][column tiles][N1 of the deconvolution]: max|y| per tile and row, left by pass C
+  unsigned* d_tile = nullptr;       // [B][column tiles][chunks]: max|y| per tile and 8 192-sample chunk, left by pass C
   int tiles = 0;
+  int64_t chunks = 0;               // chunks per channel: N1 of the deconvolution (pair mode: N1 / 2)
   imp::RowPeak* d_res = nullptr;
   int64_t* d_meta = nullptr;        // off[B], len[B]
 };
@@ -1403,6 +1556,7 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
   if (deconv->lanes != 1 || fir->lanes != 1) return fail(IMP_ERR_INVALID, "imp_chain_create: plans must run in stream order (lanes = 1)");
   if (deconv->ola || fir->ola || deconv->resident || fir->resident)
     return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: overlap-add and XCD-resident plans cannot be chained");
+  if (fir->paired) return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: the FIR stage reads one response per transform (mono plan)");
   const int64_t n = fir->L;
   if (B < 1 || B > deconv->ws_channels || B > fir->ws_channels) return fail(IMP_ERR_INVALID, "imp_chain_create: B exceeds a plan's workspace");
   if (fir->n_filters > 1 && B > fir->n_filters) return fail(IMP_ERR_INVALID, "imp_chain_create: fewer FIRs than channels");
@@ -1433,7 +1587,8 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
     return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: deconvolution plan of %d rows", deconv->N1);
   }
   c->tiles = plan_col_tiles(deconv);
-  const size_t chunk_bytes = (size_t)(B * deconv->N1) * sizeof(unsigned);
+  c->chunks = deconv->paired ? deconv->N1 / 2 : deconv->N1;
+  const size_t chunk_bytes = (size_t)(B * c->chunks) * sizeof(unsigned);
   if (hipMalloc((void**)&c->d_ir, (size_t)(B * c->pitch_ir) * sizeof(float)) != hipSuccess ||
       hipMalloc((void**)&c->d_tile, chunk_bytes * (size_t)c->tiles) != hipSuccess ||
       hipMalloc((void**)&c->d_res, (size_t)B * sizeof(imp::RowPeak)) != hipSuccess ||
@@ -1465,7 +1620,7 @@ extern "C" int imp_chain_execute_device(imp_chain* c, const float* d_x, int64_t 
   if (rc) return rc;
   hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)c->B), dim3(imp::kPeakThreads), 0, s, c->d_ir, c->d_meta,
                      c->d_meta + c->B, c->deconv->out_start, (const unsigned*)c->d_tile, c->tiles, (const unsigned*)nullptr,
-                     (int64_t)c->deconv->N1, c->d_res, c->peak_height, d_peaks_out);
+                     c->chunks, c->d_res, c->peak_height, d_peaks_out);
   HIP_TRY(hipGetLastError());
   imp::LoadCropAtPeak ld{c->d_ir, c->pitch_ir, c->deconv->out_len, c->d_res, c->n, c->head, c->fade_in, c->fade_out};
   return run_group_with(c->fir, ld, c->B, d_out, chan_stride_out, 0, 2);

@@ -321,6 +321,55 @@ struct StoreRealCropMax {
   }
 };
 
+// The same in pair mode: sample n of BOTH channels sits in point p = n, a four-step row holds 4 096 samples of each channel,
+// and the maxima are kept per channel and per 8 192-sample chunk (two four-step rows): tile_max[channel][tile][n1 / 2].
+__device__ __forceinline__ unsigned* crop_max_lds_r() {
+  __shared__ unsigned rows_r[kMaxPlanRows / 2];
+  return rows_r;
+}
+
+__device__ __forceinline__ int half_wave_max(float m) {      // max over each 32-lane half, valid in lanes 31 / 63
+  int mi = __float_as_int(m);
+  mi = __float_as_int(fmaxf(__int_as_float(mi), __int_as_float(__builtin_amdgcn_update_dpp(0, mi, 0xB1, 0xF, 0xF, true))));
+  mi = __float_as_int(fmaxf(__int_as_float(mi), __int_as_float(__builtin_amdgcn_update_dpp(0, mi, 0x4E, 0xF, 0xF, true))));
+  mi = __float_as_int(fmaxf(__int_as_float(mi), __int_as_float(__builtin_amdgcn_update_dpp(0, mi, 0x141, 0xF, 0xF, true))));
+  mi = __float_as_int(fmaxf(__int_as_float(mi), __int_as_float(__builtin_amdgcn_update_dpp(0, mi, 0x140, 0xF, 0xF, true))));
+  mi = __float_as_int(fmaxf(__int_as_float(mi), __int_as_float(__builtin_amdgcn_update_dpp(0, mi, 0x142, 0xA, 0xF, true))));
+  return mi;
+}
+
+struct StorePairCropMax {
+  StorePairCrop crop;
+  unsigned* __restrict__ tile_max;   // [channels][tiles][n1 / 2]
+  __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind(int p) const { return crop.bind(p); }
+  __device__ __forceinline__ void begin(int tid, int threads) const {
+    unsigned *rl = crop_max_lds(), *rr = crop_max_lds_r();
+    for (int r = tid; r < kMaxPlanRows / 2; r += threads) rl[r] = rr[r] = 0u;
+    __syncthreads();
+  }
+  __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, int p, unsigned e, unsigned step_elems, cf v) const {
+    crop.put(r, p, e, step_elems, v);
+    const unsigned n = e + step_elems;
+    const bool kept = n - (unsigned)crop.start < (unsigned)crop.len;      // wraps out of range below the window
+    const int ml = half_wave_max(kept ? fabsf(v.x) : 0.f), mr = half_wave_max(kept ? fabsf(v.y) : 0.f);
+    if ((threadIdx.x & 31) == 31) {
+      if (ml != 0) atomicMax(crop_max_lds() + (n >> 13), (unsigned)ml);
+      if (mr != 0) atomicMax(crop_max_lds_r() + (n >> 13), (unsigned)mr);
+    }
+  }
+  __device__ __forceinline__ void end(int p, int tile, int tiles, int n1, int tid, int threads) const {
+    __syncthreads();
+    const int chunks = n1 >> 1;
+    const unsigned *rl = crop_max_lds(), *rr = crop_max_lds_r();
+    unsigned* out = tile_max + ((long long)(2 * p) * tiles + tile) * chunks;
+    for (int r = tid; r < chunks; r += threads) out[r] = rl[r];
+    if (2 * p + 1 < crop.nchan) {
+      out += (long long)tiles * chunks;
+      for (int r = tid; r < chunks; r += threads) out[r] = rr[r];
+    }
+  }
+};
+
 // Pass A load of K5 that IS K4: channel b is read from start = clamp(peak - head, 0, row_len - n) of its row, n samples
 // long, with a Hann fade-in of `fade_in` and fade-out of `fade_out` samples (core/impulse_response.py:82-90 crop_head +
 // the fades of core/hrir.py:591-612, :642-651 at a fixed length).  peak = ImpulseResponse.peak_index as K3 left it in

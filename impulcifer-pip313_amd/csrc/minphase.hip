@@ -670,6 +670,20 @@ __global__ __launch_bounds__(256) void alpha_beta_kernel(const cdbl* __restrict_
   ab[(long long)blockIdx.y * Nc + idx] = o;
 }
 
+// pair mode: hs[k1][q*256 + u] = H[k1 + N1 k2] / Nc, k2 = (u >> 4) + 16 (u & 15) + 256 q, over all Nc bins of the
+// Nc-point transform of the real filter; z is its packed (Nc / 2)-point transform, H[Nc - k] = conj H[k]
+__global__ __launch_bounds__(256) void pair_spectrum_kernel(const cdbl* __restrict__ z, float2* __restrict__ hs, int Nc, int N1) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Nc) return;
+  const int k1 = idx >> 12, r = idx & 4095, q = r >> 8, u = r & 255;
+  const int k2 = (u >> 4) + 16 * (u & 15) + 256 * q;
+  const long long k = (long long)k1 + (long long)N1 * k2;
+  const int half = Nc / 2;
+  cdbl H = k <= half ? unpack_bin(z, (int)k, half) : zconj(unpack_bin(z, Nc - (int)k, half));
+  const double inv = 1.0 / (double)Nc;
+  hs[idx] = make_float2((float)(H.x * inv), (float)(H.y * inv));
+}
+
 }  // namespace
 
 void fft_roots_destroy(imp_ctx* ctx) {
@@ -723,5 +737,47 @@ int spectrum_alpha_beta_device(imp_ctx* ctx, const double* filters, int64_t M, i
     // the host rows of this chunk may be reused by the caller after return: drain before the next upload
     if (hipStreamSynchronize(s) != hipSuccess) return cleanup(fail(IMP_ERR_HIP, "filter spectrum: stream error"));
   }
+  return cleanup(IMP_OK);
+}
+
+int spectrum_pair_device(imp_ctx* ctx, const double* filter, int64_t M, int64_t Nc, int N1, cf* d_hs) {
+  if (Nc % 2) return fail(IMP_ERR_UNSUPPORTED, "pair spectrum: odd circular length %lld", (long long)Nc);
+  const int64_t half = Nc / 2;
+  const std::vector<int> fac = factorise((int)half);
+  if (fac.empty()) return fail(IMP_ERR_UNSUPPORTED, "spectrum length %lld is not 2^a 3^b 5^c 11^d", (long long)half);
+  if (M > Nc) return fail(IMP_ERR_INVALID, "filter of %lld taps longer than the circular length %lld", (long long)M, (long long)Nc);
+  hipStream_t s = ctx->stream;
+  cdbl* roots = nullptr;
+  auto it = ctx->fft_roots.find((long long)half);
+  if (it != ctx->fft_roots.end()) {
+    roots = (cdbl*)it->second;
+  } else {
+    HIP_TRY(hipMalloc((void**)&roots, (size_t)half * sizeof(cdbl)));
+    hipLaunchKernelGGL(roots_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, roots, (int)half);
+    HIP_TRY(hipGetLastError());
+    ctx->fft_roots[(long long)half] = roots;
+  }
+  cdbl *a = nullptr, *b = nullptr;
+  double* d_h = nullptr;
+  auto cleanup = [&](int code) {
+    (void)hipStreamSynchronize(s);
+    (void)ctx_block_put(ctx, a);
+    (void)ctx_block_put(ctx, b);
+    (void)ctx_block_put(ctx, d_h);
+    return code;
+  };
+  if (ctx_block_get(ctx, (size_t)half * sizeof(cdbl), (void**)&a) || ctx_block_get(ctx, (size_t)half * sizeof(cdbl), (void**)&b) ||
+      ctx_block_get(ctx, (size_t)M * sizeof(double), (void**)&d_h))
+    return cleanup(fail(IMP_ERR_ALLOC, "device buffers for the pair spectrum (%lld points)", (long long)Nc));
+  if (hipMemcpyAsync(d_h, filter, (size_t)M * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess)
+    return cleanup(fail(IMP_ERR_HIP, "filter upload failed"));
+  hipLaunchKernelGGL(pack_filter_kernel, dim3((unsigned)((half + 255) / 256), 1), dim3(256), 0, s, d_h, a, (long long)M,
+                     (long long)M, (int)half);
+  cdbl *cur = a, *oth = b;
+  int rc = run_fft(ctx, fac, roots, (int)half, 1, -1, &cur, &oth);
+  if (rc) return cleanup(rc);
+  hipLaunchKernelGGL(pair_spectrum_kernel, dim3((unsigned)((Nc + 255) / 256)), dim3(256), 0, s, cur,
+                     reinterpret_cast<float2*>(d_hs), (int)Nc, N1);
+  if (hipGetLastError() != hipSuccess) return cleanup(fail(IMP_ERR_HIP, "pair spectrum launch failed"));
   return cleanup(IMP_OK);
 }

@@ -16,6 +16,7 @@ _DEFAULT_LIB = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libimpulse_hi
 
 IMP_MODE_SAME = 0
 IMP_MODE_FULL = 1
+IMP_ERR_UNSUPPORTED = -3
 
 
 class NativeUnavailable(RuntimeError):
@@ -65,6 +66,10 @@ SIGNATURES = {
     "imp_memset": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
     "imp_conv_plan_create": (C.c_int, [_vp, _pd, _i64, _i64, _i64, _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "imp_conv_plan_create_empty": (C.c_int, [_vp, _i64, _i64, _i64, C.c_int, _i64, C.POINTER(_vp)]),
+    "imp_conv_plan_create_paired": (C.c_int, [_vp, _pd, _i64, _i64, C.c_int, _i64, C.POINTER(_vp)]),
+    "imp_conv_plan_create_empty_paired": (C.c_int, [_vp, _i64, _i64, C.c_int, _i64, C.POINTER(_vp)]),
+    "imp_plan_is_paired": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "imp_conv_execute_device_pairs": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _i64, _vp, _i64]),
     "imp_plan_destroy": (None, [_vp]),
     "imp_plan_info": (C.c_int, [_vp, _pi64, _pi64, _pi64, _pi64]),
     "imp_plan_spectrum": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
@@ -87,6 +92,7 @@ SIGNATURES = {
     "imp_plan_set_timing": (C.c_int, [_vp, C.c_int]),
     "imp_plan_get_timing": (C.c_int, [_vp, _pd, _pi64, C.c_int]),
     "imp_debug_plan_geometry": (C.c_int, [_i64, _i64, C.c_int, _pi64, _pi64, _pi64]),
+    "imp_debug_plan_geometry_paired": (C.c_int, [_i64, _i64, C.c_int, _pi64, _pi64, _pi64, _pi64]),
     "imp_debug_host_spectrum": (C.c_int, [_pd, _i64, C.c_int, _pf]),
     "imp_plan_debug_run_stage": (C.c_int, [_vp, _pf, _i64, _i64, C.c_int, _pf]),
     "imp_segset_create": (C.c_int, [_vp, _pd, _pi64, _pi64, _i64, C.POINTER(_vp), _pd]),
@@ -668,25 +674,47 @@ class Curves:
 class ConvPlan:
     """Batched FFT convolution plan (imp_plan): scipy.signal.convolve(x, h, mode) for fixed (h, L)."""
 
-    def __init__(self, ctx, filt, L, mode="same", ws_channels=0, empty_M=None, n_filters=None):
+    def __init__(self, ctx, filt, L, mode="same", ws_channels=0, empty_M=None, n_filters=None, paired=False):
+        """paired: False = one channel per transform; True = pair mode (two channels per complex transform, one shared
+        filter; NativeError if the lengths need more than 256 rows); "auto" = pair mode where it is available."""
         self._lib = ctx._lib
         self.ctx = ctx
         self.L = int(L)
         self.mode = {"same": IMP_MODE_SAME, "full": IMP_MODE_FULL}[mode]
         h = _vp()
         if filt is None:
-            _check(self._lib.imp_conv_plan_create_empty(ctx.handle, int(empty_M), int(n_filters or 1), self.L,
-                                                        self.mode, int(ws_channels), C.byref(h)))
             self.M = int(empty_M)
             self.n_filters = int(n_filters or 1)
+            f = None
         else:
             f = np.ascontiguousarray(filt, dtype=np.float64)
             if f.ndim == 1:
                 f = f[None, :]
             self.n_filters, self.M = int(f.shape[0]), int(f.shape[1])
-            _check(self._lib.imp_conv_plan_create(ctx.handle, f.ctypes.data_as(_pd), self.M, self.n_filters,
-                                                  self.M, self.L, self.mode, int(ws_channels), C.byref(h)))
+        if paired and self.n_filters == 1 and os.environ.get("IMPULSE_HIP_NO_PAIRS") != "1":
+            if f is None:
+                rc = self._lib.imp_conv_plan_create_empty_paired(ctx.handle, self.M, self.L, self.mode, int(ws_channels),
+                                                                 C.byref(h))
+            else:
+                rc = self._lib.imp_conv_plan_create_paired(ctx.handle, f.ctypes.data_as(_pd), self.M, self.L, self.mode,
+                                                           int(ws_channels), C.byref(h))
+            if rc == IMP_ERR_UNSUPPORTED and paired == "auto":
+                h = _vp()                                     # too long for pair mode: one channel per transform
+            else:
+                _check(rc)
+        elif paired is True:
+            raise ValueError("pair mode needs one shared filter")
+        if not h:
+            if f is None:
+                _check(self._lib.imp_conv_plan_create_empty(ctx.handle, self.M, self.n_filters, self.L, self.mode,
+                                                            int(ws_channels), C.byref(h)))
+            else:
+                _check(self._lib.imp_conv_plan_create(ctx.handle, f.ctypes.data_as(_pd), self.M, self.n_filters,
+                                                      self.M, self.L, self.mode, int(ws_channels), C.byref(h)))
         self._h = h
+        pr = C.c_int(0)
+        _check(self._lib.imp_plan_is_paired(h, C.byref(pr)))
+        self.paired = bool(pr.value)
         ctx._plans.add(self)
         nfft, out_len, wsc, n1 = _i64(), _i64(), _i64(), _i64()
         _check(self._lib.imp_plan_info(self._h, C.byref(nfft), C.byref(out_len), C.byref(wsc), C.byref(n1)))
@@ -731,6 +759,13 @@ class ConvPlan:
     def execute_device_pcm(self, d_pcm, bits, B, chan_stride_in, elem_stride_in, d_y, chan_stride_out):
         _check(self._lib.imp_conv_execute_device_pcm(self._h, _vp(int(d_pcm)), int(bits), int(B), int(chan_stride_in),
                                                      int(elem_stride_in), _vp(int(d_y)), int(chan_stride_out)))
+
+    def execute_device_pairs(self, d_x, bits, n_pairs, pair_stride, right_offset, elem_stride, d_y, chan_stride_out):
+        """pair-mode plans: pair q = samples d_x[q*pair_stride + i*elem_stride] (left) and [... + right_offset] (right);
+        bits 0 = float32, 16 / 32 = PCM; outputs rows 2q, 2q + 1 of d_y"""
+        _check(self._lib.imp_conv_execute_device_pairs(self._h, _vp(int(d_x)), int(bits), int(n_pairs), int(pair_stride),
+                                                       int(right_offset), int(elem_stride), _vp(int(d_y)),
+                                                       int(chan_stride_out)))
 
     def execute_pcm_columns(self, frames, column_starts):
         """frames: interleaved PCM [n_frames, tracks] int16/int32 (WAV wire order).  Deconvolves, for every
@@ -782,7 +817,14 @@ class ConvPlan:
         if any(s0 < 0 or s0 + self.L > n_frames for s0 in starts):
             raise ValueError("column outside the recording")
         step = starts[1] - starts[0] if len(starts) > 1 else 0
-        if len(starts) > 1 and step > 0 and all(b - a == step for a, b in zip(starts, starts[1:])):
+        uniform = len(starts) > 1 and step > 0 and all(b - a == step for a, b in zip(starts, starts[1:]))
+        if self.paired and tracks == 2 and (uniform or len(starts) == 1):
+            # a binaural recording: the two ears of a column are ONE complex signal, a stereo frame is one load, and all
+            # columns go in one launch group (core/hrir.py:326-341: track 0 = left ear, track 1 = right ear)
+            self.execute_device_pairs(d_in + starts[0] * tracks * frames.itemsize, bits, len(starts), step * tracks, 1,
+                                      tracks, d_out, pitch)
+            return
+        if uniform:
             for t in range(tracks):
                 self.execute_device_pcm(d_in + (starts[0] * tracks + t) * frames.itemsize, bits, len(starts),
                                         step * tracks, tracks, d_out + t * pitch * 4, tracks * pitch)
@@ -862,6 +904,18 @@ def plan_geometry(M, L, mode="same"):
     _check(lib.imp_debug_plan_geometry(int(M), int(L), {"same": IMP_MODE_SAME, "full": IMP_MODE_FULL}[mode],
                                        C.byref(a), C.byref(b), C.byref(c)))
     return a.value, b.value, c.value
+
+
+def plan_geometry_paired(M, L, mode="same"):
+    """(nfft, out_start, out_len, n1_rows) of a pair-mode plan, or None where pair mode is not available; needs no GPU."""
+    lib = load_library()
+    a, b, c, d = _i64(), _i64(), _i64(), _i64()
+    rc = lib.imp_debug_plan_geometry_paired(int(M), int(L), {"same": IMP_MODE_SAME, "full": IMP_MODE_FULL}[mode],
+                                            C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+    if rc == IMP_ERR_UNSUPPORTED:
+        return None
+    _check(rc)
+    return a.value, b.value, c.value, d.value
 
 
 def host_spectrum(filt, n1_rows):

@@ -90,8 +90,20 @@ int imp_conv_plan_create(imp_ctx* ctx,
 /* Empty plan whose spectrum is filled later (imp_plan_spectrum + a broadcast from another GPU). */
 int imp_conv_plan_create_empty(imp_ctx* ctx, int64_t M, int64_t n_filters, int64_t L, int mode,
                                int64_t ws_channels, imp_plan** out);
+/* Pair mode (the recording's own layout: core/hrir.py:326-341 hands estimate() the left- and right-ear track of a
+ * speaker, columns of one stereo frame block).  The plan's ONE real filter is shared by all channels, so two channels
+ * travel through one complex transform, z = x_L + i x_R: (x_L + i x_R) (*) h = y_L + i y_R.  Channels (2q, 2q + 1) of
+ * every execute call form pair q (an odd last channel pairs with silence); with interleaved frames the pair is ONE
+ * 8-byte load per sample.  Same entry points, same results to fp32 rounding; the circular length is 4096 * N1 samples
+ * with N1 <= 256 rows (L + M/2 <= 2^20 for 'same'): longer plans return IMP_ERR_UNSUPPORTED and the caller uses
+ * imp_conv_plan_create.  ws_channels counts channels (rounded up to whole pairs). */
+int imp_conv_plan_create_paired(imp_ctx* ctx, const double* filter, int64_t M, int64_t L, int mode,
+                                int64_t ws_channels, imp_plan** out);
+int imp_conv_plan_create_empty_paired(imp_ctx* ctx, int64_t M, int64_t L, int mode, int64_t ws_channels,
+                                      imp_plan** out);
+int imp_plan_is_paired(const imp_plan* plan, int* paired);
 void imp_plan_destroy(imp_plan* plan);
-/* geometry queries */
+/* geometry queries (pair mode: nfft = the circular length in samples = 4096 * n1_rows) */
 int imp_plan_info(const imp_plan* plan, int64_t* nfft, int64_t* out_len, int64_t* ws_channels,
                   int64_t* n1_rows);
 /* Device buffer holding the prepared filter spectrum (alpha/beta planes, fp32).  This is the only
@@ -113,6 +125,14 @@ int imp_conv_execute_device(imp_plan* plan, const float* d_x, int64_t B, int64_t
  * host-side int->float64 conversion and transpose (core/audio_truehd.py:153-185, core/hrir.py:202-219). */
 int imp_conv_execute_device_pcm(imp_plan* plan, const void* d_pcm, int bits, int64_t B, int64_t chan_stride_in,
                                 int64_t elem_stride_in, float* d_y, int64_t chan_stride_out);
+
+/* Pair-mode plans only: n_pairs channel pairs with explicit geometry (bits = 0: float32 samples, 16 / 32: PCM as in
+ * imp_conv_execute_device_pcm).  Sample i of pair q: left at d_x[q*pair_stride + i*elem_stride], right at
+ * d_x[q*pair_stride + right_offset + i*elem_stride] (in samples); outputs d_y[(2q + side)*chan_stride_out + i].
+ * The columns of a binaural recording (core/hrir.py:202-219, :326-341: WAV frames [n][2], speaker q's column starting at
+ * frame s0 + q*step) are pair_stride = 2*step, right_offset = 1, elem_stride = 2: one 8-byte load per stereo frame. */
+int imp_conv_execute_device_pairs(imp_plan* plan, const void* d_x, int bits, int64_t n_pairs, int64_t pair_stride,
+                                  int64_t right_offset, int64_t elem_stride, float* d_y, int64_t chan_stride_out);
 
 /* Overlapped execution of independent launch groups.  With lanes = n > 1 the workspace is split into n
  * private slices and successive launch groups of imp_conv_execute_device - within one call and across
@@ -155,6 +175,9 @@ int imp_plan_get_timing(imp_plan* plan, double ms[3], int64_t* launches, int res
 int imp_debug_plan_geometry(int64_t M, int64_t L, int mode, int64_t* nfft, int64_t* out_start,
                             int64_t* out_len);
 int imp_debug_host_spectrum(const double* filter, int64_t M, int n1_rows, float* ab_out);
+/* the same for a pair-mode plan: nfft = circular length in samples = 4096 * n1_rows; IMP_ERR_UNSUPPORTED beyond 256 rows */
+int imp_debug_plan_geometry_paired(int64_t M, int64_t L, int mode, int64_t* nfft, int64_t* out_start, int64_t* out_len,
+                                   int64_t* n1_rows);
 
 /* debug: copy the workspace of the last launch group to the host (complex64 [chunk][N1][4096]) */
 int imp_plan_debug_run_stage(imp_plan* plan, const float* x, int64_t B, int64_t ld_in, int stage,

@@ -2033,8 +2033,10 @@ def test_write_wav_sweep_sequence_from_device_rows_against_shipped_files(gpu_ctx
     n_frames, n_tracks = (int(v) for v in g["seg_fl_stereo_shape"])
     assert seq.shape == (n_tracks, n_frames)
     rows32 = np.ascontiguousarray(seq, dtype=np.float32)
-    block = DeviceBlock(gpu_ctx, rows32.size)
-    gpu_ctx.h2d(block.ptr, rows32)
+    from impulse_hip import _native
+    dctx = _native.default_context()                      # the context the classes keep their device rows on
+    block = DeviceBlock(dctx, rows32.size)
+    dctx.h2d(block.ptr, rows32)
     h = HRIR(e)
     h.irs = {"FL": {"left": ImpulseResponse.on_device(Row(block, 0, n_frames), 48000),
                     "right": ImpulseResponse.on_device(Row(block, n_frames, n_frames), 48000)}}
