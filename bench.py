@@ -193,7 +193,7 @@ def slice_rate(est, rec, L, reps=3):
                 note="end to end: PCM frames in host memory -> float64 responses in host memory, incl. PCIe; 16 IRs per measurement; not the headline metric")
 
 
-def deconv_fir_leg(dev_index, est, rec, L, pitch, reps=300, lanes=3, per_meas=16):
+def deconv_fir_leg(dev_index, est, rec, L, pitch, reps=300, lanes=3, per_meas=16, paired=False):
     """The metric's "+FIR" on device pointers: 7.1 x 2-ear measurements resident in HBM go through K1 (deconvolution)
     -> K3 (first-peak search) -> K4 (head crop at peak - 1 ms, 0.68 s long, Hann fades, compacted) -> K5 (per-channel
     9 600-tap FIRs whose spectra are cached in the plan) as ONE stream-ordered chain (imp_chain): the crop offsets are taken
@@ -215,21 +215,41 @@ def deconv_fir_leg(dev_index, est, rec, L, pitch, reps=300, lanes=3, per_meas=16
     firs[:, 0] += 1.0
     po = (n + K - 1 + 63) // 64 * 64
 
+    k1_lanes = int(os.environ.get("IMPULSE_BENCH_CHAIN_K1_LANES", "3"))
+    n_inputs = int(os.environ.get("IMPULSE_BENCH_CHAIN_INPUTS", "8"))
+
     class Lane:
+        """one chain: K1 on `k1_lanes` streams of one context, the peak search and K5 on the stream of a second context"""
+
         def __init__(self):
-            self.ctx = Context(dev_index)
-            self.plan1 = ConvPlan(self.ctx, np.asarray(est.inverse_filter, dtype=np.float64), L, "same", ws_channels=B)
-            self.plan5 = ConvPlan(self.ctx, firs, n, "full", ws_channels=B)
+            self.ctx, self.tail = Context(dev_index), Context(dev_index)
+            self.plan1 = ConvPlan(self.ctx, np.asarray(est.inverse_filter, dtype=np.float64), L, "same",
+                                  ws_channels=B * k1_lanes, paired=paired)
+            self.plan1.set_overlap(k1_lanes)
+            self.plan5 = ConvPlan(self.tail, firs, n, "full", ws_channels=B)
             self.chain = FirChain(self.plan1, self.plan5, B, head, head, fade)
-            self.d_x, self.d_out, self.d_pk = self.ctx.malloc(B * pitch * 4), self.ctx.malloc(B * po * 4), self.ctx.malloc(B * 8)
-            self.ctx.h2d(self.d_x, rec)
+            self.d_xs = [self.ctx.malloc(B * pitch * 4) for _ in range(n_inputs)]
+            self.d_outs = [self.ctx.malloc(B * po * 4) for _ in range(k1_lanes + 2)]
+            self.d_pk = self.ctx.malloc(B * 8)
+            for d in self.d_xs:
+                self.ctx.h2d(d, rec)
+            self.k = 0
 
         def once(self):
-            self.chain.execute_device(self.d_x, pitch, self.d_out, po, self.d_pk)
+            self.chain.execute_device(self.d_xs[self.k % n_inputs], pitch, self.d_outs[self.k % len(self.d_outs)], po, self.d_pk)
+            self.last_out = self.d_outs[self.k % len(self.d_outs)]
+            self.k += 1
+
+        def synchronize(self):
+            self.ctx.synchronize()
+            self.tail.synchronize()
 
         def close(self):
-            for p in (self.d_x, self.d_out, self.d_pk):
+            self.synchronize()
+            self.chain.close()
+            for p in self.d_xs + self.d_outs + [self.d_pk]:
                 self.ctx.free(p)
+            self.tail.close()
             self.ctx.close()
 
     team = [Lane() for _ in range(lanes)]
@@ -238,21 +258,36 @@ def deconv_fir_leg(dev_index, est, rec, L, pitch, reps=300, lanes=3, per_meas=16
             for ln in team:
                 ln.once()
         for ln in team:
-            ln.ctx.synchronize()
+            ln.synchronize()
+        feeders = os.environ.get("IMPULSE_BENCH_CHAIN_FEEDERS", "0") == "1"
         t0 = time.perf_counter()
-        for i in range(reps):
-            team[i % lanes].once()
+        if feeders:                                   # one host thread per chain (ctypes drops the GIL during the calls)
+            import threading
+
+            def feed(ln, count):
+                for _ in range(count):
+                    ln.once()
+            ths = [threading.Thread(target=feed, args=(ln, reps // lanes)) for ln in team]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+        else:
+            for i in range(reps):
+                team[i % lanes].once()
+        t_issue = time.perf_counter() - t0
         for ln in team:
-            ln.ctx.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+            ln.synchronize()
+        dt = (time.perf_counter() - t0) / (reps // lanes * lanes)
+        sys.stderr.write(f"[chain] host issue time {t_issue / reps * 1e6:.1f} us per call, total {dt * 1e6:.1f} us per call\n")
         t1 = time.perf_counter()
         for _ in range(100):
             team[0].once()
-        team[0].ctx.synchronize()
+            team[0].synchronize()
         dt_single = (time.perf_counter() - t1) / 100
         y = np.empty((B, po), dtype=np.float32)
         peaks = np.empty(B, dtype=np.int64)
-        team[-1].ctx.d2h(y, team[-1].d_out)
+        team[-1].ctx.d2h(y, team[-1].last_out)
         team[-1].ctx.d2h(peaks, team[-1].d_pk)
     finally:
         for ln in team:

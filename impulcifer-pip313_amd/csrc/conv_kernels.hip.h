@@ -280,6 +280,11 @@ struct StoreRealCropAdd {
 // 8-byte load.  Channel pair p = channels (2p, 2p + 1) of the launch group; an odd last channel pairs with silence.
 // A column thread's point e is SAMPLE e of both channels (not samples 2e, 2e + 1 of one).
 // ---------------------------------------------------------------------------------------------
+// swap with the neighbouring lane (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float lane_swap1(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+}
+
 template <class Sample> struct PairSample;
 template <> struct PairSample<float> {
   static __device__ __forceinline__ float get(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so, float) {
@@ -341,6 +346,24 @@ struct LoadPair {
       const __amdgpu_buffer_rsrc_t r = make_rsrc(pl, len > 0 ? span + (unsigned)sizeof(Sample) : 0u);
 #pragma unroll
       for (int j = 0; j < F; ++j) v[j] = PairSample<Sample>::get2(r, vo, (unsigned)(j * STEP) * es, scale);
+    } else if (elem_stride == 1 && has_r && right_off > 0 && ((unsigned long long)pl % (2 * sizeof(Sample))) == 0 &&
+               (right_off & 1) == 0 && (unsigned long long)(right_off + len) * sizeof(Sample) < 0xFFFFFFFFull) {
+      // planar rows: lanes are consecutive samples, so the even lane of a lane pair fetches x_L[n], x_L[n + 1] and the
+      // odd one x_R[n - 1], x_R[n] as ONE aligned 8-byte load each (both rows through one buffer), then they swap a word
+      const bool odd = (threadIdx.x & 1) != 0;                             // == e0 & 1: tiles start at even columns
+      const __amdgpu_buffer_rsrc_t r = make_rsrc(pl, (unsigned)(right_off + len) * (unsigned)sizeof(Sample));
+      const unsigned n0 = e0 & ~1u;
+      const unsigned vo2 = (n0 + (odd ? (unsigned)right_off : 0u)) * (unsigned)sizeof(Sample);
+      const unsigned ulen = (unsigned)len;
+#pragma unroll
+      for (int j = 0; j < F; ++j) {
+        cf x = PairSample<Sample>::get2(r, vo2, (unsigned)(j * STEP) * (unsigned)sizeof(Sample), scale);
+        const unsigned i0 = n0 + (unsigned)(j * STEP);
+        x.x = i0 < ulen ? x.x : 0.f;                                       // the left row's padding is the right row's head
+        x.y = i0 + 1u < ulen ? x.y : 0.f;
+        const float got = lane_swap1(odd ? x.x : x.y);                     // even lanes receive x_R[n], odd lanes x_L[n]
+        v[j] = odd ? make_float2(got, x.y) : make_float2(x.x, got);
+      }
     } else {
       const __amdgpu_buffer_rsrc_t rl = make_rsrc(pl, len > 0 ? span : 0u);
       const __amdgpu_buffer_rsrc_t rr = make_rsrc(pl + right_off, (has_r && len > 0) ? span : 0u);
@@ -353,8 +376,12 @@ struct LoadPair {
   }
 };
 
-// y_L[n - start] = re, y_R[n - start] = im, window [start, start + len) of the linear convolution; the crop is the range
-// check (StoreRealCrop), an absent right channel an empty range.  A wave writes 256 contiguous bytes per channel.
+// y_L[n - start] = re, y_R[n - start] = im, window [start, start + len) of the linear convolution.  Lanes are consecutive
+// samples, so two neighbouring lanes hold (re, im) of samples n, n + 1 (n even): they swap one word each and the even lane
+// writes y_L[n], y_L[n + 1], the odd lane y_R[n], y_R[n + 1] - ONE 8-byte store per lane and point, 256 contiguous bytes per
+// channel and wave instruction (two 4-byte stores per lane: pass C of C2 34 us instead of 26 us for the mono plan).  Both
+// channels go through one buffer (base = the left row, the right row chan_stride further), so the crop is an explicit
+// range test here, not the hardware's; the samples at the window's two edges take 4-byte stores.
 struct StorePairCrop {
   float* __restrict__ base;
   long long chan_stride;
@@ -362,17 +389,35 @@ struct StorePairCrop {
   long long len;
   int nchan;
   __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind(int p) const {
-    return make_rsrc(base + (long long)(2 * p) * chan_stride, (unsigned)len * 4u);
-  }
-  __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind_r(int p) const {
-    return make_rsrc(base + (long long)(2 * p + 1) * chan_stride, (2 * p + 1 < nchan) ? (unsigned)len * 4u : 0u);
+    const bool has_r = 2 * p + 1 < nchan;
+    return make_rsrc(base + (long long)(2 * p) * chan_stride, (unsigned)((has_r ? chan_stride : 0) + len) * 4u);
   }
   __device__ __forceinline__ void begin(int, int) const {}
   __device__ __forceinline__ void end(int, int, int, int, int, int) const {}
   __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, int p, unsigned e, unsigned step_elems, cf v) const {
-    const unsigned off = (e + step_elems - (unsigned)start) * 4u;      // below the window: wraps out of range
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), r, off, 0u, kStreamAux);
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), bind_r(p), off, 0u, kStreamAux);
+    const unsigned n = e + step_elems;
+#ifdef IMP_EXPERIMENT_FRAMES_OUT
+    // timing experiment only (wrong layout for the callers): the pair's two rows written as one block of stereo frames
+    if (n - (unsigned)start < (unsigned)len) bstore_cf<kStreamAux>(v, r, (n - (unsigned)start) * 8u, 0u);
+    return;
+#endif
+    const bool odd = (threadIdx.x & 1) != 0;                   // == n & 1: tiles start at even columns
+    const float got = lane_swap1(odd ? v.x : v.y);             // even lanes receive re[n + 1], odd lanes im[n - 1]
+    const float w0 = odd ? got : v.x, w1 = odd ? v.y : got;    // the lane's channel at samples n0, n0 + 1
+    const unsigned i0 = (n & ~1u) - (unsigned)start;           // below the window: wraps out of range
+    const unsigned ulen = (unsigned)len;
+    const bool ok0 = i0 < ulen, ok1 = i0 + 1u < ulen;
+    const bool chan_ok = !odd || 2 * p + 1 < nchan;
+    const unsigned off = i0 * 4u + (odd ? (unsigned)chan_stride * 4u : 0u);
+    if (ok0 && ok1 && chan_ok) {
+      u32x2 x;
+      x.x = __float_as_uint(w0);
+      x.y = __float_as_uint(w1);
+      __builtin_amdgcn_raw_buffer_store_b64(x, r, off, 0u, kStreamAux);
+    } else if (chan_ok) {
+      if (ok0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(w0), r, off, 0u, 0);
+      if (ok1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(w1), r, off + 4u, 0u, 0);
+    }
   }
 };
 
@@ -526,10 +571,13 @@ struct MixCfg {
   static constexpr int T = TC * R2;
   static constexpr int G = (F + R2 - 1) / R2;
   static constexpr size_t lds_bytes = sizeof(cf) * F * T;
+  // the 12-wave workgroups of 11 x 12 (pair mode's 132 rows) fit a CU twice only below 81 VGPRs: ask for 6 waves per SIMD
+  // (HIP's second launch-bounds figure is waves per execution unit)
+  static constexpr int min_waves = (T >= 704 && lds_bytes <= 80 * 1024) ? 6 : 1;
 };
 
 template <int F, int R2, int DIR, class Load, class Store>
-__global__ __launch_bounds__((MixCfg<F, R2>::T)) void cols_mixed_kernel(Load ld, Store st, Twiddles tw, int nchan,
+__global__ __launch_bounds__((MixCfg<F, R2>::T), (MixCfg<F, R2>::min_waves)) void cols_mixed_kernel(Load ld, Store st, Twiddles tw, int nchan,
                                                                        int n1_total) {
   using Cfg = MixCfg<F, R2>;
   constexpr int TC = Cfg::TC, T = Cfg::T, G = Cfg::G;
@@ -548,8 +596,11 @@ __global__ __launch_bounds__((MixCfg<F, R2>::T)) void cols_mixed_kernel(Load ld,
 
   // pass A: the four-step twiddles of this thread's outputs are fetched with the inputs, not after the
   // exchange where their latency would sit in front of the stores
+  // (the 12-wave workgroups of 11 x 12 have to stay below 81 VGPRs - MixCfg::min_waves - and fetch them between the
+  // exchange's writes and its barrier instead, when the first stage's registers are free again)
+  constexpr bool kLateTwiddles = Cfg::min_waves > 1;
   cf twd[G][R2];
-  if constexpr (DIR < 0) {
+  auto fetch_twiddles = [&]() {
 #pragma unroll
     for (int i = 0; i < G; ++i) {
       const int ka = g + R2 * i;
@@ -559,11 +610,13 @@ __global__ __launch_bounds__((MixCfg<F, R2>::T)) void cols_mixed_kernel(Load ld,
           twd[i][kb] = bload_cf(r_full, ((unsigned)ka * kN2 + n2) * 8u, (unsigned)(kb * F * kN2) * 8u);
       }
     }
-  }
+  };
+  if constexpr (DIR < 0 && !kLateTwiddles) fetch_twiddles();
   cf v[F];
   cols_first_stage<F, R2, TC, DIR>(ld, tw, r_full, b, g, (unsigned)g * kN2 + n2, v);
 #pragma unroll
   for (int a = 0; a < F; ++a) buf[a * T + tid] = v[a];
+  if constexpr (DIR < 0 && kLateTwiddles) fetch_twiddles();
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < G; ++i) {

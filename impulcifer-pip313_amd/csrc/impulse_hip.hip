@@ -962,6 +962,9 @@ static int run_group_pair(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64
     return fail(IMP_ERR_INVALID, "launch group of %lld channels exceeds the workspace lane (%lld, whole pairs)",
                 (long long)nchan, (long long)lane_channels);
   const int64_t npairs = (nchan + 1) / 2;
+  // the two rows of a pair are written through ONE 32-bit buffer range (StorePairCrop)
+  if ((double)(chan_stride_out + p->out_len) * 4.0 >= 4294967296.0)
+    return fail(IMP_ERR_INVALID, "chan_stride_out %lld: a pair's two output rows must lie within 4 GiB", (long long)chan_stride_out);
   imp::StoreWorkspace stw{p->cur_ws, p->N1};
   if ((rc = timing_event(p, 0))) return rc;
   if ((rc = launch_cols_any<-1>(p, npairs, ld, stw))) return rc;
@@ -1519,27 +1522,51 @@ extern "C" int imp_peak_index(imp_ctx* ctx, const float* x, const int64_t* off, 
 // Chain K1 -> K3 -> K4 -> K5 on one stream without a host round trip ("deconv + FIR" of the metric)
 // ------------------------------------------------------------------------------------------------
 struct imp_chain {
-  imp_ctx* ctx = nullptr;
-  imp_plan* deconv = nullptr;       // K1: 'same' plan of the recording length
+  imp_ctx* ctx = nullptr;           // the deconvolution plan's context
+  imp_ctx* tail_ctx = nullptr;      // the FIR plan's context: its stream carries the peak search and K5 of every call
+  imp_plan* deconv = nullptr;       // K1: 'same' plan of the recording length, one or more lanes
   imp_plan* fir = nullptr;          // K5: 'full' plan of length n with per-channel (or one shared) filters
   int64_t B = 0, n = 0, head = 0, fade_in = 0, fade_out = 0, pitch_ir = 0;
   double peak_height = 0.12589;
-  float* d_ir = nullptr;            // [B][pitch_ir]: the deconvolved columns
-  unsigned* d_tile = nullptr;       // [B][column tiles][chunks]: max|y| per tile and 8 192-sample chunk, left by pass C
+  int lanes = 1;
   int tiles = 0;
   int64_t chunks = 0;               // chunks per channel: N1 of the deconvolution (pair mode: N1 / 2)
-  imp::RowPeak* d_res = nullptr;
+  // one set per lane of the deconvolution plan
+  std::vector<float*> d_ir;         // [B][pitch_ir]: the deconvolved columns
+  std::vector<unsigned*> d_tile;    // [B][column tiles][chunks]: max|y| per tile and 8 192-sample chunk, left by pass C
+  std::vector<imp::RowPeak*> d_res;
+  std::vector<hipEvent_t> k1_done;  // recorded on the lane's stream after pass C
+  std::vector<hipEvent_t> ir_free;  // recorded on the tail stream after K5 has read the lane's buffers
+  std::vector<char> ir_busy;
   int64_t* d_meta = nullptr;        // off[B], len[B]
+};
+
+// both contexts, in address order
+struct ChainLock {
+  std::unique_lock<std::recursive_mutex> a, b;
+  ChainLock(imp_ctx* x, imp_ctx* y) {
+    if (x == y) {
+      a = std::unique_lock<std::recursive_mutex>(x->mu);
+    } else {
+      imp_ctx* lo = x < y ? x : y;
+      imp_ctx* hi = x < y ? y : x;
+      a = std::unique_lock<std::recursive_mutex>(lo->mu);
+      b = std::unique_lock<std::recursive_mutex>(hi->mu);
+    }
+  }
 };
 
 extern "C" void imp_chain_destroy(imp_chain* c) {
   if (!c) return;
-  IMP_CTX_LOCK(c->ctx);
+  ChainLock lk(c->ctx, c->tail_ctx);
   (void)hipSetDevice(c->ctx->device);
-  (void)hipStreamSynchronize(c->ctx->stream);
-  (void)hipFree(c->d_ir);
-  (void)hipFree(c->d_tile);
-  (void)hipFree(c->d_res);
+  (void)plan_sync_lanes(c->deconv);
+  (void)hipStreamSynchronize(c->tail_ctx->stream);
+  for (auto p : c->d_ir) (void)hipFree(p);
+  for (auto p : c->d_tile) (void)hipFree(p);
+  for (auto p : c->d_res) (void)hipFree(p);
+  for (auto e : c->k1_done) (void)hipEventDestroy(e);
+  for (auto e : c->ir_free) (void)hipEventDestroy(e);
   (void)hipFree(c->d_meta);
   delete c;
 }
@@ -1548,26 +1575,32 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
                                 double peak_height, imp_chain** out) {
   if (!deconv || !fir || !out) return fail(IMP_ERR_INVALID, "imp_chain_create: null argument");
   *out = nullptr;
-  if (deconv->ctx != fir->ctx) return fail(IMP_ERR_INVALID, "imp_chain_create: the two plans belong to different contexts");
-  IMP_CTX_LOCK(deconv->ctx);
+  if (deconv->ctx->device != fir->ctx->device) return fail(IMP_ERR_INVALID, "imp_chain_create: the two plans live on different devices");
+  ChainLock lk(deconv->ctx, fir->ctx);
   if (deconv->mode != IMP_MODE_SAME || fir->mode != IMP_MODE_FULL)
     return fail(IMP_ERR_INVALID, "imp_chain_create: needs a 'same' deconvolution plan and a 'full' FIR plan");
   if (!(peak_height > 0.0)) return fail(IMP_ERR_INVALID, "imp_chain_create: peak_height must be positive (got %g)", peak_height);
-  if (deconv->lanes != 1 || fir->lanes != 1) return fail(IMP_ERR_INVALID, "imp_chain_create: plans must run in stream order (lanes = 1)");
+  if (fir->lanes != 1) return fail(IMP_ERR_INVALID, "imp_chain_create: the FIR plan must run in stream order (lanes = 1)");
+  if (deconv->lanes > 1 && deconv->ctx == fir->ctx)
+    return fail(IMP_ERR_INVALID, "imp_chain_create: a deconvolution plan with several lanes needs the FIR plan on a context of its own "
+                                 "(its stream carries the peak search and K5 beside the lanes)");
   if (deconv->ola || fir->ola || deconv->resident || fir->resident)
     return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: overlap-add and XCD-resident plans cannot be chained");
   if (fir->paired) return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: the FIR stage reads one response per transform (mono plan)");
   const int64_t n = fir->L;
-  if (B < 1 || B > deconv->ws_channels || B > fir->ws_channels) return fail(IMP_ERR_INVALID, "imp_chain_create: B exceeds a plan's workspace");
+  if (B < 1 || B > deconv->ws_channels / deconv->lanes || B > fir->ws_channels)
+    return fail(IMP_ERR_INVALID, "imp_chain_create: B exceeds a plan's workspace (per lane)");
   if (fir->n_filters > 1 && B > fir->n_filters) return fail(IMP_ERR_INVALID, "imp_chain_create: fewer FIRs than channels");
   if (n > deconv->out_len || head < 0 || fade_in < 0 || fade_out < 0 || fade_in > n || fade_out > n)
     return fail(IMP_ERR_INVALID, "imp_chain_create: crop of %lld samples with fades %lld / %lld does not fit", (long long)n,
                 (long long)fade_in, (long long)fade_out);
+  if (deconv->N1 > imp::kMaxPlanRows) return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: deconvolution plan of %d rows", deconv->N1);
   int rc = ctx_bind(deconv->ctx);
   if (rc) return rc;
   imp_chain* c = new (std::nothrow) imp_chain();
   if (!c) return fail(IMP_ERR_ALLOC, "out of host memory");
   c->ctx = deconv->ctx;
+  c->tail_ctx = fir->ctx;
   c->deconv = deconv;
   c->fir = fir;
   c->B = B;
@@ -1576,24 +1609,37 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
   c->fade_in = fade_in;
   c->fade_out = fade_out;
   c->peak_height = peak_height;
+  c->lanes = deconv->lanes;
   c->pitch_ir = (deconv->out_len + 63) / 64 * 64;
   std::vector<int64_t> meta((size_t)(2 * B));
   for (int64_t b = 0; b < B; ++b) {
     meta[(size_t)b] = b * c->pitch_ir;
     meta[(size_t)(B + b)] = deconv->out_len;
   }
-  if (deconv->N1 > imp::kMaxPlanRows) {
-    delete c;
-    return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: deconvolution plan of %d rows", deconv->N1);
-  }
   c->tiles = plan_col_tiles(deconv);
   c->chunks = deconv->paired ? deconv->N1 / 2 : deconv->N1;
   const size_t chunk_bytes = (size_t)(B * c->chunks) * sizeof(unsigned);
-  if (hipMalloc((void**)&c->d_ir, (size_t)(B * c->pitch_ir) * sizeof(float)) != hipSuccess ||
-      hipMalloc((void**)&c->d_tile, chunk_bytes * (size_t)c->tiles) != hipSuccess ||
-      hipMalloc((void**)&c->d_res, (size_t)B * sizeof(imp::RowPeak)) != hipSuccess ||
-      hipMalloc((void**)&c->d_meta, (size_t)(2 * B) * sizeof(int64_t)) != hipSuccess ||
-      hipMemcpy(c->d_meta, meta.data(), meta.size() * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) {
+  bool ok = hipMalloc((void**)&c->d_meta, (size_t)(2 * B) * sizeof(int64_t)) == hipSuccess &&
+            hipMemcpy(c->d_meta, meta.data(), meta.size() * sizeof(int64_t), hipMemcpyHostToDevice) == hipSuccess;
+  for (int l = 0; l < c->lanes && ok; ++l) {
+    float* ir = nullptr;
+    unsigned* tile = nullptr;
+    imp::RowPeak* res = nullptr;
+    hipEvent_t e1 = nullptr, e2 = nullptr;
+    ok = hipMalloc((void**)&ir, (size_t)(B * c->pitch_ir) * sizeof(float)) == hipSuccess;
+    if (ir) c->d_ir.push_back(ir);
+    ok = ok && hipMalloc((void**)&tile, chunk_bytes * (size_t)c->tiles) == hipSuccess;
+    if (tile) c->d_tile.push_back(tile);
+    ok = ok && hipMalloc((void**)&res, (size_t)B * sizeof(imp::RowPeak)) == hipSuccess;
+    if (res) c->d_res.push_back(res);
+    ok = ok && hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess;
+    if (e1) c->k1_done.push_back(e1);
+    ok = ok && hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
+    if (e2) c->ir_free.push_back(e2);
+  }
+  c->ir_busy.assign((size_t)c->lanes, 0);
+  if (!ok) {
+    (void)hipGetLastError();
     imp_chain_destroy(c);
     return fail(IMP_ERR_ALLOC, "imp_chain_create: device allocation failed");
   }
@@ -1601,29 +1647,44 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
   return IMP_OK;
 }
 
-// Five launches in stream order: pass A, pass B, pass C (+ chunk maxima), the peak search, then K5 whose pass A reads the
-// cropped, faded responses straight out of the deconvolved columns (LoadCropAtPeak), pass B, pass C.
+// Seven launches per call: pass A, pass B, pass C (+ chunk maxima) on the deconvolution plan's next lane, then - on the FIR
+// plan's stream, ordered behind that lane by an event - the peak search and K5, whose pass A reads the cropped, faded
+// responses straight out of the deconvolved columns (LoadCropAtPeak), pass B, pass C.  The lane's buffers are handed back
+// by a second event, so a later call on the same lane waits for this call's K5 and nothing else does.
 extern "C" int imp_chain_execute_device(imp_chain* c, const float* d_x, int64_t chan_stride_in, int64_t elem_stride_in,
                                         float* d_out, int64_t chan_stride_out, long long* d_peaks_out) {
   if (!c || !d_x || !d_out) return fail(IMP_ERR_INVALID, "imp_chain_execute_device: null argument");
-  IMP_CTX_LOCK(c->ctx);
+  ChainLock lk(c->ctx, c->tail_ctx);
   if (chan_stride_out < c->fir->out_len)
     return fail(IMP_ERR_INVALID, "chan_stride_out %lld < out_len %lld", (long long)chan_stride_out, (long long)c->fir->out_len);
-  if (c->deconv->lanes != 1 || c->fir->lanes != 1 || c->deconv->resident || c->fir->resident)
-    return fail(IMP_ERR_INVALID, "imp_chain_execute_device: a plan was switched to overlapped or resident execution");
+  if (c->deconv->lanes != c->lanes || c->fir->lanes != 1 || c->deconv->resident || c->fir->resident)
+    return fail(IMP_ERR_INVALID, "imp_chain_execute_device: a plan's overlap / resident setting changed since the chain was made");
   int rc = ctx_bind(c->ctx);
   if (rc) return rc;
-  hipStream_t s = c->ctx->stream;
-  c->deconv->tile_max = c->d_tile;
-  rc = imp_conv_execute_device(c->deconv, d_x, c->B, chan_stride_in, elem_stride_in, c->d_ir, c->pitch_ir);
+  const int l = c->lanes > 1 ? (int)(c->deconv->group_counter_lane % c->lanes) : 0;      // the lane run_group will pick
+  hipStream_t lane_stream = l ? c->ctx->side_streams[(size_t)(l - 1)] : c->ctx->stream;
+  hipStream_t tail = c->tail_ctx->stream;
+  if (c->ir_busy[(size_t)l] && tail != lane_stream) HIP_TRY(hipStreamWaitEvent(lane_stream, c->ir_free[(size_t)l], 0));
+  c->deconv->tile_max = c->d_tile[(size_t)l];
+  rc = imp_conv_execute_device(c->deconv, d_x, c->B, chan_stride_in, elem_stride_in, c->d_ir[(size_t)l], c->pitch_ir);
   c->deconv->tile_max = nullptr;
   if (rc) return rc;
-  hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)c->B), dim3(imp::kPeakThreads), 0, s, c->d_ir, c->d_meta,
-                     c->d_meta + c->B, c->deconv->out_start, (const unsigned*)c->d_tile, c->tiles, (const unsigned*)nullptr,
-                     c->chunks, c->d_res, c->peak_height, d_peaks_out);
+  if (c->deconv->cur_stream != lane_stream) return fail(IMP_ERR_HIP, "imp_chain_execute_device: lane bookkeeping out of step");
+  if (tail != lane_stream) {
+    HIP_TRY(hipEventRecord(c->k1_done[(size_t)l], lane_stream));
+    HIP_TRY(hipStreamWaitEvent(tail, c->k1_done[(size_t)l], 0));
+  }
+  hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)c->B), dim3(imp::kPeakThreads), 0, tail, c->d_ir[(size_t)l],
+                     c->d_meta, c->d_meta + c->B, c->deconv->out_start, (const unsigned*)c->d_tile[(size_t)l], c->tiles,
+                     (const unsigned*)nullptr, c->chunks, c->d_res[(size_t)l], c->peak_height, d_peaks_out);
   HIP_TRY(hipGetLastError());
-  imp::LoadCropAtPeak ld{c->d_ir, c->pitch_ir, c->deconv->out_len, c->d_res, c->n, c->head, c->fade_in, c->fade_out};
-  return run_group_with(c->fir, ld, c->B, d_out, chan_stride_out, 0, 2);
+  imp::LoadCropAtPeak ld{c->d_ir[(size_t)l], c->pitch_ir, c->deconv->out_len, c->d_res[(size_t)l], c->n, c->head, c->fade_in, c->fade_out};
+  if ((rc = run_group_with(c->fir, ld, c->B, d_out, chan_stride_out, 0, 2))) return rc;
+  if (tail != lane_stream) {
+    HIP_TRY(hipEventRecord(c->ir_free[(size_t)l], tail));
+    c->ir_busy[(size_t)l] = 1;
+  }
+  return IMP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

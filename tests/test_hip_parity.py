@@ -2195,7 +2195,8 @@ def test_fir_chain_on_every_column_kernel_family(gpu_ctx, L, M, rows, n, K):
 
 def test_chain_and_peak_search_refuse_what_they_cannot_do(gpu_ctx):
     """Loud errors instead of wrong answers: a non-positive peak height (the search works on |x| against one positive
-    threshold), plans that run overlapped, overlap-add plans, the wrong plan modes, a crop longer than the response."""
+    threshold), plans whose overlap setting does not fit the chain, overlap-add plans, the wrong plan modes, a crop longer
+    than the response."""
     from impulse_hip import ConvPlan
     from impulse_hip._native import FirChain, NativeError
     rng = np.random.default_rng(3)
@@ -2217,15 +2218,19 @@ def test_chain_and_peak_search_refuse_what_they_cannot_do(gpu_ctx):
         with pytest.raises(NativeError, match="cannot be chained"):
             FirChain(ola, full, 1, 48, 48, 100)
         same.set_overlap(2)
-        with pytest.raises(NativeError, match="stream order"):
+        with pytest.raises(NativeError, match="context of its own"):       # lanes need the FIR plan on its own context / stream
             FirChain(same, full, 2, 48, 48, 100)
         same.set_overlap(1)
+        full.set_overlap(2)
+        with pytest.raises(NativeError, match="stream order"):
+            FirChain(same, full, 2, 48, 48, 100)
+        full.set_overlap(1)
         chain = FirChain(same, full, 2, 48, 48, 100)
         d_x, d_out = gpu_ctx.malloc(2 * 40000 * 4), gpu_ctx.malloc(2 * 9300 * 4)
         with pytest.raises(NativeError, match="chan_stride_out"):
             chain.execute_device(d_x, 40000, d_out, 9000)           # rows of 9 299 samples do not fit a pitch of 9 000
         same.set_overlap(2)
-        with pytest.raises(NativeError, match="switched to overlapped"):
+        with pytest.raises(NativeError, match="setting changed since the chain was made"):
             chain.execute_device(d_x, 40000, d_out, 9300)
         chain.close()
         gpu_ctx.free(d_x)

@@ -164,7 +164,7 @@ def test_pair_overlapped_lanes_and_many_groups(gpu_ctx):
     from impulse_hip import ConvPlan
     from oracle.scipy_restated import fft_convolve
     rng = np.random.default_rng(9)
-    L, M, B = 50000, 30000, 22
+    L, M, B = 50000, 30000, 24
     h = rng.standard_normal(M) * np.exp(-np.arange(M) / 4000.0)
     x = rng.standard_normal((B, L)).astype(np.float32)
     x[B // 2:] = x[:B // 2]                                          # twins in other launch groups

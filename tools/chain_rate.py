@@ -13,5 +13,5 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 est = bench.make_estimator("c2")
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 rec, L, pitch, _ = bench.synth_recordings(est, B, 0xC2)
-out = bench.deconv_fir_leg(0, est, rec, L, pitch, reps=reps, lanes=lanes)
+out = bench.deconv_fir_leg(0, est, rec, L, pitch, reps=reps, lanes=lanes, paired=os.environ.get("PAIRED", "0") == "1")
 print({k: out[k] for k in ("value", "ms_per_measurement", "one_chain", "parity")}, flush=True)

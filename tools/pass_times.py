@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "impulcifer-pip313_amd"))
 from impulse_hip import Context, ConvPlan  # noqa: E402
 
+PAIRED = os.environ.get("PAIRED", "0") == "1"
 L, M = int(sys.argv[1]), int(sys.argv[2])
 ctx = Context(0)
 rng = np.random.default_rng(0)
@@ -20,7 +21,7 @@ for B in [int(v) for v in sys.argv[3:]]:
     d_y = ctx.malloc(B * pitch * 4 + 256)
     for d in d_x:
         ctx.h2d(d, host)
-    plan = ConvPlan(ctx, h, L, "same", ws_channels=B)
+    plan = ConvPlan(ctx, h, L, "same", ws_channels=B, paired=PAIRED)
     for i in range(40):
         plan.execute_device(d_x[i % 8], B, pitch, d_y, pitch)
     ctx.synchronize()
