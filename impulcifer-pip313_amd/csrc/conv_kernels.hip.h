@@ -131,6 +131,21 @@ struct LoadRealPacked {
     const long long rest = len - first;
     return LoadRealPacked{base + first * elem_stride, chan_stride, elem_stride, rest < maxlen ? rest : maxlen};
   }
+  // fir_block_kernel's view of a channel: (x[s], x[s + 1]) for EVEN s, zero outside [0, len) - s may be negative (the
+  // whole byte offset goes through the VGPR, so a negative one is out of range)
+  struct Row {
+    __amdgpu_buffer_rsrc_t r;
+    unsigned es;                      // bytes between samples
+    __device__ __forceinline__ cf pair_at(long long s) const {
+      if (es == 4u) return bload_cf<kStreamAux>(r, (unsigned)(s * 4), 0u);
+      return make_float2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (unsigned)s * es, 0u, kStreamAux)),
+                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (unsigned)(s + 1) * es, 0u, kStreamAux)));
+    }
+  };
+  __device__ __forceinline__ Row open(int b) const {
+    const unsigned span = len > 0 ? ((unsigned)(len - 1) * (unsigned)elem_stride + 1u) * 4u : 0u;
+    return Row{make_rsrc(base + (long long)b * chan_stride, span), (unsigned)elem_stride * 4u};
+  }
   template <int STEP, int F>
   __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[F]) const {
     const float* p = base + (long long)b * chan_stride;
@@ -173,6 +188,22 @@ struct LoadPcmPacked {
   __device__ __forceinline__ float sample(__amdgpu_buffer_rsrc_t r, unsigned vo, unsigned so) const {
     if constexpr (sizeof(Sample) == 2) return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(r, vo, so, kStreamAux) * scale;
     else return (float)(int)__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, kStreamAux) * scale;
+  }
+  struct Row {                        // see LoadRealPacked::Row
+    __amdgpu_buffer_rsrc_t r;
+    unsigned es;
+    float scale;
+    __device__ __forceinline__ float one(unsigned off) const {
+      if constexpr (sizeof(Sample) == 2) return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0u, kStreamAux) * scale;
+      else return (float)(int)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0u, kStreamAux) * scale;
+    }
+    __device__ __forceinline__ cf pair_at(long long s) const {
+      return make_float2(one((unsigned)s * es), one((unsigned)(s + 1) * es));
+    }
+  };
+  __device__ __forceinline__ Row open(int b) const {
+    const unsigned span = len > 0 ? ((unsigned)(len - 1) * (unsigned)elem_stride + 1u) * (unsigned)sizeof(Sample) : 0u;
+    return Row{make_rsrc(base + (long long)b * chan_stride, span), (unsigned)elem_stride * (unsigned)sizeof(Sample), scale};
   }
   template <int STEP, int F>
   __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[F]) const {
@@ -732,31 +763,17 @@ __device__ unsigned long long g_phase_trace[8192 * 16];
 #define IMP_MARK_WALL(i)
 #endif
 
-// One row pair: workspace slot ws_b, spectrum of channel `chan`; 512 threads, 68 KiB of LDS at `lds`.  WS_AUX / AB_AUX: cache policy of
-// the workspace loads and of the alpha/beta loads (the three-launch path uses the defaults; the XCD-resident path reads
-// the workspace with sc1 because other CUs of the XCD wrote it, and streams alpha/beta with nt).
-template <int WS_AUX, int AB_AUX>
-__device__ __forceinline__ void rows_pair(const RowsArgs& args, const Twiddles& tw, int ws_b, int chan, int pair, cf* lds,
-                                          const int tid) {
-  IMP_MARK_WALL(12);
-  IMP_MARK(0);
-
-  // a wave never straddles the two rows: everything derived from `half` is wave-uniform (SGPRs)
-  const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
-  const int t = tid & 255;
-  const int N1 = args.n1_total;
-  const int rowA = pair;
-  const int rowB = (pair == 0) ? (N1 >> 1) : (N1 - pair);
-  const int k1 = half ? rowB : rowA;
+// The row pass between its loads and its stores: v[j] = row[t + 256 j] in, the filtered, inverse-transformed row out, in
+// the same registers.  `half` (which row of the pair), `pair` and k1 are wave-uniform; lds = the pair's two 34 KiB planes;
+// r_ab = the alpha/beta row of (channel, k1).  Used by rows_pair (rows in the workspace) and by fir_block_kernel (rows that
+// never leave the CU).
+template <int AB_AUX>
+__device__ __forceinline__ void rows_core(cf (&v)[16], cf* lds, const int half, const int pair, const int k1,
+                                          const __amdgpu_buffer_rsrc_t r_ab, const Twiddles& tw, const int t) {
   cf* buf = lds + half * (16 * kRowPad);
-
-  const __amdgpu_buffer_rsrc_t r_row = make_rsrc(args.ws + ((long long)ws_b * N1 + k1) * kN2, kN2 * sizeof(cf));
-  const __amdgpu_buffer_rsrc_t r_ab =
-      make_rsrc(args.ab + (long long)chan * args.ab_chan_stride + (long long)k1 * kN2, kN2 * sizeof(float4));
   const __amdgpu_buffer_rsrc_t r_t1 = make_rsrc(tw.t1, 16 * 256 * sizeof(cf));
   const __amdgpu_buffer_rsrc_t r_t2 = make_rsrc(tw.t2, 16 * 16 * sizeof(cf));
   const __amdgpu_buffer_rsrc_t r_t4 = make_rsrc(tw.t4, 16 * 256 * sizeof(cf));
-
   const int hi4 = t >> 4;   // "ka" of the (ka, x) thread naming
   const int lo4 = t & 15;
   const unsigned vo8 = (unsigned)t * 8u;       // byte offset of element t in a [..][256] cf table / the row
@@ -766,13 +783,10 @@ __device__ __forceinline__ void rows_pair(const RowsArgs& args, const Twiddles& 
   // Every table read below is issued one phase ahead of its use, into whichever of the two register
   // arrays is idle at that point, so its latency hides behind the butterflies / the LDS exchange
   // (phase trace: the four twiddle fetches were ~1 us of exposed latency each).
-  cf v[16], u[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) v[j] = bload_cf<WS_AUX>(r_row, vo8, j * 256 * 8);
+  cf u[16];
 #pragma unroll
   for (int a = 1; a < 16; ++a) u[a] = bload_cf(r_t1, vo8, a * 256 * 8);      // stage-1 twiddles
   IMP_MARK_MEM(1);
-
   // ---- forward FFT4096 ----
   fft16<-1>(v);                                            // over j -> a
 #pragma unroll
@@ -876,6 +890,31 @@ __device__ __forceinline__ void rows_pair(const RowsArgs& args, const Twiddles& 
   for (int a = 0; a < 16; ++a) v[a] = buf[a * kRowPad + t];
   fft16<+1>(v);                                            // over ka -> j
   IMP_MARK(8);
+}
+
+// One row pair: workspace slot ws_b, spectrum of channel `chan`; 512 threads, 68 KiB of LDS at `lds`.  WS_AUX / AB_AUX: cache policy of
+// the workspace loads and of the alpha/beta loads (the three-launch path uses the defaults; the XCD-resident path reads
+// the workspace with sc1 because other CUs of the XCD wrote it, and streams alpha/beta with nt).
+template <int WS_AUX, int AB_AUX>
+__device__ __forceinline__ void rows_pair(const RowsArgs& args, const Twiddles& tw, int ws_b, int chan, int pair, cf* lds,
+                                          const int tid) {
+  IMP_MARK_WALL(12);
+  IMP_MARK(0);
+  // a wave never straddles the two rows: everything derived from `half` is wave-uniform (SGPRs)
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int t = tid & 255;
+  const int N1 = args.n1_total;
+  const int rowA = pair;
+  const int rowB = (pair == 0) ? (N1 >> 1) : (N1 - pair);
+  const int k1 = half ? rowB : rowA;
+  const __amdgpu_buffer_rsrc_t r_row = make_rsrc(args.ws + ((long long)ws_b * N1 + k1) * kN2, kN2 * sizeof(cf));
+  const __amdgpu_buffer_rsrc_t r_ab =
+      make_rsrc(args.ab + (long long)chan * args.ab_chan_stride + (long long)k1 * kN2, kN2 * sizeof(float4));
+  const unsigned vo8 = (unsigned)t * 8u;
+  cf v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = bload_cf<WS_AUX>(r_row, vo8, j * 256 * 8);
+  rows_core<AB_AUX>(v, lds, half, pair, k1, r_ab, tw, t);
 #pragma unroll
   for (int j = 0; j < 16; ++j) bstore_cf<IMP_AUX_ROWS_ST>(v[j], r_row, vo8, j * 256 * 8);
   IMP_MARK_MEM(9);
@@ -985,6 +1024,108 @@ __global__ __launch_bounds__(256, 4) void rows_single_kernel(RowsPairArgs args, 
   fft16<+1>(v);                                            // over ka -> j
 #pragma unroll
   for (int j = 0; j < 16; ++j) bstore_cf<IMP_AUX_ROWS_ST>(v[j], r_row, vo8, j * 256 * 8);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5 as ONE launch: overlap-save blocks that never leave the CU (core/impulse_response.py:110-119 equalize / :126-135
+// convolve, core/parallel_workers.py:9-21: x[n] (*) fir[K], K <= 24 577).  A workgroup of 1024 threads owns one
+// (channel, block): 32 768 input samples starting kp = K - 1 (rounded up to even) before the block's first output, as a
+// four-row four-step transform held in registers and LDS:
+//   load      the thread that will own row k1 reads its 16 columns of ALL four input rows and keeps only output k1 of
+//             the radix-4 column butterfly (x the four-step twiddle): four times the loads (L1 / L2 hits) and a few adds
+//             instead of an exchange
+//   rows      rows_core on the row pairs (0, 2) and (1, 3): forward FFT4096, W = alpha Z + beta conj Z[Nc - k] with the
+//             channel's own alpha/beta planes (those of a 4-row plan), inverse FFT4096
+//   store     rows -> LDS [4][4096] -> inverse radix-4 per column -> the 32 768 - kp valid samples of the block
+// Against the three-launch short plan (8 rows of workspace, three kernels of 128 - 512 small workgroups): no workspace
+// traffic at all, one launch, and the spectrum planes are half as long.
+// ---------------------------------------------------------------------------------------------
+struct FirBlockArgs {
+  const float4* __restrict__ ab;   // [n_filters][4][4096], register order of rows_core
+  long long ab_chan_stride;        // 0: one filter shared by all channels; 4 * 4096: per channel
+  float* __restrict__ out;
+  long long out_stride;            // samples between output rows
+  long long out_start, out_len;    // window of the linear convolution that is kept ('full': 0, L + M - 1)
+  int kp;                          // taps - 1 rounded up to even: samples of history a block starts with
+  int valid;                       // 32768 - kp output samples per block
+  int blocks;                      // blocks per channel in this launch
+  int first_block;                 // the launch's block 0 is block first_block of the convolution ('same': the window starts late)
+  int nchan;
+};
+
+constexpr int kFirBlockPoints = 4 * kN2;                       // complex points of a block
+constexpr size_t kFirBlockLds = sizeof(cf) * 4 * 16 * kRowPad;
+
+template <class Load>
+__global__ __launch_bounds__(1024, 4) void fir_block_kernel(Load ld, FirBlockArgs a, Twiddles tw) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cf* lds = reinterpret_cast<cf*>(smem_raw);
+  // a channel's blocks share its alpha/beta planes: keep them on one XCD (blocks b and b + 8 share an XCD)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int chan = (slot / a.blocks) * 8 + xcd, blk = a.first_block + slot % a.blocks;
+  if (chan >= a.nchan) return;                                 // the grid is padded to eight channels (whole workgroup exits)
+  const int tid = threadIdx.x;
+  const int pairq = __builtin_amdgcn_readfirstlane(tid >> 9);  // 0: rows (0, 2), 1: rows (1, 3)
+  const int half = __builtin_amdgcn_readfirstlane((tid >> 8) & 1);
+  const int t = tid & 255;
+  const int k1 = pairq + 2 * half;
+  const long long s0 = (long long)blk * a.valid - a.kp;        // even: first input sample of the block
+  const __amdgpu_buffer_rsrc_t r_full = make_rsrc(tw.full, 4u * kN2 * 8u);
+  const auto row = ld.open(chan);
+
+  cf v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int n2 = t + 256 * j;
+    const long long s = s0 + 2ll * n2;
+    const cf x0 = row.pair_at(s), x1 = row.pair_at(s + 2ll * kN2), x2 = row.pair_at(s + 4ll * kN2), x3 = row.pair_at(s + 6ll * kN2);
+    // output k1 of the forward 4-point DFT over the rows
+    const cf e = (k1 & 1) ? csub(x0, x2) : cadd(x0, x2);
+    const cf o = (k1 & 1) ? csub(x1, x3) : cadd(x1, x3);
+    cf z;
+    if (k1 == 0) z = cadd(e, o);
+    else if (k1 == 2) z = csub(e, o);
+    else if (k1 == 1) z = cadd_mi(e, o);                       // e - i o
+    else z = cadd_pi(e, o);                                    // e + i o
+    if (k1 != 0) z = cmul(z, bload_cf(r_full, (unsigned)(k1 * kN2 + n2) * 8u, 0u));
+    v[j] = z;
+  }
+  const __amdgpu_buffer_rsrc_t r_ab =
+      make_rsrc(a.ab + (long long)chan * a.ab_chan_stride + (long long)k1 * kN2, kN2 * sizeof(float4));
+  rows_core<0>(v, lds + pairq * (2 * 16 * kRowPad), half, pairq, k1, r_ab, tw, t);
+
+  __syncthreads();                                             // every plane is free
+#pragma unroll
+  for (int j = 0; j < 16; ++j) lds[k1 * kN2 + t + 256 * j] = v[j];
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out + (long long)chan * a.out_stride, (unsigned)a.out_len * 4u);
+  const long long o0 = (long long)blk * a.valid - a.kp - a.out_start;   // output index of the block's position 0
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int n2 = tid + 1024 * c;
+    cf w0 = lds[n2], w1 = lds[kN2 + n2], w2 = lds[2 * kN2 + n2], w3 = lds[3 * kN2 + n2];
+    w1 = cmulc(w1, bload_cf(r_full, (unsigned)(kN2 + n2) * 8u, 0u));
+    w2 = cmulc(w2, bload_cf(r_full, (unsigned)(2 * kN2 + n2) * 8u, 0u));
+    w3 = cmulc(w3, bload_cf(r_full, (unsigned)(3 * kN2 + n2) * 8u, 0u));
+    bfly4<+1>(w0, w1, w2, w3);                                 // samples 2 (n1 4096 + n2), + 1 of the block, n1 = 0..3
+    const cf y[4] = {w0, w1, w2, w3};
+#pragma unroll
+    for (int n1 = 0; n1 < 4; ++n1) {
+      const int pos = 2 * (n1 * kN2 + n2);
+      if (pos < a.kp) continue;                                // the block's history: wrapped-around garbage
+      // the window's two edges fall to the range check (an offset below the window wraps out of range); an odd window
+      // start splits the pair into two 4-byte stores, like StoreRealCrop
+      const unsigned off = (unsigned)((o0 + pos) * 4);
+      if (a.out_start & 1) {
+        unsigned off_im = off + 4u;
+        asm volatile("" : "+v"(off_im));
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[n1].x), r_out, off, 0u, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[n1].y), r_out, off_im, 0u, 0);
+      } else {
+        bstore_cf<kStreamAux>(y[n1], r_out, off, 0u);
+      }
+    }
+  }
 }
 
 }  // namespace imp

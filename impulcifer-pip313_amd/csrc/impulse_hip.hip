@@ -445,6 +445,10 @@ struct imp_plan {
   TwSet tw;
   float4* ab = nullptr;    // [n_filters][N1][4096]
   cf* ws = nullptr;        // [ws_channels][N1][4096] (pair mode: [ws_channels / 2][N1][4096])
+  // fused FIR plan (conv_kernels.hip.h fir_block_kernel): overlap-save blocks of 32 768 samples, one launch, no workspace
+  bool fused = false;
+  int f_kp = 0, f_valid = 0;        // history samples a block starts with (taps - 1, even), outputs per block
+  int64_t f_first = 0, f_blocks = 0; // first block that touches the kept window, blocks per channel
   // pair mode (conv_kernels.hip.h): two channels per transform, z = x_L + i x_R; Nc = nfft = circular length in samples
   bool paired = false;
   cf* hs = nullptr;        // [N1][4096]: H / Nc in the register order of rows_single_kernel
@@ -596,8 +600,11 @@ static int launch_rows_single(imp_plan* p, int64_t npairs) {
   return IMP_OK;
 }
 
+// taps a fused FIR plan takes: a block then still yields 8 191 or more of its 32 768 samples
+static constexpr int64_t kFusedMaxTaps = 24577;
+
 static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, int mode, int64_t ws_channels,
-                         bool paired = false) {
+                         bool paired = false, bool allow_fused = true) {
   if (M < 1 || L < 1) return fail(IMP_ERR_INVALID, "M and L must be >= 1 (M=%lld L=%lld)", (long long)M, (long long)L);
   if (n_filters < 1) return fail(IMP_ERR_INVALID, "n_filters must be >= 1");
   if (mode != IMP_MODE_SAME && mode != IMP_MODE_FULL) return fail(IMP_ERR_INVALID, "mode must be IMP_MODE_SAME or IMP_MODE_FULL");
@@ -615,6 +622,31 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
       {16, 8, false}, {11, 12, true}, {16, 9, false}, {16, 10, false}, {16, 12, false}, {16, 16, false}};
   const int64_t samples_per_row = paired ? imp::kN2 : 2 * imp::kN2;
   if (paired && n_filters != 1) return fail(IMP_ERR_INVALID, "pair mode needs ONE filter shared by both channels of a pair");
+  // Short filters (every FIR of the path: 9 600 taps at 48 kHz, 19 200 at 96 kHz): one launch of overlap-save blocks that stay
+  // in a CU's registers and LDS instead of a three-launch transform over the whole input (IMPULSE_HIP_NO_FUSED_FIR=1 or
+  // imp_conv_plan_create_ex(..., IMP_PLAN_NO_FUSED) keep the three-launch plan)
+  p->fused = allow_fused && !paired && M <= kFusedMaxTaps && std::getenv("IMPULSE_HIP_NO_FUSED_FIR") == nullptr;
+  if (p->fused) {
+    p->ola = false;
+    p->paired = false;
+    p->L = L;
+    p->M = M;
+    p->n_filters = n_filters;
+    p->mode = mode;
+    p->R2 = 1;
+    p->F = 4;
+    p->N1 = 4;
+    p->Nc = 4 * imp::kN2;
+    p->nfft = 2 * p->Nc;
+    p->out_start = mode == IMP_MODE_SAME ? (M - 1) / 2 : 0;
+    p->out_len = mode == IMP_MODE_SAME ? L : full;
+    p->f_kp = (int)((M - 1 + 1) & ~(int64_t)1);
+    p->f_valid = (int)(p->nfft - p->f_kp);
+    p->f_first = p->out_start / p->f_valid;
+    p->f_blocks = (p->out_start + p->out_len - 1) / p->f_valid - p->f_first + 1;
+    p->ws_channels = ws_channels > 0 ? ws_channels : 64;
+    return IMP_OK;
+  }
   int r2 = 0, f1 = 16;
   const char* min_rows_env = std::getenv("IMPULSE_HIP_MIN_ROWS");             // experiments: 16 = the round-1 smallest plan
   const int min_rows = min_rows_env ? atoi(min_rows_env) : 0;
@@ -687,7 +719,7 @@ static int plan_alloc(imp_plan* p) {
   if (p->paired) e = hipMalloc((void**)&p->hs, plane * sizeof(cf));
   else e = hipMalloc((void**)&p->ab, plane * (size_t)(p->n_filters * p->ola_parts) * sizeof(float4));
   if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(spectrum): %s", hipGetErrorString(e));
-  e = hipMalloc((void**)&p->ws, plane * (size_t)(p->paired ? p->ws_channels / 2 : p->ws_channels) * sizeof(cf));
+  e = hipMalloc((void**)&p->ws, p->fused ? 256 : plane * (size_t)(p->paired ? p->ws_channels / 2 : p->ws_channels) * sizeof(cf));
   if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(workspace): %s", hipGetErrorString(e));
   return IMP_OK;
 }
@@ -715,14 +747,14 @@ extern "C" void imp_plan_destroy(imp_plan* p) {
 }
 
 static int plan_create_empty_impl(imp_ctx* ctx, int64_t M, int64_t n_filters, int64_t L, int mode, int64_t ws_channels,
-                                  bool paired, imp_plan** out) {
+                                  bool paired, imp_plan** out, bool allow_fused = true) {
   if (!ctx || !out) return fail(IMP_ERR_INVALID, "imp_conv_plan_create_empty: null argument");
   IMP_CTX_LOCK(ctx);
   *out = nullptr;
   imp_plan* p = new (std::nothrow) imp_plan();
   if (!p) return fail(IMP_ERR_ALLOC, "out of host memory");
   p->ctx = ctx;
-  int rc = plan_geometry(p, M, n_filters, L, mode, ws_channels, paired);
+  int rc = plan_geometry(p, M, n_filters, L, mode, ws_channels, paired, allow_fused);
   if (!rc) rc = plan_alloc(p);
   if (rc) {
     imp_plan_destroy(p);
@@ -778,13 +810,13 @@ static int plan_fill_spectrum(imp_plan* p, const double* filter, int64_t filter_
 }
 
 static int plan_create_impl(imp_ctx* ctx, const double* filter, int64_t M, int64_t n_filters, int64_t filter_ld, int64_t L,
-                            int mode, int64_t ws_channels, bool paired, imp_plan** out) {
+                            int mode, int64_t ws_channels, bool paired, imp_plan** out, bool allow_fused = true) {
   if (!ctx || !out) return fail(IMP_ERR_INVALID, "imp_conv_plan_create: null argument");
   if (!filter) return fail(IMP_ERR_INVALID, "imp_conv_plan_create: null filter");
   IMP_CTX_LOCK(ctx);
   if (n_filters > 1 && filter_ld < M) return fail(IMP_ERR_INVALID, "filter_ld < M");
   imp_plan* p = nullptr;
-  int rc = plan_create_empty_impl(ctx, M, n_filters, L, mode, ws_channels, paired, &p);
+  int rc = plan_create_empty_impl(ctx, M, n_filters, L, mode, ws_channels, paired, &p, allow_fused);
   if (rc) return rc;
   if ((rc = plan_fill_spectrum(p, filter, filter_ld))) {
     imp_plan_destroy(p);
@@ -803,6 +835,21 @@ extern "C" int imp_conv_plan_create(imp_ctx* ctx, const double* filter, int64_t 
 extern "C" int imp_conv_plan_create_paired(imp_ctx* ctx, const double* filter, int64_t M, int64_t L, int mode,
                                            int64_t ws_channels, imp_plan** out) {
   return plan_create_impl(ctx, filter, M, 1, M, L, mode, ws_channels, true, out);
+}
+
+extern "C" int imp_conv_plan_create_ex(imp_ctx* ctx, const double* filter, int64_t M, int64_t n_filters, int64_t filter_ld,
+                                       int64_t L, int mode, int64_t ws_channels, int flags, imp_plan** out) {
+  if (flags & ~(IMP_PLAN_PAIRED | IMP_PLAN_NO_FUSED)) return fail(IMP_ERR_INVALID, "imp_conv_plan_create_ex: unknown flag bits %d", flags);
+  const bool paired = (flags & IMP_PLAN_PAIRED) != 0;
+  if (paired && n_filters != 1) return fail(IMP_ERR_INVALID, "pair mode needs ONE filter shared by both channels of a pair");
+  if (!filter) return plan_create_empty_impl(ctx, M, n_filters, L, mode, ws_channels, paired, out, !(flags & IMP_PLAN_NO_FUSED));
+  return plan_create_impl(ctx, filter, M, n_filters, filter_ld, L, mode, ws_channels, paired, out, !(flags & IMP_PLAN_NO_FUSED));
+}
+
+extern "C" int imp_plan_kind(const imp_plan* p, int* kind) {
+  if (!p || !kind) return fail(IMP_ERR_INVALID, "imp_plan_kind: null argument");
+  *kind = p->fused ? 2 : p->paired ? 1 : 0;
+  return IMP_OK;
 }
 
 extern "C" int imp_plan_is_paired(const imp_plan* p, int* paired) {
@@ -824,11 +871,26 @@ extern "C" int imp_plan_set_filters(imp_plan* p, const double* filter, int64_t f
 extern "C" int imp_debug_plan_geometry(int64_t M, int64_t L, int mode, int64_t* nfft, int64_t* out_start,
                                        int64_t* out_len) {
   imp_plan tmp;
-  int rc = plan_geometry(&tmp, M, 1, L, mode, 1);
+  int rc = plan_geometry(&tmp, M, 1, L, mode, 1, false, false);      // the three-launch geometry
   if (rc) return rc;
   if (nfft) *nfft = tmp.nfft;
   if (out_start) *out_start = tmp.out_start;
   if (out_len) *out_len = tmp.out_len;
+  return IMP_OK;
+}
+
+extern "C" int imp_debug_plan_geometry_fused(int64_t M, int64_t L, int mode, int64_t* history, int64_t* valid,
+                                             int64_t* first_block, int64_t* blocks) {
+  if (M > kFusedMaxTaps) return fail(IMP_ERR_UNSUPPORTED, "a fused FIR plan takes at most %lld taps (got %lld)",
+                                     (long long)kFusedMaxTaps, (long long)M);
+  imp_plan tmp;
+  int rc = plan_geometry(&tmp, M, 1, L, mode, 1, false, true);
+  if (rc) return rc;
+  if (!tmp.fused) return fail(IMP_ERR_UNSUPPORTED, "fused FIR plans are switched off (IMPULSE_HIP_NO_FUSED_FIR)");
+  if (history) *history = tmp.f_kp;
+  if (valid) *valid = tmp.f_valid;
+  if (first_block) *first_block = tmp.f_first;
+  if (blocks) *blocks = tmp.f_blocks;
   return IMP_OK;
 }
 
@@ -950,6 +1012,31 @@ template <class Load>
 static int run_group_with(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64_t chan_stride_out,
                           int64_t first_chan, int last_stage);
 
+template <class Load>
+static int launch_fir_block(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64_t chan_stride_out, int64_t first_chan) {
+  auto kern = imp::fir_block_kernel<Load>;
+  int rc = ctx_kernel_lds(p->ctx, reinterpret_cast<const void*>(kern), imp::kFirBlockLds);
+  if (rc) return rc;
+  const int64_t plane = (int64_t)4 * imp::kN2;
+  imp::FirBlockArgs a;
+  a.ab = p->ab + (p->n_filters > 1 ? first_chan * plane : 0);
+  a.ab_chan_stride = p->n_filters > 1 ? plane : 0;
+  a.out = d_y;
+  a.out_stride = chan_stride_out;
+  a.out_start = p->out_start;
+  a.first_block = (int)p->f_first;
+  a.out_len = p->out_len;
+  a.kp = p->f_kp;
+  a.valid = p->f_valid;
+  a.blocks = (int)p->f_blocks;
+  a.nchan = (int)nchan;
+  imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
+  dim3 grid((unsigned)((nchan + 7) / 8 * 8 * p->f_blocks)), block(1024);
+  hipLaunchKernelGGL(kern, grid, block, imp::kFirBlockLds, p->cur_stream, ld, a, tw);
+  HIP_TRY(hipGetLastError());
+  return IMP_OK;
+}
+
 // one launch group in pair mode: channels (2q, 2q + 1) of the group share a transform; ld.nchan = nchan
 template <class Load>
 static int run_group_pair(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64_t chan_stride_out, int last_stage) {
@@ -1008,6 +1095,15 @@ static int run_group_with(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64
   if (p->n_filters > 1 && first_chan + nchan > p->n_filters)
     return fail(IMP_ERR_INVALID, "channel %lld has no filter: the plan holds %lld per-channel filters",
                 (long long)(first_chan + nchan - 1), (long long)p->n_filters);
+  if (p->fused) {
+    if (last_stage < 2) return fail(IMP_ERR_UNSUPPORTED, "debug stages are not available on fused FIR plans");
+    if (p->tile_max) return fail(IMP_ERR_UNSUPPORTED, "a fused FIR plan leaves no chunk maxima");
+    if ((rc = timing_event(p, 0))) return rc;
+    if ((rc = launch_fir_block(p, ld, nchan, d_y, chan_stride_out, first_chan))) return rc;
+    for (int slot = 1; slot <= 3; ++slot)
+      if ((rc = timing_event(p, slot))) return rc;              // the one launch is reported as "pass A"
+    return IMP_OK;
+  }
   imp::StoreWorkspace stw{p->cur_ws, p->N1};
   if (p->ola) {
     if (last_stage < 2) return fail(IMP_ERR_UNSUPPORTED, "debug stages are not available on overlap-add plans");
@@ -1587,6 +1683,7 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
   if (deconv->ola || fir->ola || deconv->resident || fir->resident)
     return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: overlap-add and XCD-resident plans cannot be chained");
   if (fir->paired) return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: the FIR stage reads one response per transform (mono plan)");
+  if (deconv->fused) return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: a fused FIR plan cannot be the deconvolution stage");
   const int64_t n = fir->L;
   if (B < 1 || B > deconv->ws_channels / deconv->lanes || B > fir->ws_channels)
     return fail(IMP_ERR_INVALID, "imp_chain_create: B exceeds a plan's workspace (per lane)");

@@ -387,6 +387,35 @@ struct LoadCropAtPeak {
     if (fade_out > 0 && i >= n - fade_out && i < n) g *= hann_sym_fwd(fade_out + (i - (n - fade_out)), 2 * fade_out);
     return (float)((double)x * g);
   }
+  struct Row {                        // fir_block_kernel's view of a channel (see LoadRealPacked::Row)
+    __amdgpu_buffer_rsrc_t r;
+    long long n, fade_in, fade_out;
+    __device__ __forceinline__ float shaped(float x, long long i) const {
+      double g = 1.0;
+      if (i < fade_in) g *= hann_sym_fwd(i, 2 * fade_in);
+      if (fade_out > 0 && i >= n - fade_out && i < n) g *= hann_sym_fwd(fade_out + (i - (n - fade_out)), 2 * fade_out);
+      return (float)((double)x * g);
+    }
+    __device__ __forceinline__ cf pair_at(long long s) const {
+      cf v = bload_cf<0>(r, (unsigned)(s * 4), 0u);
+      if (s >= 0 && (s < fade_in || s + 1 >= n - fade_out)) {      // only the two ends pay for the window
+        v.x = shaped(v.x, s);
+        v.y = shaped(v.y, s + 1);
+      }
+      return v;
+    }
+  };
+  __device__ __forceinline__ Row open(int b) const {
+    const RowPeak rp = res[b];
+    long long pk;
+    if (row_len == 0 || !(__uint_as_float(rp.maxabs_bits) >= 1e-20f)) pk = 0;
+    else pk = (long long)(rp.first_peak != ~0ull ? rp.first_peak : rp.first_max);
+    long long start = pk - head;
+    if (start > row_len - n) start = row_len - n;
+    if (start < 0) start = 0;
+    const long long avail = row_len - start;
+    return Row{make_rsrc(base + (long long)b * chan_stride + start, (unsigned)(avail < n ? avail : n) * 4u), n, fade_in, fade_out};
+  }
   template <int STEP, int F>
   __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[F]) const {
     const RowPeak rp = res[b];

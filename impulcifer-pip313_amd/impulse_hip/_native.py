@@ -69,6 +69,8 @@ SIGNATURES = {
     "imp_conv_plan_create_paired": (C.c_int, [_vp, _pd, _i64, _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "imp_conv_plan_create_empty_paired": (C.c_int, [_vp, _i64, _i64, C.c_int, _i64, C.POINTER(_vp)]),
     "imp_plan_is_paired": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "imp_conv_plan_create_ex": (C.c_int, [_vp, _pd, _i64, _i64, _i64, _i64, C.c_int, _i64, C.c_int, C.POINTER(_vp)]),
+    "imp_plan_kind": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "imp_conv_execute_device_pairs": (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _i64, _vp, _i64]),
     "imp_plan_destroy": (None, [_vp]),
     "imp_plan_info": (C.c_int, [_vp, _pi64, _pi64, _pi64, _pi64]),
@@ -92,6 +94,7 @@ SIGNATURES = {
     "imp_plan_set_timing": (C.c_int, [_vp, C.c_int]),
     "imp_plan_get_timing": (C.c_int, [_vp, _pd, _pi64, C.c_int]),
     "imp_debug_plan_geometry": (C.c_int, [_i64, _i64, C.c_int, _pi64, _pi64, _pi64]),
+    "imp_debug_plan_geometry_fused": (C.c_int, [_i64, _i64, C.c_int, _pi64, _pi64, _pi64, _pi64]),
     "imp_debug_plan_geometry_paired": (C.c_int, [_i64, _i64, C.c_int, _pi64, _pi64, _pi64, _pi64]),
     "imp_debug_host_spectrum": (C.c_int, [_pd, _i64, C.c_int, _pf]),
     "imp_plan_debug_run_stage": (C.c_int, [_vp, _pf, _i64, _i64, C.c_int, _pf]),
@@ -674,9 +677,10 @@ class Curves:
 class ConvPlan:
     """Batched FFT convolution plan (imp_plan): scipy.signal.convolve(x, h, mode) for fixed (h, L)."""
 
-    def __init__(self, ctx, filt, L, mode="same", ws_channels=0, empty_M=None, n_filters=None, paired=False):
+    def __init__(self, ctx, filt, L, mode="same", ws_channels=0, empty_M=None, n_filters=None, paired=False, fused=True):
         """paired: False = one channel per transform; True = pair mode (two channels per complex transform, one shared
-        filter; NativeError if the lengths need more than 256 rows); "auto" = pair mode where it is available."""
+        filter; NativeError if the lengths need more than 256 rows); "auto" = pair mode where it is available.
+        fused: False keeps the three-launch transform for filters short enough for the fused overlap-save kernel."""
         self._lib = ctx._lib
         self.ctx = ctx
         self.L = int(L)
@@ -705,16 +709,13 @@ class ConvPlan:
         elif paired is True:
             raise ValueError("pair mode needs one shared filter")
         if not h:
-            if f is None:
-                _check(self._lib.imp_conv_plan_create_empty(ctx.handle, self.M, self.n_filters, self.L, self.mode,
-                                                            int(ws_channels), C.byref(h)))
-            else:
-                _check(self._lib.imp_conv_plan_create(ctx.handle, f.ctypes.data_as(_pd), self.M, self.n_filters,
-                                                      self.M, self.L, self.mode, int(ws_channels), C.byref(h)))
+            _check(self._lib.imp_conv_plan_create_ex(ctx.handle, None if f is None else f.ctypes.data_as(_pd), self.M,
+                                                     self.n_filters, self.M, self.L, self.mode, int(ws_channels),
+                                                     0 if fused else 2, C.byref(h)))
         self._h = h
-        pr = C.c_int(0)
-        _check(self._lib.imp_plan_is_paired(h, C.byref(pr)))
-        self.paired = bool(pr.value)
+        kind = C.c_int(0)
+        _check(self._lib.imp_plan_kind(h, C.byref(kind)))
+        self.paired, self.fused = kind.value == 1, kind.value == 2
         ctx._plans.add(self)
         nfft, out_len, wsc, n1 = _i64(), _i64(), _i64(), _i64()
         _check(self._lib.imp_plan_info(self._h, C.byref(nfft), C.byref(out_len), C.byref(wsc), C.byref(n1)))
@@ -904,6 +905,18 @@ def plan_geometry(M, L, mode="same"):
     _check(lib.imp_debug_plan_geometry(int(M), int(L), {"same": IMP_MODE_SAME, "full": IMP_MODE_FULL}[mode],
                                        C.byref(a), C.byref(b), C.byref(c)))
     return a.value, b.value, c.value
+
+
+def plan_geometry_fused(M, L, mode="same"):
+    """(history, valid, first_block, blocks) of a fused FIR plan, or None beyond 24 577 taps; needs no GPU."""
+    lib = load_library()
+    a, b, c, d = _i64(), _i64(), _i64(), _i64()
+    rc = lib.imp_debug_plan_geometry_fused(int(M), int(L), {"same": IMP_MODE_SAME, "full": IMP_MODE_FULL}[mode],
+                                           C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+    if rc == IMP_ERR_UNSUPPORTED:
+        return None
+    _check(rc)
+    return a.value, b.value, c.value, d.value
 
 
 def plan_geometry_paired(M, L, mode="same"):

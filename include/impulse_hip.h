@@ -102,6 +102,18 @@ int imp_conv_plan_create_paired(imp_ctx* ctx, const double* filter, int64_t M, i
 int imp_conv_plan_create_empty_paired(imp_ctx* ctx, int64_t M, int64_t L, int mode, int64_t ws_channels,
                                       imp_plan** out);
 int imp_plan_is_paired(const imp_plan* plan, int* paired);
+/* Fused FIR plans.  A filter of at most 24 577 taps - every FIR of the path: the 9 600- / 19 200-tap equalisation filters of
+ * core/impulse_response.py:110-119, core/hrir.py:858-888 - makes imp_conv_plan_create build a FUSED plan: the convolution
+ * runs as overlap-save blocks of 32 768 samples (taps - 1 of history + up to 23 169 new outputs), each block on one
+ * workgroup that keeps its four-row transform in registers and LDS (fir_block_kernel): ONE launch per group, no workspace.
+ * Same entry points, results and modes; imp_plan_info reports nfft = 32 768, n1_rows = 4.  The general form:
+ * flags = IMP_PLAN_PAIRED (pair mode) | IMP_PLAN_NO_FUSED (keep the three-launch transform over the whole input);
+ * filter = NULL makes an empty plan (imp_conv_plan_create_empty).  imp_plan_kind: 0 three-launch, 1 pair mode, 2 fused. */
+#define IMP_PLAN_PAIRED 1
+#define IMP_PLAN_NO_FUSED 2
+int imp_conv_plan_create_ex(imp_ctx* ctx, const double* filter, int64_t M, int64_t n_filters, int64_t filter_ld,
+                            int64_t L, int mode, int64_t ws_channels, int flags, imp_plan** out);
+int imp_plan_kind(const imp_plan* plan, int* kind);
 void imp_plan_destroy(imp_plan* plan);
 /* geometry queries (pair mode: nfft = the circular length in samples = 4096 * n1_rows) */
 int imp_plan_info(const imp_plan* plan, int64_t* nfft, int64_t* out_len, int64_t* ws_channels,
@@ -175,6 +187,11 @@ int imp_plan_get_timing(imp_plan* plan, double ms[3], int64_t* launches, int res
 int imp_debug_plan_geometry(int64_t M, int64_t L, int mode, int64_t* nfft, int64_t* out_start,
                             int64_t* out_len);
 int imp_debug_host_spectrum(const double* filter, int64_t M, int n1_rows, float* ab_out);
+/* the block geometry of a fused FIR plan: samples of history per block (taps - 1 rounded up to even), outputs per block
+ * (32 768 - history), the first block that reaches the kept window and the number of blocks per channel;
+ * IMP_ERR_UNSUPPORTED beyond 24 577 taps.  imp_debug_plan_geometry always reports the three-launch geometry. */
+int imp_debug_plan_geometry_fused(int64_t M, int64_t L, int mode, int64_t* history, int64_t* valid, int64_t* first_block,
+                                  int64_t* blocks);
 /* the same for a pair-mode plan: nfft = circular length in samples = 4096 * n1_rows; IMP_ERR_UNSUPPORTED beyond 256 rows */
 int imp_debug_plan_geometry_paired(int64_t M, int64_t L, int mode, int64_t* nfft, int64_t* out_start, int64_t* out_len,
                                    int64_t* n1_rows);

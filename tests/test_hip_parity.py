@@ -55,15 +55,17 @@ def spec_rel_cropped(y, ref, fs=48000, n=None):
                                  (150000, 80000), (300000, 150000), (420000, 200000), (500000, 300000), (800000, 400000)])
 @pytest.mark.parametrize("mode", ["same", "full"])
 def test_conv_matches_oracle(gpu_ctx, L, M, mode):
+    """the three-launch transform over the whole input (filters short enough for the fused overlap-save kernel are covered
+    on both paths: tests/test_fused_fir.py)"""
     from impulse_hip import ConvPlan
     from oracle.scipy_restated import fft_convolve
     rng = np.random.default_rng(L * 31 + M)
     x = rng.standard_normal((3, L)).astype(np.float32)
     x[2] = 0.0                                                   # an all-zero (silent) channel
     h = rng.standard_normal(M) * np.exp(-np.arange(M) / max(M / 5.0, 1.0))
-    plan = ConvPlan(gpu_ctx, h, L, mode)
+    plan = ConvPlan(gpu_ctx, h, L, mode, fused=False)
     from impulse_hip._native import plan_geometry
-    assert plan.nfft == plan_geometry(M, L, mode)[0]
+    assert plan.nfft == plan_geometry(M, L, mode)[0] and not plan.fused
     y = plan.execute(x)
     plan.close()
     assert y.shape == (3, L if mode == "same" else L + M - 1)
