@@ -136,8 +136,9 @@ struct LoadRealPacked {
   struct Row {
     __amdgpu_buffer_rsrc_t r;
     unsigned es;                      // bytes between samples
-    __device__ __forceinline__ cf pair_at(long long s) const {
-      if (es == 4u) return bload_cf<kStreamAux>(r, (unsigned)(s * 4), 0u);
+    __device__ __forceinline__ cf finish(cf v, int) const { return v; }
+    __device__ __forceinline__ cf pair_at(int s) const {               // |s| < 2^29: fused plans stop there
+      if (es == 4u) return bload_cf<kStreamAux>(r, (unsigned)s * 4u, 0u);
       return make_float2(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (unsigned)s * es, 0u, kStreamAux)),
                          __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (unsigned)(s + 1) * es, 0u, kStreamAux)));
     }
@@ -197,7 +198,8 @@ struct LoadPcmPacked {
       if constexpr (sizeof(Sample) == 2) return (float)(short)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0u, kStreamAux) * scale;
       else return (float)(int)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0u, kStreamAux) * scale;
     }
-    __device__ __forceinline__ cf pair_at(long long s) const {
+    __device__ __forceinline__ cf finish(cf v, int) const { return v; }
+    __device__ __forceinline__ cf pair_at(int s) const {
       return make_float2(one((unsigned)s * es), one((unsigned)(s + 1) * es));
     }
   };
@@ -767,7 +769,7 @@ __device__ unsigned long long g_phase_trace[8192 * 16];
 // the same registers.  `half` (which row of the pair), `pair` and k1 are wave-uniform; lds = the pair's two 34 KiB planes;
 // r_ab = the alpha/beta row of (channel, k1).  Used by rows_pair (rows in the workspace) and by fir_block_kernel (rows that
 // never leave the CU).
-template <int AB_AUX>
+template <int AB_AUX, int AB_PREFETCH = kAbPrefetch>
 __device__ __forceinline__ void rows_core(cf (&v)[16], cf* lds, const int half, const int pair, const int k1,
                                           const __amdgpu_buffer_rsrc_t r_ab, const Twiddles& tw, const int t) {
   cf* buf = lds + half * (16 * kRowPad);
@@ -814,9 +816,9 @@ __device__ __forceinline__ void rows_core(cf (&v)[16], cf* lds, const int half, 
   // thread (ka = hi4, kb1 = lo4) gathers t2 = 0..15
 #pragma unroll
   for (int t2 = 0; t2 < 16; ++t2) v[t2] = buf[hi4 * kRowPad + t2 * 17 + lo4];
-  float4 ab_pre[kAbPrefetch];                              // first half of this thread's alpha/beta, a phase early
+  float4 ab_pre[AB_PREFETCH];                              // first half of this thread's alpha/beta, a phase early
 #pragma unroll
-  for (int q = 0; q < kAbPrefetch; ++q) ab_pre[q] = bload_f4<AB_AUX>(r_ab, vo16, q * 256 * 16);
+  for (int q = 0; q < AB_PREFETCH; ++q) ab_pre[q] = bload_f4<AB_AUX>(r_ab, vo16, q * 256 * 16);
   fft16<-1>(v);                                            // over t2 -> kb2
   __syncthreads();
   IMP_MARK(3);
@@ -857,7 +859,7 @@ __device__ __forceinline__ void rows_core(cf (&v)[16], cf* lds, const int half, 
   // W = alpha Z + beta conj(Z[Nc-k]), in place
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    v[q] = filter_bin(q < kAbPrefetch ? ab_pre[q] : bload_f4<AB_AUX>(r_ab, vo16, q * 256 * 16), v[q], u[q]);
+    v[q] = filter_bin(q < AB_PREFETCH ? ab_pre[q] : bload_f4<AB_AUX>(r_ab, vo16, q * 256 * 16), v[q], u[q]);
   }
   if (dc_lane) v[0] = w_dc;
   IMP_MARK_MEM(5);
@@ -1031,9 +1033,9 @@ __global__ __launch_bounds__(256, 4) void rows_single_kernel(RowsPairArgs args, 
 // convolve, core/parallel_workers.py:9-21: x[n] (*) fir[K], K <= 24 577).  A workgroup of 1024 threads owns one
 // (channel, block): 32 768 input samples starting kp = K - 1 (rounded up to even) before the block's first output, as a
 // four-row four-step transform held in registers and LDS:
-//   load      the thread that will own row k1 reads its 16 columns of ALL four input rows and keeps only output k1 of
-//             the radix-4 column butterfly (x the four-step twiddle): four times the loads (L1 / L2 hits) and a few adds
-//             instead of an exchange
+//   load      four columns per thread (eight loads in flight at a time), radix-4 over the four rows, x the four-step twiddle,
+//             through LDS [4][4096] to the threads that own the rows (a thread reading all four rows of its 16 row-pass
+//             columns instead was 2.5x slower: sixteen dependent round trips to memory)
 //   rows      rows_core on the row pairs (0, 2) and (1, 3): forward FFT4096, W = alpha Z + beta conj Z[Nc - k] with the
 //             channel's own alpha/beta planes (those of a 4-row plan), inverse FFT4096
 //   store     rows -> LDS [4][4096] -> inverse radix-4 per column -> the 32 768 - kp valid samples of the block
@@ -1069,37 +1071,50 @@ __global__ __launch_bounds__(1024, 4) void fir_block_kernel(Load ld, FirBlockArg
   const int half = __builtin_amdgcn_readfirstlane((tid >> 8) & 1);
   const int t = tid & 255;
   const int k1 = pairq + 2 * half;
-  const long long s0 = (long long)blk * a.valid - a.kp;        // even: first input sample of the block
+  const int s0 = blk * a.valid - a.kp;                         // even: first input sample of the block (|s0| < 2^29)
   const __amdgpu_buffer_rsrc_t r_full = make_rsrc(tw.full, 4u * kN2 * 8u);
   const auto row = ld.open(chan);
 
+  // columns n2 = tid + 1024 c: sixteen 8-byte loads and twelve twiddles in flight per thread, radix-4 over the rows,
+  // x the four-step twiddle, then through LDS [4][4096] to the threads that own the rows
   cf v[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int n2 = t + 256 * j;
-    const long long s = s0 + 2ll * n2;
-    const cf x0 = row.pair_at(s), x1 = row.pair_at(s + 2ll * kN2), x2 = row.pair_at(s + 4ll * kN2), x3 = row.pair_at(s + 6ll * kN2);
-    // output k1 of the forward 4-point DFT over the rows
-    const cf e = (k1 & 1) ? csub(x0, x2) : cadd(x0, x2);
-    const cf o = (k1 & 1) ? csub(x1, x3) : cadd(x1, x3);
-    cf z;
-    if (k1 == 0) z = cadd(e, o);
-    else if (k1 == 2) z = csub(e, o);
-    else if (k1 == 1) z = cadd_mi(e, o);                       // e - i o
-    else z = cadd_pi(e, o);                                    // e + i o
-    if (k1 != 0) z = cmul(z, bload_cf(r_full, (unsigned)(k1 * kN2 + n2) * 8u, 0u));
-    v[j] = z;
+  for (int h = 0; h < 2; ++h) {                                // two columns at a time: eight loads + six twiddles in flight
+    cf x[2][4], w[2][3];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int n2 = tid + 1024 * (2 * h + c);
+#pragma unroll
+      for (int n1 = 0; n1 < 4; ++n1) x[c][n1] = row.pair_at(s0 + 2 * (n1 * kN2 + n2));
+#pragma unroll
+      for (int k = 1; k < 4; ++k) w[c][k - 1] = bload_cf(r_full, (unsigned)(k * kN2 + n2) * 8u, 0u);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int n2 = tid + 1024 * (2 * h + c);
+#pragma unroll
+      for (int n1 = 0; n1 < 4; ++n1) x[c][n1] = row.finish(x[c][n1], s0 + 2 * (n1 * kN2 + n2));   // (the chain's fades)
+      bfly4<-1>(x[c][0], x[c][1], x[c][2], x[c][3]);
+      lds[n2] = x[c][0];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) lds[k * kN2 + n2] = cmul(x[c][k], w[c][k - 1]);
+    }
   }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = lds[k1 * kN2 + t + 256 * j];
+  __syncthreads();                                             // rows_core reuses the same LDS
   const __amdgpu_buffer_rsrc_t r_ab =
       make_rsrc(a.ab + (long long)chan * a.ab_chan_stride + (long long)k1 * kN2, kN2 * sizeof(float4));
-  rows_core<0>(v, lds + pairq * (2 * 16 * kRowPad), half, pairq, k1, r_ab, tw, t);
+  // (16 waves per CU leave 128 VGPRs: four alpha/beta bins prefetched instead of the row pass's eight)
+  rows_core<0, 4>(v, lds + pairq * (2 * 16 * kRowPad), half, pairq, k1, r_ab, tw, t);
 
   __syncthreads();                                             // every plane is free
 #pragma unroll
   for (int j = 0; j < 16; ++j) lds[k1 * kN2 + t + 256 * j] = v[j];
   __syncthreads();
   const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out + (long long)chan * a.out_stride, (unsigned)a.out_len * 4u);
-  const long long o0 = (long long)blk * a.valid - a.kp - a.out_start;   // output index of the block's position 0
+  const int o0 = blk * a.valid - a.kp - (int)a.out_start;      // output index of the block's position 0
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int n2 = tid + 1024 * c;
@@ -1115,7 +1130,7 @@ __global__ __launch_bounds__(1024, 4) void fir_block_kernel(Load ld, FirBlockArg
       if (pos < a.kp) continue;                                // the block's history: wrapped-around garbage
       // the window's two edges fall to the range check (an offset below the window wraps out of range); an odd window
       // start splits the pair into two 4-byte stores, like StoreRealCrop
-      const unsigned off = (unsigned)((o0 + pos) * 4);
+      const unsigned off = (unsigned)(o0 + pos) * 4u;
       if (a.out_start & 1) {
         unsigned off_im = off + 4u;
         asm volatile("" : "+v"(off_im));

@@ -626,6 +626,8 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   // in a CU's registers and LDS instead of a three-launch transform over the whole input (IMPULSE_HIP_NO_FUSED_FIR=1 or
   // imp_conv_plan_create_ex(..., IMP_PLAN_NO_FUSED) keep the three-launch plan)
   p->fused = allow_fused && !paired && M <= kFusedMaxTaps && std::getenv("IMPULSE_HIP_NO_FUSED_FIR") == nullptr;
+  if (p->fused && (L >= ((int64_t)1 << 29) || full >= ((int64_t)1 << 29)))
+    return fail(IMP_ERR_UNSUPPORTED, "L = %lld beyond the 2^29 samples one channel's buffer range covers", (long long)L);
   if (p->fused) {
     p->ola = false;
     p->paired = false;
@@ -1142,7 +1144,8 @@ static int run_group_with(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64
 // TRANSFORM (nfft samples: the zero padding is the hardware range check), not just up to L: the whole span
 // nfft * elem_stride * sizeof(sample) must stay below 4 GiB or a padded offset would wrap back into range.
 static int check_input_span(const imp_plan* p, int64_t elem_stride, size_t sample_bytes) {
-  const int64_t reach = p->ola ? ((int64_t)1 << 21) : p->nfft;
+  // (a fused FIR plan forms sample offsets up to one block past the input's end)
+  const int64_t reach = p->fused ? p->L + p->nfft : p->ola ? ((int64_t)1 << 21) : p->nfft;
   if ((double)reach * (double)elem_stride * (double)sample_bytes >= 4294967296.0)
     return fail(IMP_ERR_INVALID,
                 "transform length %lld x elem_stride %lld x %zu B exceeds the 4 GiB buffer range of one channel",
@@ -1635,6 +1638,7 @@ struct imp_chain {
   std::vector<hipEvent_t> ir_free;  // recorded on the tail stream after K5 has read the lane's buffers
   std::vector<char> ir_busy;
   int64_t* d_meta = nullptr;        // off[B], len[B]
+  double* d_win = nullptr;          // the two Hann fades as tables (LoadCropAtPeak)
 };
 
 // both contexts, in address order
@@ -1664,6 +1668,7 @@ extern "C" void imp_chain_destroy(imp_chain* c) {
   for (auto e : c->k1_done) (void)hipEventDestroy(e);
   for (auto e : c->ir_free) (void)hipEventDestroy(e);
   (void)hipFree(c->d_meta);
+  (void)hipFree(c->d_win);
   delete c;
 }
 
@@ -1717,7 +1722,13 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
   c->chunks = deconv->paired ? deconv->N1 / 2 : deconv->N1;
   const size_t chunk_bytes = (size_t)(B * c->chunks) * sizeof(unsigned);
   bool ok = hipMalloc((void**)&c->d_meta, (size_t)(2 * B) * sizeof(int64_t)) == hipSuccess &&
-            hipMemcpy(c->d_meta, meta.data(), meta.size() * sizeof(int64_t), hipMemcpyHostToDevice) == hipSuccess;
+            hipMemcpy(c->d_meta, meta.data(), meta.size() * sizeof(int64_t), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMalloc((void**)&c->d_win, (size_t)std::max<int64_t>(fade_in + fade_out, 1) * sizeof(double)) == hipSuccess;
+  if (ok && fade_in + fade_out > 0) {
+    hipLaunchKernelGGL(imp::fade_table_kernel, dim3((unsigned)((fade_in + fade_out + 255) / 256)), dim3(256), 0, deconv->ctx->stream,
+                       c->d_win, (long long)fade_in, (long long)fade_out);
+    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(deconv->ctx->stream) == hipSuccess;
+  }
   for (int l = 0; l < c->lanes && ok; ++l) {
     float* ir = nullptr;
     unsigned* tile = nullptr;
@@ -1775,7 +1786,8 @@ extern "C" int imp_chain_execute_device(imp_chain* c, const float* d_x, int64_t 
                      c->d_meta, c->d_meta + c->B, c->deconv->out_start, (const unsigned*)c->d_tile[(size_t)l], c->tiles,
                      (const unsigned*)nullptr, c->chunks, c->d_res[(size_t)l], c->peak_height, d_peaks_out);
   HIP_TRY(hipGetLastError());
-  imp::LoadCropAtPeak ld{c->d_ir[(size_t)l], c->pitch_ir, c->deconv->out_len, c->d_res[(size_t)l], c->n, c->head, c->fade_in, c->fade_out};
+  imp::LoadCropAtPeak ld{c->d_ir[(size_t)l], c->pitch_ir, c->deconv->out_len, c->d_res[(size_t)l], c->n, c->head, c->fade_in, c->fade_out,
+                         c->d_win};
   if ((rc = run_group_with(c->fir, ld, c->B, d_out, chan_stride_out, 0, 2))) return rc;
   if (tail != lane_stream) {
     HIP_TRY(hipEventRecord(c->ir_free[(size_t)l], tail));

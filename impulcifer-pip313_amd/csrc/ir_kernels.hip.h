@@ -380,65 +380,69 @@ struct LoadCropAtPeak {
   long long row_len;                // samples per row
   const RowPeak* __restrict__ res;
   long long n, head, fade_in, fade_out;
+  // hann(2 fade_in)[:fade_in] followed by hann(2 fade_out)[fade_out:], fp64, made once per chain (fade_table_kernel): the
+  // loaders multiply by table entries instead of evaluating a cosine per sample (the library cospi keeps a stack frame,
+  // and a kernel with scratch pays for it at every launch)
+  const double* __restrict__ win;
   __host__ __device__ LoadCropAtPeak shifted(long long, long long) const { return *this; }   // overlap-add plans are refused
-  __device__ __forceinline__ float shaped(float x, long long i) const {
+  static __device__ __forceinline__ float shaped(float x, long long i, long long n, long long fade_in, long long fade_out,
+                                                 const double* __restrict__ win) {
     double g = 1.0;
-    if (i < fade_in) g *= hann_sym_fwd(i, 2 * fade_in);
-    if (fade_out > 0 && i >= n - fade_out && i < n) g *= hann_sym_fwd(fade_out + (i - (n - fade_out)), 2 * fade_out);
+    if (i < fade_in) g *= win[i];
+    if (fade_out > 0 && i >= n - fade_out && i < n) g *= win[fade_in + (i - (n - fade_out))];
     return (float)((double)x * g);
+  }
+  __device__ __forceinline__ long long crop_start(int b) const {
+    const RowPeak rp = res[b];
+    long long pk;
+    if (row_len == 0 || !(__uint_as_float(rp.maxabs_bits) >= 1e-20f)) pk = 0;
+    else pk = (long long)(rp.first_peak != ~0ull ? rp.first_peak : rp.first_max);
+    long long start = pk - head;
+    if (start > row_len - n) start = row_len - n;
+    if (start < 0) start = 0;
+    return start;
   }
   struct Row {                        // fir_block_kernel's view of a channel (see LoadRealPacked::Row)
     __amdgpu_buffer_rsrc_t r;
-    long long n, fade_in, fade_out;
-    __device__ __forceinline__ float shaped(float x, long long i) const {
-      double g = 1.0;
-      if (i < fade_in) g *= hann_sym_fwd(i, 2 * fade_in);
-      if (fade_out > 0 && i >= n - fade_out && i < n) g *= hann_sym_fwd(fade_out + (i - (n - fade_out)), 2 * fade_out);
-      return (float)((double)x * g);
-    }
-    __device__ __forceinline__ cf pair_at(long long s) const {
-      cf v = bload_cf<0>(r, (unsigned)(s * 4), 0u);
-      if (s >= 0 && (s < fade_in || s + 1 >= n - fade_out)) {      // only the two ends pay for the window
-        v.x = shaped(v.x, s);
-        v.y = shaped(v.y, s + 1);
+    int n, fade_in, fade_out;
+    const double* __restrict__ win;
+    __device__ __forceinline__ cf pair_at(int s) const { return bload_cf<0>(r, (unsigned)s * 4u, 0u); }
+    // the window, applied once the loads have landed (kept out of the load loop: fewer registers live across it)
+    __device__ __forceinline__ cf finish(cf v, int s) const {
+      if ((unsigned)s < (unsigned)n && (s < fade_in || s + 1 >= n - fade_out)) {      // only the two ends pay for the window
+        v.x = shaped(v.x, s, n, fade_in, fade_out, win);
+        v.y = shaped(v.y, s + 1, n, fade_in, fade_out, win);
       }
       return v;
     }
   };
   __device__ __forceinline__ Row open(int b) const {
-    const RowPeak rp = res[b];
-    long long pk;
-    if (row_len == 0 || !(__uint_as_float(rp.maxabs_bits) >= 1e-20f)) pk = 0;
-    else pk = (long long)(rp.first_peak != ~0ull ? rp.first_peak : rp.first_max);
-    long long start = pk - head;
-    if (start > row_len - n) start = row_len - n;
-    if (start < 0) start = 0;
-    const long long avail = row_len - start;
-    return Row{make_rsrc(base + (long long)b * chan_stride + start, (unsigned)(avail < n ? avail : n) * 4u), n, fade_in, fade_out};
+    const long long start = crop_start(b), avail = row_len - start;
+    return Row{make_rsrc(base + (long long)b * chan_stride + start, (unsigned)(avail < n ? avail : n) * 4u), (int)n, (int)fade_in,
+               (int)fade_out, win};
   }
   template <int STEP, int F>
   __device__ __forceinline__ void column(int b, unsigned e0, cf (&v)[F]) const {
-    const RowPeak rp = res[b];
-    long long pk;
-    if (row_len == 0 || !(__uint_as_float(rp.maxabs_bits) >= 1e-20f)) pk = 0;
-    else pk = (long long)(rp.first_peak != ~0ull ? rp.first_peak : rp.first_max);
-    long long start = pk - head;
-    if (start > row_len - n) start = row_len - n;
-    if (start < 0) start = 0;
-    const long long avail = row_len - start;
+    const long long start = crop_start(b), avail = row_len - start;
     const __amdgpu_buffer_rsrc_t r = make_rsrc(base + (long long)b * chan_stride + start, (unsigned)(avail < n ? avail : n) * 4u);
 #pragma unroll
     for (int j = 0; j < F; ++j) {
       const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, e0 * 8u, (unsigned)(j * STEP) * 8u, 0);
       v[j] = make_float2(__uint_as_float(x.x), __uint_as_float(x.y));
       const long long i = 2ll * ((long long)e0 + (long long)j * STEP);
-      if (i < fade_in || i + 1 >= n - fade_out) {              // only the two ends pay for the window
-        v[j].x = shaped(v[j].x, i);
-        v[j].y = shaped(v[j].y, i + 1);
+      if (i < n && (i < fade_in || i + 1 >= n - fade_out)) {     // only the two ends pay for the window
+        v[j].x = shaped(v[j].x, i, n, fade_in, fade_out, win);
+        v[j].y = shaped(v[j].y, i + 1, n, fade_in, fade_out, win);
       }
     }
   }
 };
+
+__global__ __launch_bounds__(256) void fade_table_kernel(double* __restrict__ win, long long fade_in, long long fade_out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < fade_in) win[i] = hann_sym_fwd(i, 2 * fade_in);
+  else if (i < fade_in + fade_out) win[i] = hann_sym_fwd(fade_out + (i - fade_in), 2 * fade_out);
+}
 
 // layout-compatible with imp_window_params (include/impulse_hip.h)
 struct WindowParams {

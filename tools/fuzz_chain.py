@@ -46,8 +46,8 @@ def main(cases=60, seed=1):
         firs = rng.standard_normal((B, K)) * np.exp(-np.arange(K) / max(K / 5.0, 1.0))
         firs /= np.maximum(np.linalg.norm(firs, axis=1, keepdims=True), 1e-30)
         firs[:, 0] += 1.0
-        plan1 = ConvPlan(ctx, h, L, "same", ws_channels=B)
-        plan5 = ConvPlan(ctx, firs, n, "full", ws_channels=B)
+        plan1 = ConvPlan(ctx, h, L, "same", ws_channels=B, fused=False)          # the deconvolution stage leaves chunk maxima
+        plan5 = ConvPlan(ctx, firs, n, "full", ws_channels=B, fused=bool(case % 2))   # both K5 forms
         chain = FirChain(plan1, plan5, B, head, fade_in, fade_out)
         po = n + K - 1 + int(rng.integers(0, 9))
         d_x, d_out, d_pk = ctx.malloc(x.nbytes), ctx.malloc(B * po * 4), ctx.malloc(B * 8)
