@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py - IRs/s of the batched ESS deconvolution on MI355X (BASELINE.json metric).
+"""bench.py - IRs/s of the sweep deconvolution + FIR hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N ranks (child torchrun)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One STEP = one pass of the hot path (K1: deconvolution incl. the 'same' crop) over every input set in
-rotation: at the default workload (BASELINE.json configs[1], "C2": 7.1 x 2 ears = 16 channels, 6.15 s sweep
-@48 kHz, column L = N + 2 fs = 391 270) that is 40 measurements = 640 IRs per GPU per step, all resident in
-HBM before the clock starts (1 GiB of inputs, so no input line survives in the 256 MiB Infinity Cache between
-two uses).  Channels shard across ranks with no data-path collective ("weak": one such stream of measurements
-per GPU); the only collective is the one-off RCCL broadcast of the prepared inverse-sweep spectrum.
+One STEP = one pass of the hot path over every measurement resident in HBM.  The hot path is the metric's own wording,
+"sweep deconv+FIR": per 7.1 x 2-ear measurement (BASELINE.json configs[1], "C2": 16 channels, 6.15 s sweep @48 kHz,
+column L = N + 2 fs = 391 270 samples)
 
-With N > 1 (or --strong) the line also carries `strong_c5`: BASELINE.json configs[4] (1024 channels x 2^20
-samples) sharded over the ranks, its IR/s, and the speed-up over rank 0 doing all 1024 channels alone in the
-same run (north_star's strong-scaling figure).
+    K1 deconvolution (estimate(): recording (*) inverse filter, 'same')      core/impulse_response_estimator.py:149-151
+ -> K3 first significant peak                                                core/impulse_response.py:32-70
+ -> K4 crop at peak - 1 ms, 0.68 s long, Hann fades                          core/hrir.py:548-653
+ -> K5 per-channel 9 600-tap minimum-phase FIR, 'full'                       core/impulse_response.py:110-119
 
-The JSON line carries `roofline` (HIP-event time of the dominant kernel over the timed steps, priced in
-ALGORITHMIC bytes 8*L per IR) and `cpu_baseline` (the NumPy oracle of the reference's
-scipy.signal.convolve(x, inverse_filter, 'same') timed on this box's host cores, rank 0, N=1).
+as ONE device chain per call (imp_chain: five launches, nothing crosses the bus, crop offsets taken from the peak search
+on the device).  `value` is that chain; `deconv_only` (K1 alone, last round's headline) is given beside it with the
+roofline of its dominant kernel.  The default step holds 272 blocks of two measurements = 8 704 IRs per GPU (13 GiB of
+inputs in rotation, so no input line survives in the 256 MiB Infinity Cache between two uses, and 20 steps time ~0.5 s).
+Channels shard across ranks with no data-path collective ("weak": one stream of measurements per GPU); the only
+collective is the one-off RCCL broadcast of the prepared inverse-sweep spectrum.
+
+With N > 1 (or --strong) the line also carries `strong_c5`: BASELINE.json configs[4] (1024 channels x 2^20 samples)
+sharded over the ranks, its IR/s, and the speed-up over rank 0 doing all 1024 channels alone in the same run.
+
+The JSON line carries `roofline` (HIP-event time of the dominant kernel over the timed steps, priced in ALGORITHMIC
+bytes 8 L per IR, L2<->fabric bytes from rocprofv3 --pmc child runs) and `cpu_baseline` (the NumPy oracle of the same
+chain timed on this box's host cores, rank 0, N = 1).  No torch at N = 1: device memory comes from the library.
 """
 import argparse
 import json
@@ -36,48 +44,46 @@ sys.path.insert(0, ROOT)
 PITCH_ALIGN = int(os.environ.get("IMPULSE_BENCH_PITCH_ALIGN", "64"))     # samples
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BROADCAST_VIA = None           # set when the in-library RCCL broadcast had to be replaced
+RCCL_RANKS_SEEN = None         # ranks the library's own communicator counted (ncclCommCount), set by spectrum_broadcast
 METRIC = "impulse responses/sec (sweep deconv+FIR), 7.1×2-ear @48kHz, 1/2/4/8 GPU"
 
 WORKLOADS = {
     # name: (fs, min_duration, channels, description); c2/c3: channels PER RANK per measurement (weak scaling),
     # c4/c5: channels in TOTAL, sharded over the ranks (strong scaling)
     "c2": (48000, 5.0, 16, "C2: 7.1 layout (8 spk x 2 ear = 16 IRs), 6.15 s ESS sweep @48 kHz"),
-    "c3": (96000, 5.0, 26, "C3: 13-ch TrueHD layout x 2 ear @96 kHz (deconvolution stage only)"),
-    "c4": (48000, None, 256, "C4: synthetic 256-channel batch, 2^20-sample sweeps @48 kHz, channel-sharded"),
-    "c5": (48000, None, 1024, "C5: synthetic 1024-channel batch, 2^20-sample sweeps @48 kHz, channel-sharded"),
+    "c3": (96000, 5.0, 26, "C3: 13-ch TrueHD layout x 2 ear @96 kHz"),
+    "c4": (48000, None, 256, "C4: synthetic 256-channel batch, 2^20-sample sweeps @48 kHz, channel-sharded (deconvolution only)"),
+    "c5": (48000, None, 1024, "C5: synthetic 1024-channel batch, 2^20-sample sweeps @48 kHz, channel-sharded (deconvolution only)"),
 }
-# channels per launch group when groups overlap on 3 lanes (measured sweeps): the
-# groups in flight together must still fit the 256 MiB Infinity Cache with their inputs and outputs
+# channels per K1 launch group (measured sweeps): the groups in flight together must still fit the
+# 256 MiB Infinity Cache with their inputs and outputs.  C2: two measurements = 32 channels; C3: 13
 GROUP_CHANNELS = {"c2": 32, "c3": 13, "c4": 8, "c5": 8}
-# Resident measurements that travel through K1 as ONE launch group (their rows are contiguous in HBM).  At C2 two 7.1
-# measurements = 32 channels per group: with three groups in flight the workspaces (96 x 2.2 MB) still fit the 256 MiB
-# Infinity Cache, and every launch carries twice the workgroups (tools/k1_rate.py: 16 ch x 3 lanes 413 k, 32 x 3 443 k,
-# 48 x 3 359 k IR/s - past 32 the workspaces spill to HBM).  --measurements-per-group 1 is the round-1 shape.
-MEASUREMENTS_PER_GROUP = {"c2": 2, "c3": 1, "c4": 1, "c5": 1}
+MEASUREMENTS_PER_BLOCK = {"c2": 2, "c3": 1}
+DEFAULT_BLOCKS = {"c2": 272, "c3": 96, "c4": 12, "c5": 12}
+CHAINS = 3                     # chains (K1 launch groups) in flight
 
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ws-channels", type=int, default=0,
-                    help="workspace size in channels (0 = lanes x the per-workload group size)")
-    ap.add_argument("--lanes", type=int, default=3,
-                    help="independent launch groups in flight (imp_plan_set_overlap); 1 = strictly serial kernels")
+    ap.add_argument("--lanes", type=int, default=CHAINS,
+                    help="chains / K1 launch groups in flight; 1 = strictly serial kernels")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not collect FETCH_SIZE / WRITE_SIZE with rocprofv3 child runs (roofline.traffic then comes from "
                          "the committed profiles/ summary)")
     ap.add_argument("--event-stride", type=int, default=32,
-                    help="bracket the passes of every n-th launch group with HIP events (sampling keeps the "
-                         "event records from perturbing the throughput being measured)")
-    ap.add_argument("--input-sets", type=int, default=0,
-                    help="input batches in rotation = measurements per step (0: enough for 1 GiB, at most 40)")
-    ap.add_argument("--measurements-per-group", type=int, default=0,
-                    help="resident measurements per K1 launch group (default: 2 at C2, 1 elsewhere)")
+                    help="bracket the passes of every n-th K1 launch group with HIP events (sampling keeps the event "
+                         "records from perturbing the throughput being measured)")
+    ap.add_argument("--blocks", type=int, default=0,
+                    help="resident input blocks per step (0: 272 at C2 = 13 GiB; a block = the measurements of one chain call)")
+    ap.add_argument("--stage", default="chain", choices=["chain", "deconv"],
+                    help="what `value` times: the deconvolution + FIR chain (the metric) or K1 alone (C4 / C5 always K1)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--strong", action="store_true", help="add the strong_c5 block at N = 1 too")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong_c5 block at N > 1")
     ap.add_argument("--strong-channels", type=int, default=1024)
@@ -166,6 +172,22 @@ def synth_recordings(est, n_channels, seed0, column=None):
     return rec, L, pitch, delays
 
 
+def fir_stage_shape(est):
+    """the FIR stage of the chain at this sampling rate: crop length (0.68 s), taps (fs / 5: 9 600 @48 k, 19 200 @96 k - the
+    minimum-phase FIR length the reference designs, autoeq/frequency_response.py:637-681), head (1 ms), fade-out length"""
+    fs = est.fs
+    n, K, head = int(0.68 * fs), fs // 5, fs // 1000
+    fade = 2 * int(fs * (len(est) / fs / est.n_octaves) * (1 / 24)) // 2
+    return n, K, head, fade
+
+
+def synth_firs(B, K, seed=0xF1):
+    rng = np.random.default_rng(seed)
+    firs = rng.standard_normal((B, K)) * np.exp(-np.arange(K) / 400.0) * 0.05
+    firs[:, 0] += 1.0
+    return firs
+
+
 def slice_rate(est, rec, L, reps=3):
     """SURVEY 8(d) secondary figure: the whole hot-path slice (ingest K1 -> crop_heads K3/K4 -> crop_tails K7/K4 ->
     EQ curves + FIR design K12/K6 -> equalize K5 -> normalize K2) on ONE 7.1 x 2-ear measurement laid out as a recording
@@ -193,166 +215,216 @@ def slice_rate(est, rec, L, reps=3):
                 note="end to end: PCM frames in host memory -> float64 responses in host memory, incl. PCIe; 16 IRs per measurement; not the headline metric")
 
 
-def deconv_fir_leg(dev_index, est, rec, L, pitch, reps=300, lanes=3, per_meas=16, paired=False):
-    """The metric's "+FIR" on device pointers: 7.1 x 2-ear measurements resident in HBM go through K1 (deconvolution)
-    -> K3 (first-peak search) -> K4 (head crop at peak - 1 ms, 0.68 s long, Hann fades, compacted) -> K5 (per-channel
-    9 600-tap FIRs whose spectra are cached in the plan) as ONE stream-ordered chain (imp_chain): the crop offsets are taken
-    from the peak search on the device, nothing crosses the bus.  `lanes` chains on their own contexts (streams) take the
-    measurements round robin so that one measurement's row pass runs beside another's column passes.
-    `rec` holds one or more measurements of `per_meas` channels; all of them go through one chain call (two per call is
-    the measured optimum, as for K1 alone: 16 ch x 3 chains 291 k, 32 x 3 312 k, 48 x 3 279 k IR/s).
-    Algorithmic bytes per IR: 4 L in + 4 (n + K - 1) out."""
-    from impulse_hip import Context, ConvPlan
-    from impulse_hip._native import FirChain
+# ------------------------------------------------------------------------------------------------------
+# resident inputs and the two timed arrangements
+# ------------------------------------------------------------------------------------------------------
+class InputRing:
+    """n_blocks copies of one block of recordings ([B][pitch] fp32) at different addresses of HBM (library memory)."""
+
+    def __init__(self, ctx, rec, n_blocks):
+        self.ctx, self.nbytes = ctx, rec.nbytes
+        self.ptrs = [ctx.malloc(rec.nbytes) for _ in range(n_blocks)]
+        ctx.h2d(self.ptrs[0], rec)
+        for p in self.ptrs[1:]:
+            ctx.d2d(p, self.ptrs[0], rec.nbytes)
+        ctx.synchronize()
+
+    def release(self):
+        for p in self.ptrs:
+            self.ctx.free(p)
+        self.ptrs = []
+
+
+def copy_spectrum(dst_plan, src_plan, ctx):
+    """the prepared filter spectrum of one plan into another plan of the same geometry on the same device"""
+    (d, n), (s, m) = dst_plan.spectrum_buffer(), src_plan.spectrum_buffer()
+    assert n == m
+    ctx.d2d(d, s, n)
+    ctx.synchronize()
+
+
+class ChainTeam:
+    """`chains` deconvolution + FIR chains, each on its own pair of contexts (K1 on one stream; peak search + fused K5 on a
+    second one, so the next call's K1 runs beside them), fed round robin with the blocks of the input ring."""
+
+    def __init__(self, dev_index, est, inv, ring, L, pitch, B, chains, firs=None, k1_plan0=None):
+        from impulse_hip import Context, ConvPlan
+        from impulse_hip._native import FirChain
+        self.ring, self.L, self.pitch, self.B = ring, L, pitch, B
+        self.n, self.K, self.head, self.fade = fir_stage_shape(est)
+        self.firs = synth_firs(B, self.K) if firs is None else firs
+        self.po = (self.n + self.K - 1 + 63) // 64 * 64
+        self.lanes = []
+        for i in range(chains):
+            ctx, tail = Context(dev_index), Context(dev_index)
+            if i == 0 and k1_plan0 is not None:
+                plan1 = k1_plan0(ctx)                               # rank 0: from the filter; other ranks: empty + broadcast
+            elif i == 0:
+                plan1 = ConvPlan(ctx, inv, L, "same", ws_channels=B, fused=False)
+            else:
+                plan1 = ConvPlan(ctx, None, L, "same", ws_channels=B, empty_M=len(inv), n_filters=1, fused=False)
+                copy_spectrum(plan1, self.lanes[0]["plan1"], ctx)
+            plan5 = ConvPlan(tail, self.firs, self.n, "full", ws_channels=B)
+            chain = FirChain(plan1, plan5, B, self.head, self.head, self.fade)
+            outs = [ctx.malloc(B * self.po * 4) for _ in range(3)]
+            self.lanes.append(dict(ctx=ctx, tail=tail, plan1=plan1, plan5=plan5, chain=chain, outs=outs, d_pk=ctx.malloc(B * 8), k=0))
+        self.next = 0
+
+    def call(self, d_x):
+        ln = self.lanes[self.next % len(self.lanes)]
+        self.next += 1
+        out = ln["outs"][ln["k"] % len(ln["outs"])]
+        ln["k"] += 1
+        ln["last_out"] = out
+        ln["chain"].execute_device(d_x, self.pitch, out, self.po, ln["d_pk"])
+
+    def step(self):
+        for p in self.ring.ptrs:
+            self.call(p)
+
+    def sync(self):
+        for ln in self.lanes:
+            ln["ctx"].synchronize()
+            ln["tail"].synchronize()
+
+    def set_timing(self, every):
+        for ln in self.lanes:
+            ln["plan1"].set_timing(every)
+            ln["plan5"].set_timing(every)
+            ln["plan1"].get_timing(reset=True)
+            ln["plan5"].get_timing(reset=True)
+
+    def timing(self):
+        """(ms of K1 pass A, B, C summed over the sampled launch groups, groups), (ms of the fused K5 launch, launches)"""
+        k1, n1, k5, n5 = np.zeros(3), 0, 0.0, 0
+        for ln in self.lanes:
+            ms, n = ln["plan1"].get_timing(reset=True)
+            k1 += np.asarray(ms)
+            n1 += n
+            ms, n = ln["plan5"].get_timing(reset=True)
+            k5 += ms[0]
+            n5 += n
+        return (k1, n1), (k5, n5)
+
+    def fetch(self, lane=-1):
+        """outputs [B][n + K - 1] and peak indices of the last call of one chain"""
+        ln = self.lanes[lane]
+        y = np.empty((self.B, self.po), dtype=np.float32)
+        pk = np.empty(self.B, dtype=np.int64)
+        ln["ctx"].d2h(y, ln["last_out"])
+        ln["ctx"].d2h(pk, ln["d_pk"])
+        return y[:, :self.n + self.K - 1], pk
+
+    def release(self):
+        self.sync()
+        for ln in self.lanes:
+            ln["chain"].close()
+            ln["plan1"].close()
+            ln["plan5"].close()
+            for p in ln["outs"] + [ln["d_pk"]]:
+                ln["ctx"].free(p)
+            ln["tail"].close()
+            ln["ctx"].close()
+        self.lanes = []
+
+
+class DeconvOnly:
+    """K1 alone over the input ring: one plan, `lanes` launch groups in flight, one output buffer per lane."""
+
+    def __init__(self, ctx, plan, ring, B, L, pitch, M, lanes):
+        self.ctx, self.plan, self.ring, self.B, self.L, self.pitch = ctx, plan, ring, B, L, pitch
+        self.lanes = max(1, min(lanes, 4))
+        plan.set_overlap(self.lanes)
+        # output rows: same pitch; the first sample of a row is placed so that the crop offset of the 'same' window
+        # lands the stores on 128-byte lines (the caller chooses where results go: here (M-1)/2 mod 32 samples in)
+        self.skew = ((M - 1) // 2) % 32 if os.environ.get("IMPULSE_BENCH_OUT_SKEW", "1") == "1" else 0
+        self.bufs = [ctx.malloc((B * pitch + 64) * 4) for _ in range(self.lanes)]
+        self.n = 0
+
+    def call(self, d_x):
+        out = self.bufs[self.n % self.lanes] + 4 * self.skew
+        self.n += 1
+        self.plan.execute_device(d_x, self.B, self.pitch, out, self.pitch)
+
+    def step(self):
+        for p in self.ring.ptrs:
+            self.call(p)
+
+    def sync(self):
+        self.ctx.synchronize()
+
+    def outputs(self):
+        ys = []
+        for b in self.bufs:
+            y = np.empty((self.B, self.pitch), dtype=np.float32)
+            self.ctx.d2h(y, b + 4 * self.skew)
+            ys.append(y[:, :self.L])
+        return ys
+
+    def release(self):
+        self.sync()
+        self.plan.close()
+        for b in self.bufs:
+            self.ctx.free(b)
+
+
+# ------------------------------------------------------------------------------------------------------
+# CPU baseline: the NumPy oracle of the same work on this box's host cores
+# ------------------------------------------------------------------------------------------------------
+def oracle_chain(x, inv, fir, n, head, fade):
+    """estimate -> peak_index -> crop at peak - head (n samples, clamped) with Hann fades -> fir, 'full' (float64)"""
     from oracle.estimator import estimate
     from oracle.impulse_response import peak_index
     from oracle.scipy_restated import fft_convolve, hann
-    fs, B = est.fs, rec.shape[0]
-    n, K, head = int(0.68 * fs), 9600, fs // 1000
-    fade = 2 * int(fs * (len(est) / fs / est.n_octaves) * (1 / 24)) // 2
-    rng = np.random.default_rng(0xF1)
-    firs = rng.standard_normal((B, K)) * np.exp(-np.arange(K) / 400.0) * 0.05
-    firs[:, 0] += 1.0
-    po = (n + K - 1 + 63) // 64 * 64
-
-    k1_lanes = int(os.environ.get("IMPULSE_BENCH_CHAIN_K1_LANES", "3"))
-    n_inputs = int(os.environ.get("IMPULSE_BENCH_CHAIN_INPUTS", "8"))
-
-    class Lane:
-        """one chain: K1 on `k1_lanes` streams of one context, the peak search and K5 on the stream of a second context"""
-
-        def __init__(self):
-            self.ctx, self.tail = Context(dev_index), Context(dev_index)
-            self.plan1 = ConvPlan(self.ctx, np.asarray(est.inverse_filter, dtype=np.float64), L, "same",
-                                  ws_channels=B * k1_lanes, paired=paired)
-            self.plan1.set_overlap(k1_lanes)
-            self.plan5 = ConvPlan(self.tail, firs, n, "full", ws_channels=B)
-            self.chain = FirChain(self.plan1, self.plan5, B, head, head, fade)
-            self.d_xs = [self.ctx.malloc(B * pitch * 4) for _ in range(n_inputs)]
-            self.d_outs = [self.ctx.malloc(B * po * 4) for _ in range(k1_lanes + 2)]
-            self.d_pk = self.ctx.malloc(B * 8)
-            for d in self.d_xs:
-                self.ctx.h2d(d, rec)
-            self.k = 0
-
-        def once(self):
-            self.chain.execute_device(self.d_xs[self.k % n_inputs], pitch, self.d_outs[self.k % len(self.d_outs)], po, self.d_pk)
-            self.last_out = self.d_outs[self.k % len(self.d_outs)]
-            self.k += 1
-
-        def synchronize(self):
-            self.ctx.synchronize()
-            self.tail.synchronize()
-
-        def close(self):
-            self.synchronize()
-            self.chain.close()
-            for p in self.d_xs + self.d_outs + [self.d_pk]:
-                self.ctx.free(p)
-            self.tail.close()
-            self.ctx.close()
-
-    team = [Lane() for _ in range(lanes)]
-    try:
-        for _ in range(10):
-            for ln in team:
-                ln.once()
-        for ln in team:
-            ln.synchronize()
-        feeders = os.environ.get("IMPULSE_BENCH_CHAIN_FEEDERS", "0") == "1"
-        t0 = time.perf_counter()
-        if feeders:                                   # one host thread per chain (ctypes drops the GIL during the calls)
-            import threading
-
-            def feed(ln, count):
-                for _ in range(count):
-                    ln.once()
-            ths = [threading.Thread(target=feed, args=(ln, reps // lanes)) for ln in team]
-            for th in ths:
-                th.start()
-            for th in ths:
-                th.join()
-        else:
-            for i in range(reps):
-                team[i % lanes].once()
-        t_issue = time.perf_counter() - t0
-        for ln in team:
-            ln.synchronize()
-        dt = (time.perf_counter() - t0) / (reps // lanes * lanes)
-        sys.stderr.write(f"[chain] host issue time {t_issue / reps * 1e6:.1f} us per call, total {dt * 1e6:.1f} us per call\n")
-        t1 = time.perf_counter()
-        for _ in range(100):
-            team[0].once()
-            team[0].synchronize()
-        dt_single = (time.perf_counter() - t1) / 100
-        y = np.empty((B, po), dtype=np.float32)
-        peaks = np.empty(B, dtype=np.int64)
-        team[-1].ctx.d2h(y, team[-1].last_out)
-        team[-1].ctx.d2h(peaks, team[-1].d_pk)
-    finally:
-        for ln in team:
-            ln.close()
-    errs, peaks_ok = [], True
+    ir = estimate(x, inv)
+    pk = peak_index(ir)
+    s0 = min(max(pk - head, 0), len(ir) - n)
     w = np.ones(n)
     w[:head] *= hann(2 * head)[:head]
     w[n - fade:] *= hann(2 * fade)[fade:]
-    for c in (0, B - 1):
-        ir = estimate(rec[c, :L].astype(np.float64), np.asarray(est.inverse_filter, dtype=np.float64))
-        pk = peak_index(ir)
-        peaks_ok &= pk == int(peaks[c])
-        s0 = min(max(pk - head, 0), L - n)
-        ref = fft_convolve(ir[s0:s0 + n] * w, firs[c], "full")
-        errs.append(float(np.max(np.abs(y[c, :n + K - 1] - ref)) / np.max(np.abs(ref))))
-    alg = per_meas * (4.0 * L + 4.0 * (n + K - 1))
-    mpc = B / per_meas                                            # measurements per chain call
-    dt, dt_single = dt / mpc, dt_single / mpc
-    return dict(value=per_meas / dt, unit="IR/s", ms_per_measurement=dt * 1e3, channels=per_meas, channels_per_chain_call=B,
-                chains_in_flight=lanes,
-                one_chain=dict(value=per_meas / dt_single, ms_per_measurement=dt_single * 1e3),
-                stages="K1 deconvolution -> K3 first peak -> K4 crop (peak - 1 ms, 0.68 s) + Hann fades -> K5 per-channel "
-                       "9 600-tap FIR (spectra cached in the plan): one stream-ordered chain (imp_chain, seven launches) per call of "
-                       f"{B} channels, crop offsets taken from the peak search on the device, no host round trip",
-                algorithmic_bytes_per_measurement=alg, achieved_GBps=alg / dt / 1e9, frac_of_hbm_peak=alg / dt / 1e9 / HBM_PEAK_GBS,
-                parity=dict(peak_indices_exact=bool(peaks_ok), time_max_rel_err=max(errs), tolerance=1e-6, channels_checked=2))
+    return ir, pk, fft_convolve(ir[s0:s0 + n] * w, fir, "full")
 
 
-def cpu_baseline(est, rec, L, budget_s=12.0):
-    """The oracle's restatement of estimate() (float64, nfft = next_fast_len, rfft(h) recomputed per
-    call exactly like core/impulse_response_estimator.py:149-151), serial over channels as the
-    reference ingests them (core/hrir.py:307-355).  Bounded sample of the same workload."""
+def cpu_baseline(est, rec, L, firs, shape, with_fir, budget_s=10.0):
+    """The oracle's restatement of the timed work (float64; estimate() = nfft next_fast_len with rfft(h) recomputed per call,
+    exactly like core/impulse_response_estimator.py:149-151), serial over channels as the reference ingests them
+    (core/hrir.py:307-355), then through a thread pool of min(2*cpu, 32) workers - the reference's
+    core/parallel_processing.py:31-48 heuristic (pocketfft releases the GIL).  Bounded samples of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle.estimator import estimate
     inv = np.asarray(est.inverse_filter, dtype=np.float64)
-    done, t0 = 0, time.perf_counter()
-    outs = {}
+    n, K, head, fade = shape
+
+    def work(c):
+        x = rec[c, :L].astype(np.float64)
+        return oracle_chain(x, inv, firs[c], n, head, fade) if with_fir else (estimate(x, inv), None, None)
+
+    done, t0, outs = 0, time.perf_counter(), {}
     while True:
         c = done % rec.shape[0]
-        y = estimate(rec[c, :L].astype(np.float64), inv)
+        r = work(c)
         if c not in outs:
-            outs[c] = y
+            outs[c] = r
         done += 1
         el = time.perf_counter() - t0
         if el >= budget_s or done >= 512:
             break
-    return dict(value=done / el, unit="IR/s", cores=1, kind="port",
-                sample=f"{done} IRs of the same synthetic batch, serial float64 NumPy pocketfft "
-                       f"(host has {os.cpu_count()} logical cores, {len(os.sched_getaffinity(0))} usable)"), outs
-
-
-def cpu_pooled(est, rec, L, budget_s=8.0):
-    """Same work through a thread pool of min(2*cpu, 32) workers - the reference's
-    core/parallel_processing.py:31-48 heuristic (pocketfft releases the GIL)."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle.estimator import estimate
-    inv = np.asarray(est.inverse_filter, dtype=np.float64)
+    serial = dict(value=done / el, unit="IR/s", cores=1, kind="port",
+                  sample=f"{done} IRs of the same synthetic batch, serial float64 NumPy pocketfft")
     workers = min(2 * (os.cpu_count() or 1), 32)
-    xs = [rec[c, :L].astype(np.float64) for c in range(rec.shape[0])]
-    done, t0 = 0, time.perf_counter()
+    idx = list(range(rec.shape[0])) * max(1, (2 * workers) // rec.shape[0])
+    pdone, t0 = 0, time.perf_counter()
     with ThreadPoolExecutor(max_workers=workers) as pool:
         while time.perf_counter() - t0 < budget_s:
-            list(pool.map(lambda x: estimate(x, inv), xs * max(1, (2 * workers) // len(xs))))
-            done += len(xs) * max(1, (2 * workers) // len(xs))
-    el = time.perf_counter() - t0
-    return dict(value=done / el, unit="IR/s", cores=workers, kind="port", sample=f"{done} IRs, thread pool")
+            list(pool.map(work, idx))
+            pdone += len(idx)
+    pel = time.perf_counter() - t0
+    what = "estimate -> peak_index -> crop + fades -> FIR (the chain `value` times)" if with_fir else "estimate() only"
+    return dict(value=pdone / pel, unit="IR/s", cores=workers, kind="port",
+                sample=f"{pdone} IRs of the same synthetic batch through a pool of {workers} threads (the reference's "
+                       f"parallel_map heuristic) on a host with {os.cpu_count()} logical cores, "
+                       f"{len(os.sched_getaffinity(0))} usable; {what}",
+                work=what, serial=serial), outs
 
 
 def fp32_fft_floor(est, x, L):
@@ -384,10 +456,9 @@ def demo_column_error():
     from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
     from oracle.estimator import estimate
     z = np.load(path)
-    key = "column_i32" if "column_i32" in z.files else None
-    if key is None:
+    if "column_i32" not in z.files:
         return None
-    col = z[key].astype(np.float64) / 2.0 ** 31
+    col = z["column_i32"].astype(np.float64) / 2.0 ** 31
     est = ImpulseResponseEstimator(min_duration=5.0, fs=48000)
     y = est.estimate_batch(col[None, :].astype(np.float32))[0].astype(np.float64)
     ref = estimate(col.astype(np.float32).astype(np.float64), np.asarray(est.inverse_filter, dtype=np.float64))
@@ -401,10 +472,15 @@ def demo_column_error():
                 source="tests/golden/demo_fc.npz (reference data/demo/FC.wav, left track, column 0)")
 
 
+# ------------------------------------------------------------------------------------------------------
+# L2<->fabric traffic from the PMC counters
+# ------------------------------------------------------------------------------------------------------
+PMC_KEYS = ("cols_fwd", "rows_kernel", "cols_inv", "peak_search", "fir_block")
+
+
 def load_profile_traffic(workload):
-    """L2<->fabric bytes per launch from the committed rocprofv3 --pmc summary of this command (profiles/), or
-    None.  bench.py cannot collect PMC counters itself; the figure is from an EARLIER profiled run and says so."""
-    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+    """L2<->fabric bytes per launch from the committed rocprofv3 --pmc summary of this command (profiles/), or None."""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as fh:
@@ -416,14 +492,13 @@ def load_profile_traffic(workload):
     return None, None
 
 
-def live_pmc_traffic(workload, mpg):
-    """FETCH_SIZE and WRITE_SIZE of the three K1 kernels, collected NOW: two child runs of this very script under
-    `rocprofv3 --pmc` (one counter per pass, as MI355X_MICROARCH.md prescribes; strictly serial launch groups so a
-    counter belongs to one kernel at a time), started after this process has finished its own GPU work.  Returns the
-    same dict as load_profile_traffic, or None when rocprofv3 is missing, this process is itself being profiled, or a
-    child fails - the caller then falls back to the committed summary and says so."""
+def live_pmc_traffic(workload):
+    """FETCH_SIZE and WRITE_SIZE of the chain's kernels, collected NOW: two child runs of this very script under
+    `rocprofv3 --pmc` (one counter per pass, as MI355X_MICROARCH.md prescribes; strictly serial launches so a counter
+    belongs to one kernel at a time), started after this process has finished its own GPU work.  Returns bytes per launch
+    per kernel, or None when rocprofv3 is missing, this process is itself being profiled, or a child fails - the caller
+    then falls back to the committed summary and says so."""
     import shutil
-    import subprocess
     import tempfile
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)
@@ -438,26 +513,44 @@ def live_pmc_traffic(workload, mpg):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(out, counter), "-o", "p", "--",
-                   sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "1",
-                   "--no-cpu-baseline", "--no-pmc", "--lanes", "1", "--no-events", "--input-sets", "4",
-                   "--measurements-per-group", str(mpg)]
-            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=60)
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--pmc-child"]
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=90)
             if res.returncode != 0:
                 sys.stderr.write(f"[bench] rocprofv3 --pmc {counter} child failed (rc {res.returncode}): {res.stderr[-400:]}\n")
                 return None
         pm = pmc_summary.main(out)
-        keys = ("rows_kernel", "cols_fwd", "cols_inv")
-        if not all(k in pm and "FETCH_SIZE" in pm[k] and "WRITE_SIZE" in pm[k] for k in keys):
+        if not all(k in pm and "FETCH_SIZE" in pm[k] and "WRITE_SIZE" in pm[k] for k in ("rows_kernel", "cols_fwd", "cols_inv")):
             return None
-        b = lambda k: (2 * pm[k]["FETCH_SIZE"] + pm[k]["WRITE_SIZE"]) * 1024      # noqa: E731 - gfx950: FETCH_SIZE counts half
-        return {"rows_kernel_bytes_per_launch": b("rows_kernel"), "cols_fwd_bytes_per_launch": b("cols_fwd"),
-                "cols_inv_bytes_per_launch": b("cols_inv"), "rows_kernel_fetch_kb_raw": pm["rows_kernel"]["FETCH_SIZE"],
-                "rows_kernel_write_kb": pm["rows_kernel"]["WRITE_SIZE"]}
+        # gfx950: FETCH_SIZE counts half of a coalesced read stream (MI355X_MICROARCH.md)
+        t = {k + "_bytes_per_launch": (2 * pm[k]["FETCH_SIZE"] + pm[k]["WRITE_SIZE"]) * 1024 for k in PMC_KEYS
+             if k in pm and "FETCH_SIZE" in pm[k] and "WRITE_SIZE" in pm[k]}
+        t["rows_kernel_fetch_kb_raw"] = pm["rows_kernel"]["FETCH_SIZE"]
+        t["rows_kernel_write_kb"] = pm["rows_kernel"]["WRITE_SIZE"]
+        return t
     except Exception as exc:                                  # noqa: BLE001 - a reported figure, never fatal
         sys.stderr.write(f"[bench] live PMC collection failed: {exc!r}\n")
         return None
     finally:
         shutil.rmtree(out, ignore_errors=True)
+
+
+def pmc_child(args):
+    """what the --pmc children run: a few strictly serial chain calls (every kernel alone on the chip)"""
+    from impulse_hip import Context
+    est = make_estimator(args.workload)
+    B = WORKLOADS[args.workload][2] * MEASUREMENTS_PER_BLOCK.get(args.workload, 1)
+    rec, L, pitch, _ = synth_recordings(est, B, seed0=0xC2)
+    ctx = Context(0)
+    ring = InputRing(ctx, rec, 2)
+    inv = np.asarray(est.inverse_filter, dtype=np.float64)
+    team = ChainTeam(0, est, inv, ring, L, pitch, B, 1)
+    for _ in range(3):
+        team.step()
+        team.sync()
+    team.release()
+    ring.release()
+    ctx.close()
+    return 0
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -493,85 +586,40 @@ def rehearse_launch(args, rank, world):
     return 0
 
 
-def spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world, tag):
+def spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world):
     """The path's one collective.  With the RCCL backend the LIBRARY does it (imp_comm_* over librccl; the 128-byte
     communicator id is handed round by the launcher's process group) - torch.distributed only provides the launcher's barriers
     and clock reductions; the gloo rehearsal stages the bytes through host memory instead."""
+    global BROADCAST_VIA, RCCL_RANKS_SEEN
     from impulse_hip.sharding import broadcast_plan_spectrum, broadcast_plan_spectrum_rccl
     if backend != "nccl" or os.environ.get("IMPULSE_BENCH_BCAST", "lib") != "lib":
         return broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0, via_host=(backend != "nccl"))
-    # the communicator id is 128 bytes of control plane: rank 0 makes it, the launcher's process group hands it round
-    from impulse_hip._native import comm_unique_id
-    box = [comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    n, err = 0, None
-    try:
-        if os.environ.get("IMPULSE_BENCH_FAIL_LIB_BCAST") == "1":           # rehearsal of the fallback below
-            raise RuntimeError("IMPULSE_BENCH_FAIL_LIB_BCAST")
-        n = broadcast_plan_spectrum_rccl(plan, ctx, rank, world, unique_id=box[0])
-    except Exception as exc:                                  # noqa: BLE001 - agreed on below, then reported
-        err = repr(exc)
-    # every rank must take the same road: if the library's communicator failed anywhere (librccl not loadable, say),
-    # all ranks repeat the broadcast through the launcher's process group and the line says so
-    flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=device)
+    from impulse_hip._native import comm_probe, comm_unique_id
+    # preflight: ncclCommInitRank has no timeout, so every rank first says whether it can load librccl at all; only if
+    # ALL can does anyone create a communicator
+    bad = 0 if (comm_probe() and os.environ.get("IMPULSE_BENCH_FAIL_LIB_BCAST") != "1") else 1
+    flag = torch.tensor([bad], dtype=torch.int32, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     if int(flag.item()):
-        sys.stderr.write(f"[bench] rank {rank}: in-library RCCL broadcast failed ({err}); using torch.distributed\n")
-        global BROADCAST_VIA
-        BROADCAST_VIA = "torch.distributed (the library's own RCCL communicator failed: see stderr)"
+        sys.stderr.write(f"[bench] rank {rank}: librccl not loadable by the library on some rank; using torch.distributed\n")
+        BROADCAST_VIA = "torch.distributed (librccl could not be opened by the library on every rank: see stderr)"
         return broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0, via_host=False)
+    # the communicator id is 128 bytes of control plane: rank 0 makes it, the launcher's process group hands it round
+    box = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    n = broadcast_plan_spectrum_rccl(plan, ctx, rank, world, unique_id=box[0])
+    seen = torch.tensor([getattr(broadcast_plan_spectrum_rccl, "last_nranks", 0)], dtype=torch.int32, device=device)
+    dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+    RCCL_RANKS_SEEN = int(seen.item())
     dist.barrier()
     return n
 
 
-class DeviceBatch:
-    """A workload resident in HBM: plan, rotating input sets, per-lane output buffers (torch = device memory
-    plumbing only)."""
-
-    def __init__(self, torch, device, ctx, plan, rec, L, pitch, M, lanes, n_sets):
-        self.torch, self.device, self.ctx, self.plan = torch, device, ctx, plan
-        self.B, self.L, self.pitch, self.M = rec.shape[0], L, pitch, M
-        self.lanes = max(1, min(lanes, 4, plan.ws_channels))
-        plan.set_overlap(self.lanes)
-        d_x = torch.from_numpy(rec).to(device)
-        self.d_xs = [d_x] + [d_x.clone() for _ in range(n_sets - 1)]
-        # output rows: same pitch; the first sample of a row is placed so that the crop offset of the 'same' window
-        # lands the stores on 128-byte lines (the caller chooses where results go: here (M-1)/2 mod 32 samples in)
-        self.skew = ((M - 1) // 2) % 32 if os.environ.get("IMPULSE_BENCH_OUT_SKEW", "1") == "1" else 0
-        # overlapped launch groups must not write the same memory: one output buffer per lane, used round robin
-        self.d_ybufs = [torch.empty(self.B * pitch + 64, dtype=torch.float32, device=device) for _ in range(self.lanes)]
-        self.d_ys = [b[self.skew: self.skew + self.B * pitch].view(self.B, pitch) for b in self.d_ybufs]
-        self.n = 0
-        torch.cuda.synchronize(device)
-
-    def measurement(self):
-        """one launch-group sequence over one input set (B channels)"""
-        out = self.d_ys[self.n % len(self.d_ys)]
-        src = self.d_xs[self.n % len(self.d_xs)]
-        self.n += 1
-        self.plan.execute_device(src.data_ptr(), self.B, self.pitch, out.data_ptr(), self.pitch)
-
-    def step(self):
-        for _ in range(len(self.d_xs)):
-            self.measurement()
-
-    def sync(self):
-        self.ctx.synchronize()
-        self.torch.cuda.synchronize(self.device)
-
-    def outputs(self):
-        return [b.cpu().numpy()[:, :self.L] for b in self.d_ys]
-
-    def release(self):
-        self.plan.close()
-        self.d_xs = self.d_ys = self.d_ybufs = None
-
-
-def strong_block(args, torch, dist, device, comm_device, ctx, rank, world, backend):
+def strong_block(args, torch, dist, comm_device, device, ctx, rank, world, backend):
     """BASELINE.json configs[4]: 1024 channels x 2^20 samples sharded over the ranks (strong scaling), then rank 0
-    alone over all of them for the single-GPU figure of the same run."""
+    alone over all of them for the single-GPU figure of the same run.  Deconvolution (K1) only, as the config says."""
     from impulse_hip import ConvPlan
-    from impulse_hip.sharding import broadcast_plan_spectrum, shard_channels
+    from impulse_hip.sharding import shard_channels
     total = args.strong_channels
     est = make_estimator("c5")
     M = len(est)
@@ -585,46 +633,53 @@ def strong_block(args, torch, dist, device, comm_device, ctx, rank, world, backe
         plan = ConvPlan(ctx, None, M, "same", ws_channels=lanes * grp, empty_M=M, n_filters=1)
     bcast = 0
     if dist is not None:
-        bcast = spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world, "c5")
+        bcast = spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world)
     plan.set_overlap(lanes)
     base, L, pitch, dl = synth_recordings(est, 64, seed0=0xC5, column=M)
-    d_base = torch.from_numpy(base).to(device)
+    d_base = ctx.malloc(base.nbytes)
+    ctx.h2d(d_base, base)
+    row_bytes = pitch * 4
 
     def timed(lo, hi, everyone):
         n = hi - lo
-        reps = -(-n // 64)
         # channel c of the 1024-channel batch is recording c % 64 (tiled on the device)
-        d_x = torch.roll(d_base, -(lo % 64), 0).repeat(reps, 1)[:n].contiguous()
+        d_x = ctx.malloc(n * row_bytes)
+        for i in range(n):
+            ctx.d2d(d_x + i * row_bytes, d_base + ((lo + i) % 64) * row_bytes, row_bytes)
         skew = ((M - 1) // 2) % 32
-        d_ybuf = torch.empty(n * pitch + 64, dtype=torch.float32, device=device)
-        d_y = d_ybuf[skew: skew + n * pitch].view(n, pitch)
+        d_ybuf = ctx.malloc((n * pitch + 64) * 4)
+        d_y = d_ybuf + 4 * skew
+        ctx.synchronize()
 
         def one_pass():
-            plan.execute_device(d_x.data_ptr(), n, pitch, d_y.data_ptr(), pitch)
+            plan.execute_device(d_x, n, pitch, d_y, pitch)
 
         one_pass()
         ctx.synchronize()
-        torch.cuda.synchronize(device)
         if everyone and dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(args.strong_passes):
             one_pass()
         ctx.synchronize()
-        torch.cuda.synchronize(device)
         el = time.perf_counter() - t0
         if everyone and dist is not None:
             t = torch.tensor([el], dtype=torch.float64, device=comm_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        # parity: every channel's peak where the analytic truth puts it (sampled rows come to the host)
+        # parity: every sampled channel's peak where the analytic truth puts it, and bit-equal to its twin 64 channels on
+        # (same recording -> same bits whatever launch group / lane)
         rows = sorted(set(list(range(0, n, max(1, n // 16))) + [n - 1]))
-        y = d_y[rows].cpu().numpy()[:, :L]
-        ok = all(int(np.argmax(np.abs(y[i]))) == M // 2 + dl[(lo + r) % 64] for i, r in enumerate(rows))
-        # tiles bit-equal their twins (same recording 64 channels apart -> same bits whatever launch group / lane)
-        if n > 64:
-            ok &= bool(torch.equal(d_y[:n - 64, :L], d_y[64:n, :L]))
-        del d_x, d_y, d_ybuf
+        ok = True
+        y, twin = np.empty(pitch, dtype=np.float32), np.empty(pitch, dtype=np.float32)
+        for r in rows:
+            ctx.d2h(y, d_y + r * row_bytes)
+            ok &= int(np.argmax(np.abs(y[:L]))) == M // 2 + dl[(lo + r) % 64]
+            if r + 64 < n:
+                ctx.d2h(twin, d_y + (r + 64) * row_bytes)
+                ok &= bool(np.array_equal(y[:L], twin[:L]))
+        ctx.free(d_x)
+        ctx.free(d_ybuf)
         return el, ok
 
     lo, hi = shard_channels(total, world, rank)
@@ -639,13 +694,14 @@ def strong_block(args, torch, dist, device, comm_device, ctx, rank, world, backe
         flag = torch.tensor([1 if flag_ok else 0], dtype=torch.int32, device=comm_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         flag_ok = bool(flag.item())
-    ranks_seen = dist.get_world_size() if dist is not None else 1
     nfft = plan.nfft
     plan.close()
+    ctx.free(d_base)
     out = None
     if rank == 0:
         rate = total * args.strong_passes / el_n
-        out = dict(workload=WORKLOADS["c5"][3], channels=total, scaling="strong", n_gpus=world, ranks_seen=ranks_seen,
+        out = dict(workload=WORKLOADS["c5"][3], channels=total, scaling="strong", n_gpus=world,
+                   ranks_seen=dist.get_world_size() if dist is not None else 1, rccl_ranks_seen=RCCL_RANKS_SEEN,
                    channels_per_rank=hi - lo, passes=args.strong_passes, value=rate, unit="IR/s",
                    ms_per_pass=el_n / args.strong_passes * 1e3, nfft=nfft,
                    path_frac=rate / world * 8.0 * L / 1e9 / HBM_PEAK_GBS,
@@ -669,6 +725,8 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.pmc_child:
+        return pmc_child(args)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.rehearse_launch:
@@ -681,16 +739,19 @@ def main(argv=None):
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
-    dist = None
+    torch = dist = device = comm_device = None
     # IMPULSE_BENCH_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks: ranks are
     # folded onto the visible devices and the spectrum broadcast is staged through host memory.
     backend = os.environ.get("IMPULSE_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend == "gloo" else local_rank
+    dev_index = local_rank
     # IMPULSE_BENCH_FORCE_DIST=1 takes the collective path with a single rank too (a one-GPU box can
-    # then exercise RCCL init, the spectrum broadcast and the reductions)
+    # then exercise RCCL init, the spectrum broadcast and the reductions).  torch is the LAUNCHER's control plane
+    # (rendezvous, barriers, clock reductions) and is imported for N > 1 only.
     if world > 1 or os.environ.get("IMPULSE_BENCH_FORCE_DIST") == "1":
+        import torch
         import torch.distributed as dist
+        if backend == "gloo":
+            dev_index = local_rank % max(torch.cuda.device_count(), 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -700,129 +761,178 @@ def main(argv=None):
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
-    device = torch.device("cuda", dev_index)
-    comm_device = device if backend == "nccl" else torch.device("cpu")
+        device = torch.device("cuda", dev_index)
+        comm_device = device if backend == "nccl" else torch.device("cpu")
 
     from impulse_hip import Context, ConvPlan
-    from impulse_hip.sharding import broadcast_plan_spectrum, shard_channels
+    from impulse_hip.sharding import shard_channels
 
-    fs, dur, B, desc = WORKLOADS[args.workload]
+    fs, dur, B_meas, desc = WORKLOADS[args.workload]
     est = make_estimator(args.workload)
     strong = args.workload in ("c4", "c5")
-    mpg, B_meas = 1, B
-    if strong:
-        lo, hi = shard_channels(B, world, rank)
-        total_channels, B = B, hi - lo
-        # 64 distinct recordings tiled over the shard keep host set-up short; L = N = 2^20
-        base, L, pitch, dl = synth_recordings(est, min(B, 64), seed0=0xC5 + lo, column=len(est))
-        reps = -(-B // base.shape[0])
-        rec = np.tile(base, (reps, 1))[:B]
-        delays = (dl * reps)[:B]
-    else:
-        mpg = max(1, args.measurements_per_group or MEASUREMENTS_PER_GROUP[args.workload])
-        B_meas, B = B, B * mpg                       # a resident block = mpg measurements, rows contiguous
-        rec, L, pitch, delays = synth_recordings(est, B, seed0=0xC2 + 1000 * rank)
-        total_channels = B * world
+    stage = "deconv" if strong else args.stage
+    inv = np.asarray(est.inverse_filter, dtype=np.float64)
     M = len(est)
+    lanes = max(1, min(args.lanes, 4))
+    if strong:
+        lo, hi = shard_channels(B_meas, world, rank)
+        B = GROUP_CHANNELS[args.workload] * min(lanes, 3)     # channels per call: one launch group per lane
+        rec, L, pitch, delays = synth_recordings(est, B, seed0=0xC5 + lo, column=len(est))
+        mpb = 1
+        n_blocks = args.blocks or max(1, (hi - lo) // B)      # one step = one pass over this rank's shard
+    else:
+        mpb = MEASUREMENTS_PER_BLOCK[args.workload]
+        B = B_meas * mpb                                      # a resident block = mpb measurements, rows contiguous
+        rec, L, pitch, delays = synth_recordings(est, B, seed0=0xC2 + 1000 * rank)
+        # C2: 272 blocks x 2 measurements x 16 channels = 8 704 IRs per step: 20 steps time ~0.5 s at 340 k IR/s
+        n_blocks = args.blocks or int(os.environ.get("IMPULSE_BENCH_BLOCKS", "0")) or DEFAULT_BLOCKS[args.workload]
+    irs_per_step_rank = n_blocks * B
 
     ctx = Context(dev_index)
-    # C2: a resident block (mpg measurements) is one launch group; C3 cuts its 26 channels into two groups of 13
-    # (tools/k1_rate.py at C3's sizes: 9 ch x 3 lanes 185 k, 13 x 3 198 k, 26 x 2 204 k IR/s)
-    group_channels = B if args.workload == "c2" else GROUP_CHANNELS[args.workload]
-    ws_channels = args.ws_channels or max(1, args.lanes) * group_channels
-    if rank == 0:
-        plan = ConvPlan(ctx, np.asarray(est.inverse_filter, dtype=np.float64), L, "same", ws_channels=ws_channels)
-    else:
-        plan = ConvPlan(ctx, None, L, "same", ws_channels=ws_channels, empty_M=M, n_filters=1)
-    bcast_bytes = 0
-    if dist is not None:
-        bcast_bytes = spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world, "c2")
+    ring = InputRing(ctx, rec, n_blocks)
+    group_channels = B if not strong else GROUP_CHANNELS[args.workload]
+    bcast_bytes = [0]
 
-    # Successive measurements read DIFFERENT copies of the batch, 1 GiB in rotation, so that no input line survives in
-    # the 256 MiB Infinity Cache from one use to the next: inputs come from HBM, as a stream of new measurements would.
-    # (Re-reading one 25 MB batch every time measured 9 % higher at C2: 429 k vs 391-395 k IR/s.)
-    batch_bytes = rec.size * 4
-    n_sets = args.input_sets or int(os.environ.get("IMPULSE_BENCH_INPUT_SETS", "0")) or \
-        max(1, min(40, -(-(1 << 30) // batch_bytes)))
-    wl = DeviceBatch(torch, device, ctx, plan, rec, L, pitch, M, args.lanes, n_sets)
-    lanes = wl.lanes
+    def k1_plan(c, ws_channels, paired=False):
+        """rank 0 prepares the inverse-sweep spectrum; every other rank receives it (the path's one collective)"""
+        if rank == 0:
+            plan = ConvPlan(c, inv, L, "same", ws_channels=ws_channels, fused=False, paired=paired)
+        else:
+            plan = ConvPlan(c, None, L, "same", ws_channels=ws_channels, empty_M=M, n_filters=1, fused=False, paired=paired)
+        if dist is not None:
+            bcast_bytes[0] = spectrum_broadcast(plan, c, dist, torch, device, backend, rank, world)
+        return plan
 
-    def barrier():
-        wl.sync()
+    def barrier(obj):
+        obj.sync()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        wl.step()
-    barrier()
-    groups_per_measurement = -(-B // (plan.ws_channels // lanes))
-    groups_timed = args.steps * n_sets * groups_per_measurement
-    # at least ~8 sampled launch groups however short the run
-    plan.set_timing(0 if args.no_events else max(1, min(args.event_stride, groups_timed // 8)))
-    plan.get_timing(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
-    wl.sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        dist.barrier()
-    kernel_ms, launches = plan.get_timing(reset=True)
-    plan.set_timing(0)
-    # the same kernels with nothing else on the chip (strictly serial launch groups), outside the timed
-    # region: under overlap a kernel's event-to-event time includes the share of the chip it cedes to the
-    # other groups in flight, so both views are reported
-    iso_ms, iso_n = kernel_ms, launches
-    if lanes > 1:
-        barrier()
-        plan.set_overlap(1)
-        plan.set_timing(1)
-        for _ in range(max(4, min(40, n_sets))):
-            wl.measurement()
-        ctx.synchronize()
-        iso_ms, iso_n = plan.get_timing(reset=True)
-        plan.set_timing(0)
-        plan.set_overlap(lanes)
+    def timed_steps(obj, steps, warmup):
+        for _ in range(warmup):
+            obj.step()
+        barrier(obj)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            obj.step()
+        obj.sync()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=comm_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+            dist.barrier()
+        return el
 
-    # parity gate on what the timed loop produced (outside the timed region)
     peaks_ok = True
-    ys = wl.outputs()
+    shape = fir_stage_shape(est)
+    n_fir, K_fir, head, fade = shape
+    # ---------------------------------------------------------------- K1 alone (secondary; headline for C4 / C5)
+    plan = k1_plan(ctx, lanes * group_channels)
+    dec = DeconvOnly(ctx, plan, ring, B, L, pitch, M, lanes)
+    dec_steps = args.steps if stage == "deconv" else max(2, args.steps // 4)
+    groups_per_call = -(-B // (plan.ws_channels // dec.lanes))
+    groups_timed = dec_steps * n_blocks * groups_per_call
+    stride = 0 if args.no_events else max(1, min(args.event_stride, groups_timed // 8))
+    plan.set_timing(stride if stage == "deconv" else 0)
+    dec_elapsed = timed_steps(dec, dec_steps, args.warmup if stage == "deconv" else 1)
+    k1_ms, k1_n = plan.get_timing(reset=True)
+    plan.set_timing(0)
+    # the same kernels with nothing else on the chip (strictly serial launch groups), outside the timed region: under
+    # overlap a kernel's event-to-event time includes the share of the chip it cedes to the other groups in flight
+    barrier(dec)
+    plan.set_overlap(1)
+    plan.set_timing(1)
+    for p in ring.ptrs[:max(4, min(40, n_blocks))]:
+        dec.call(p)
+    ctx.synchronize()
+    iso_ms, iso_n = plan.get_timing(reset=True)
+    plan.set_timing(0)
+    plan.set_overlap(dec.lanes)
+    for p in ring.ptrs[:dec.lanes]:                            # every output buffer written by the overlapped form again
+        dec.call(p)
+    dec.sync()
+    ys = dec.outputs()
     for y in ys:
         peaks_ok &= all(int(np.argmax(np.abs(y[c]))) == M // 2 + delays[c] for c in range(B))
-    y = ys[-1]
+    y_k1 = ys[-1]
+    nfft, plan_ws, skew = plan.nfft, plan.ws_channels, dec.skew
+    dec.release()
+    dec_rate_rank = irs_per_step_rank * dec_steps / dec_elapsed
+    # pair mode on the same planar rows (two channels per complex transform), where the lengths allow it
+    pair_block = None
+    if not strong and rank == 0 and world == 1:
+        try:
+            from impulse_hip._native import plan_geometry_paired
+            if plan_geometry_paired(M, L, "same") is not None:
+                pplan = ConvPlan(ctx, inv, L, "same", ws_channels=lanes * group_channels, fused=False, paired=True)
+                pdec = DeconvOnly(ctx, pplan, ring, B, L, pitch, M, lanes)
+                psteps = max(2, args.steps // 4)
+                pel = timed_steps(pdec, psteps, 1)
+                pys = pdec.outputs()
+                p_ok = all(int(np.argmax(np.abs(yy[c]))) == M // 2 + delays[c] for yy in pys for c in range(B))
+                peaks_ok &= p_ok
+                prate = irs_per_step_rank * psteps / pel
+                pair_block = dict(value=prate, unit="IR/s", rows=pplan.n1, path_frac=prate * 8.0 * L / 1e9 / HBM_PEAK_GBS,
+                                  peak_indices_exact=bool(p_ok), max_rel_diff_vs_mono=float(
+                                      np.max(np.abs(pys[-1].astype(np.float64) - y_k1)) / np.max(np.abs(y_k1))),
+                                  note="K1 in pair mode on the same planar rows: channels (2q, 2q + 1) as ONE complex signal "
+                                       "x_L + i x_R, pointwise H in the row pass (rows_single_kernel); same circular length, "
+                                       "same workspace bytes - DESIGN.md section 7 has the per-pass times and why both modes "
+                                       "meet the same fabric ceiling")
+                pdec.release()
+        except Exception as exc:                              # noqa: BLE001 - secondary figure only
+            pair_block = dict(error=repr(exc))
+
+    # ---------------------------------------------------------------- the chain (the metric)
+    team, chain_elapsed, chain_k1, chain_k5, firs = None, None, None, None, None
+    y_chain = pk_chain = None
+    if stage == "chain":
+        team = ChainTeam(dev_index, est, inv, ring, L, pitch, B, lanes, k1_plan0=lambda c: k1_plan(c, B))
+        team.step()
+        barrier(team)
+        calls_timed = args.steps * n_blocks
+        team.set_timing(0 if args.no_events else max(1, min(args.event_stride, calls_timed // 8)))
+        chain_elapsed = timed_steps(team, args.steps, args.warmup)
+        chain_k1, chain_k5 = team.timing()
+        team.set_timing(0)
+        y_chain, pk_chain = team.fetch(-1)
+        firs = team.firs
+        peaks_ok &= all(abs(int(pk_chain[c]) - (M // 2 + delays[c])) <= 8 for c in range(B))   # exact check: against the oracle below
     if dist is not None:                      # rank 0 reports the verdict of every rank
         flag = torch.tensor([1 if peaks_ok else 0], dtype=torch.int32, device=comm_device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         peaks_ok = bool(flag.item())
-    ranks_seen = dist.get_world_size() if dist is not None else 1
-    nfft = plan.nfft
-    plan_ws = plan.ws_channels
-    wl.release()
+    if team is not None:
+        team.release()
+    ring.release()
 
     strong_c5 = None
     if (world > 1 and not args.no_strong) or args.strong:
-        strong_c5, s_ok = strong_block(args, torch, dist, device, comm_device, ctx, rank, world, backend)
+        strong_c5, s_ok = strong_block(args, torch, dist, comm_device, device, ctx, rank, world, backend)
         peaks_ok &= s_ok
 
-    result = None
     if rank == 0:
-        irs_per_step = total_channels * n_sets
-        value = irs_per_step * args.steps / elapsed
-        alg_bytes_per_launch = 8.0 * L * B / groups_per_measurement          # average over this rank's launch groups
-        names = ("cols_kernel<fwd> (pass A)", "rows_kernel (pass B)", "cols_kernel<inv> (pass C)")
+        irs_per_step = irs_per_step_rank * world
+        steps_timed = args.steps if stage == "chain" else dec_steps
+        elapsed = chain_elapsed if stage == "chain" else dec_elapsed
+        value = irs_per_step * steps_timed / elapsed
+        dec_value = dec_rate_rank * world
+        alg_k1_launch = 8.0 * L * B / groups_per_call                    # algorithmic bytes of one K1 launch group
+        alg_chain_ir = 4.0 * L + 4.0 * (n_fir + K_fir - 1)                # recording in, equalised cropped response out
+        names = ("cols_kernel<fwd> (K1 pass A)", "rows_kernel (K1 pass B)", "cols_kernel<inv> (K1 pass C)")
+        # per-kernel times over the TIMED region: from the chains' K1 plans when the chain is what is timed
+        t_ms, t_n = (chain_k1 if stage == "chain" else (np.asarray(k1_ms), k1_n))
         roof = None
-        if launches > 0:
-            avg_ms = [m / launches for m in kernel_ms]
+        if t_n > 0:
+            avg_ms = [float(m) / t_n for m in t_ms]
             dom = int(np.argmax(avg_ms))
-            achieved = alg_bytes_per_launch / (avg_ms[dom] * 1e-3) / 1e9
+            achieved = alg_k1_launch / (avg_ms[dom] * 1e-3) / 1e9
             iso_avg = [m / max(iso_n, 1) for m in iso_ms]
-            iso_achieved = alg_bytes_per_launch / (iso_avg[dom] * 1e-3) / 1e9
+            iso_achieved = alg_k1_launch / (iso_avg[dom] * 1e-3) / 1e9
             prof, prof_src, live = None, None, False
             if world == 1 and not args.no_pmc and not strong:
-                prof = live_pmc_traffic(args.workload, mpg)
+                prof = live_pmc_traffic(args.workload)
                 live = prof is not None
                 prof_src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command, made by this run"
             if prof is None:
@@ -833,42 +943,56 @@ def main(argv=None):
                         traffic_source=("live" if live else "committed summary") if prof else None,
                         traffic_note=(f"L2<->fabric bytes per launch of the dominant kernel (FETCH_SIZE x2 + WRITE_SIZE, "
                                       f"Infinity-Cache hits INCLUDED, so not HBM bytes); separate --pmc passes, strictly serial "
-                                      f"launch groups; source: {prof_src}") if prof else None,
+                                      f"launches; source: {prof_src}") if prof else None,
                         avg_kernel_ms=dict(zip(("pass_a", "pass_b", "pass_c"), avg_ms)),
-                        events_sampled=int(launches), launch_groups_in_flight=lanes,
-                        note="achieved/frac: algorithmic bytes of one launch group / HIP-event time of the dominant kernel "
-                             "over the timed region; with several launch groups in flight that time includes the share of "
-                             "the chip the kernel cedes to the others, so `isolated` (strictly serial groups) and "
-                             "`path_frac` (whole path, all kernels) are the cleaner figures",
+                        events_sampled=int(t_n), launch_groups_in_flight=lanes,
+                        note="achieved/frac: algorithmic bytes (8 L per IR) of one K1 launch group / HIP-event time of the "
+                             "dominant kernel over the timed region; with several launch groups in flight that time includes "
+                             "the share of the chip the kernel cedes to the others, so `isolated` (strictly serial groups) "
+                             "and the `path_frac` figures (whole path, all kernels) are the cleaner ones",
                         isolated=dict(note="same kernel, launch groups strictly serial (nothing else on the chip), "
-                                           "measured after the timed region", achieved=iso_achieved,
+                                           "measured outside the timed region", achieved=iso_achieved,
                                       frac=iso_achieved / HBM_PEAK_GBS,
                                       avg_kernel_ms=dict(zip(("pass_a", "pass_b", "pass_c"), iso_avg))),
-                        algorithmic_bytes_per_launch=alg_bytes_per_launch,
-                        launch_groups_per_step=groups_per_measurement * n_sets,
-                        path_achieved=value / world * 8.0 * L / 1e9,
-                        path_frac=value / world * 8.0 * L / 1e9 / HBM_PEAK_GBS)
-            if prof and all(k in prof for k in ("rows_kernel_bytes_per_launch", "cols_fwd_bytes_per_launch",
-                                                "cols_inv_bytes_per_launch")):
-                moved = sum(prof[k] for k in ("rows_kernel_bytes_per_launch", "cols_fwd_bytes_per_launch",
-                                              "cols_inv_bytes_per_launch"))
-                rate = moved * groups_per_measurement * n_sets / (elapsed / args.steps) / 1e9
+                        algorithmic_bytes_per_launch=alg_k1_launch,
+                        deconv_only_path_achieved=dec_value / world * 8.0 * L / 1e9,
+                        deconv_only_path_frac=dec_value / world * 8.0 * L / 1e9 / HBM_PEAK_GBS)
+            if stage == "chain":
+                roof["path_achieved"] = value / world * alg_chain_ir / 1e9
+                roof["path_frac"] = roof["path_achieved"] / HBM_PEAK_GBS
+                roof["path_note"] = ("path_*: the chain, algorithmic bytes per IR = 4 L in + 4 (n + K - 1) out = "
+                                     f"{alg_chain_ir / 1e6:.2f} MB (the 0.68 s equalised response is all that leaves the path); "
+                                     "deconv_only_path_*: K1 alone at 8 L per IR (last round's headline figure)")
+                if chain_k5 and chain_k5[1]:
+                    roof["fused_k5_avg_ms"] = chain_k5[0] / chain_k5[1]
+            else:
+                roof["path_achieved"], roof["path_frac"] = roof["deconv_only_path_achieved"], roof["deconv_only_path_frac"]
+            if prof and all(k + "_bytes_per_launch" in prof for k in ("rows_kernel", "cols_fwd", "cols_inv")):
+                moved_k1 = sum(prof[k + "_bytes_per_launch"] for k in ("rows_kernel", "cols_fwd", "cols_inv"))
+                moved_tail = sum(prof.get(k + "_bytes_per_launch", 0.0) for k in ("peak_search", "fir_block"))
+                per_call = moved_k1 * groups_per_call + (moved_tail if stage == "chain" else 0.0)
+                rate = per_call * n_blocks / (elapsed / steps_timed) / 1e9
                 roof["l2_fabric_traffic"] = dict(
-                    bytes_per_launch_group=moved, rate=rate, unit="GB/s", source=prof_src,
-                    note="bytes passes A+B+C move across the L2<->fabric boundary per launch group (rocprofv3 --pmc, see "
-                         "traffic_note) / this run's time per launch group.  Infinity-Cache hits are counted, so this is a "
-                         "FABRIC rate, not achieved HBM bandwidth; it is not compared with the HBM peak")
-        cpu = None
-        parity = dict(peak_indices_exact=bool(peaks_ok))
+                    bytes_per_call=per_call, k1_bytes_per_launch_group=moved_k1,
+                    peak_search_plus_fused_k5_bytes_per_call=moved_tail if stage == "chain" else None,
+                    rate=rate, unit="GB/s", source=prof_src,
+                    note=f"bytes the kernels of one call ({B} channels) move across the L2<->fabric boundary (rocprofv3 --pmc, "
+                         "see traffic_note) / this run's time per call.  Infinity-Cache hits are counted, so this is a FABRIC "
+                         "rate, not achieved HBM bandwidth; it is not compared with the HBM peak")
+        cpu, parity = None, dict(peak_indices_exact=bool(peaks_ok))
         if world == 1 and not args.no_cpu_baseline:
-            cpu, outs = cpu_baseline(est, rec, L)
-            errs, errs_full = [], []
-            for c, ref in outs.items():
+            with_fir = stage == "chain"
+            cpu, outs = cpu_baseline(est, rec, L, firs, shape, with_fir)
+            errs, errs_full, chain_errs = [], [], []
+            for c, (ref, pk_ref, ref_out) in outs.items():
                 pk = int(np.argmax(np.abs(ref)))
-                peaks_ok &= pk == int(np.argmax(np.abs(y[c])))
+                peaks_ok &= pk == int(np.argmax(np.abs(y_k1[c])))
                 for sl, acc in ((slice(pk - fs // 1000, pk - fs // 1000 + int(0.68 * fs)), errs), (slice(None), errs_full)):
-                    A, R = np.abs(np.fft.rfft(y[c][sl].astype(np.float64))), np.abs(np.fft.rfft(ref[sl]))
+                    A, R = np.abs(np.fft.rfft(y_k1[c][sl].astype(np.float64))), np.abs(np.fft.rfft(ref[sl]))
                     acc.append(float(np.max(np.abs(A - R)) / np.max(R)))
+                if with_fir:
+                    peaks_ok &= int(pk_chain[c]) == pk_ref
+                    chain_errs.append(float(np.max(np.abs(y_chain[c] - ref_out)) / np.max(np.abs(ref_out))))
             floor = fp32_fft_floor(est, rec[0], L)
             parity = dict(peak_indices_exact=bool(peaks_ok), spectrum_max_rel_err=max(errs), tolerance=1e-6,
                           spectrum_window="IR cropped as the pipeline does before any magnitude_response: peak - 1 ms, 0.68 s long",
@@ -879,47 +1003,59 @@ def main(argv=None):
                                             "reference's own pocketfft in single precision is listed beside it); reported, "
                                             "not gated",
                           channels_checked=len(errs))
+            if with_fir:
+                parity["chain_time_max_rel_err"] = max(chain_errs)
+                parity["chain_note"] = ("equalised cropped responses of the timed chain against the oracle chain in float64 "
+                                        "(max |dy| / max |y|); peak indices of the device search equal the oracle's")
+                peaks_ok &= max(chain_errs) <= 1e-6
             try:
                 parity["real_demo_column"] = demo_column_error()
             except Exception as exc:                          # noqa: BLE001 - reported figure only
                 parity["real_demo_column"] = dict(error=repr(exc))
             peaks_ok &= max(errs) <= 1e-6
-            cpu["pooled"] = cpu_pooled(est, rec, L)
+            parity["peak_indices_exact"] = bool(peaks_ok)
         whole_slice = None
         if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
             try:
                 whole_slice = slice_rate(est, rec[:B_meas], L)
             except Exception as exc:                          # noqa: BLE001 - secondary figure only
                 whole_slice = dict(error=repr(exc))
-        fir_leg = None
-        if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
-            try:
-                fir_leg = deconv_fir_leg(dev_index, est, rec, L, pitch, per_meas=B_meas)
-                peaks_ok &= fir_leg["parity"]["peak_indices_exact"] and fir_leg["parity"]["time_max_rel_err"] <= 1e-6
-            except Exception as exc:                          # noqa: BLE001 - secondary figure only
-                fir_leg = dict(error=repr(exc))
         result = {
-            "metric": METRIC, "value": value, "unit": "IR/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "timed_region_s": elapsed, "irs_per_step": irs_per_step, "ranks_seen": ranks_seen,
-            "config": {"workload": desc, "stage": "K1 ONLY: batched sweep deconvolution incl. 'same' crop "
-                       "(inverse-filter spectrum prepared once, outside the timed region); the FIR stages are not in the "
-                       "timed region (`deconv_fir` = K1 -> peak -> crop -> K5 FIR on device pointers; `slice` = the whole hot-path slice end to end)",
-                       "step": f"one pass over {n_sets * mpg} resident measurements of {B_meas} channels per GPU, "
-                               f"{mpg} measurement(s) = {B} channels per K1 launch group",
-                       "channels_per_gpu_per_measurement": B_meas, "measurements_per_step": n_sets * mpg,
-                       "measurements_per_launch_group": mpg, "channels_per_launch_group": B // groups_per_measurement,
-                       "sweep_samples": M, "column_samples": L,
-                       "layout": f"planar fp32, row pitch {pitch} samples (multiple of {PITCH_ALIGN}); output rows start "
-                                 f"{wl.skew} samples into 256-byte aligned buffers so the cropped stores fall on cache lines",
-                       "nfft": nfft, "launch_groups_in_flight": lanes, "workspace_channels": plan_ws,
+            "metric": METRIC, "value": value, "unit": "IR/s", "n_gpus": world, "steps": steps_timed,
+            "warmup": args.warmup, "ms_per_step": elapsed / steps_timed * 1e3,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "timed_region_s": elapsed, "irs_per_step": irs_per_step,
+            "ranks_seen": dist.get_world_size() if dist is not None else 1, "rccl_ranks_seen": RCCL_RANKS_SEEN,
+            "config": {"workload": desc,
+                       "stage": ("sweep deconvolution + FIR as the metric names it: K1 deconvolution ('same' crop) -> K3 first peak -> "
+                                 "K4 crop (peak - 1 ms, 0.68 s) + Hann fades -> K5 per-channel "
+                                 f"{K_fir}-tap FIR, one device chain per call (imp_chain: K1's three passes, the peak search, one "
+                                 "fused overlap-save FIR launch); spectra prepared once, outside the timed region.  `deconv_only` = K1 "
+                                 "alone; `slice` = the whole hot-path slice end to end") if stage == "chain" else
+                                "K1 ONLY: batched sweep deconvolution incl. 'same' crop (inverse-filter spectrum prepared once, "
+                                "outside the timed region)",
+                       "step": f"one pass over {n_blocks} resident blocks of {mpb} measurement(s) = {B} channels per GPU "
+                               f"({n_blocks * rec.nbytes / 2 ** 30:.1f} GiB of inputs in rotation), one call per block, "
+                               f"{lanes} calls in flight",
+                       "channels_per_gpu_per_measurement": B_meas, "measurements_per_step": n_blocks * mpb,
+                       "measurements_per_call": mpb, "channels_per_call": B, "channels_per_launch_group": B // groups_per_call,
+                       "sweep_samples": M, "column_samples": L, "fir_taps": K_fir if stage == "chain" else None,
+                       "crop_samples": n_fir if stage == "chain" else None,
+                       "layout": f"planar fp32, row pitch {pitch} samples (multiple of {PITCH_ALIGN})",
+                       "nfft": nfft, "chains_in_flight": lanes, "workspace_channels": plan_ws,
+                       "device_memory": "libimpulse_hip (imp_malloc); torch only as the launcher's control plane at N > 1",
                        "sharding": (f"channels x{world}, no data-path collective; "
                                     f"one {(BROADCAST_VIA or 'RCCL (by libimpulse_hip, no torch in the data path)') if backend == 'nccl' else backend + ' (rehearsal)'} broadcast of "
-                                    f"{bcast_bytes} B spectrum at plan creation") if dist is not None else
+                                    f"{bcast_bytes[0]} B spectrum at plan creation") if dist is not None else
                                    "single rank: no collective"},
-            "roofline": roof, "cpu_baseline": cpu, "parity": parity, "slice": whole_slice, "deconv_fir": fir_leg,
-            "strong_c5": strong_c5,
+            "roofline": roof, "cpu_baseline": cpu, "parity": parity,
+            "deconv_only": dict(value=dec_value, unit="IR/s", steps=dec_steps, timed_region_s=dec_elapsed,
+                                path_frac=dec_value / world * 8.0 * L / 1e9 / HBM_PEAK_GBS,
+                                layout=f"planar fp32; output rows start {skew} samples into 256-byte aligned buffers so the "
+                                       "cropped stores fall on cache lines",
+                                note="K1 alone over the same resident inputs (last round's headline), algorithmic bytes 8 L per IR",
+                                pair_mode=pair_block),
+            "slice": whole_slice, "strong_c5": strong_c5,
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
@@ -928,7 +1064,7 @@ def main(argv=None):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and not peaks_ok:
-        raise SystemExit("parity gate failed: deconvolved peak indices / cropped spectra do not match the truth")
+        raise SystemExit("parity gate failed: peak indices / cropped spectra / chain outputs do not match the truth")
     return 0
 
 

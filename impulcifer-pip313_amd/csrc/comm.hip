@@ -19,6 +19,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -41,7 +42,8 @@ int rccl_load() {
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(h, "ncclBroadcast"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.GetErrorString)
+  r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(h, "ncclCommCount"));
+  if (!r.CommCount || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.GetErrorString)
     return fail(IMP_ERR_UNSUPPORTED, "librccl lacks an expected entry point");
   g_rccl = r;
   return IMP_OK;
@@ -93,6 +95,17 @@ extern "C" int imp_comm_create(imp_ctx* ctx, const unsigned char id[128], int ra
     return fail(IMP_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
   }
   *out = c;
+  return IMP_OK;
+}
+
+// librccl loadable and complete?  No communicator, no device work: the ranks agree on this BEFORE any of them enters
+// ncclCommInitRank, which has no timeout (a rank that failed to load the library would leave the others blocked there).
+extern "C" int imp_comm_probe(void) { return rccl_load(); }
+
+// ranks of the communicator as RCCL itself counts them (ncclCommCount)
+extern "C" int imp_comm_nranks(imp_comm* c, int* nranks) {
+  if (!c || !nranks) return fail(IMP_ERR_INVALID, "imp_comm_nranks: null argument");
+  RCCL_TRY(g_rccl.CommCount(c->comm, nranks));
   return IMP_OK;
 }
 

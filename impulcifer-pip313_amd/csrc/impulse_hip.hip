@@ -131,7 +131,13 @@ extern "C" int imp_device_count(int* n) {
   return IMP_OK;
 }
 
-extern "C" int imp_ctx_create(int device_id, imp_ctx** out) {
+int ctx_new_stream(imp_ctx* ctx, hipStream_t* out) {
+  if (ctx->cu_mask.empty()) HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+  else HIP_TRY(hipExtStreamCreateWithCUMask(out, (uint32_t)ctx->cu_mask.size(), ctx->cu_mask.data()));
+  return IMP_OK;
+}
+
+static int ctx_create_impl(int device_id, const uint32_t* cu_mask, int mask_words, imp_ctx** out) {
   if (!out) return fail(IMP_ERR_INVALID, "imp_ctx_create: null output");
   *out = nullptr;
   int n = 0;
@@ -149,10 +155,18 @@ extern "C" int imp_ctx_create(int device_id, imp_ctx** out) {
   imp_ctx* ctx = new (std::nothrow) imp_ctx();
   if (!ctx) return fail(IMP_ERR_ALLOC, "out of host memory");
   ctx->device = device_id;
-  hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-  if (se != hipSuccess) {
+  if (cu_mask && mask_words > 0) {
+    ctx->cu_mask.assign(cu_mask, cu_mask + mask_words);
+    bool any = false;
+    for (uint32_t w : ctx->cu_mask) any |= w != 0;
+    if (!any) {
+      delete ctx;
+      return fail(IMP_ERR_INVALID, "imp_ctx_create_masked: the CU mask is empty");
+    }
+  }
+  if (ctx_new_stream(ctx, &ctx->stream)) {
     delete ctx;
-    return fail(IMP_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
+    return IMP_ERR_HIP;
   }
   if (const char* mb = std::getenv("IMPULSE_HIP_POOL_MB")) ctx->free_cap = (size_t)std::max(0ll, std::atoll(mb)) << 20;
   int rc = ctx_row_tables(ctx);
@@ -163,6 +177,13 @@ extern "C" int imp_ctx_create(int device_id, imp_ctx** out) {
   }
   *out = ctx;
   return IMP_OK;
+}
+
+extern "C" int imp_ctx_create(int device_id, imp_ctx** out) { return ctx_create_impl(device_id, nullptr, 0, out); }
+
+extern "C" int imp_ctx_create_masked(int device_id, const uint32_t* cu_mask, int mask_words, imp_ctx** out) {
+  if (!cu_mask || mask_words < 1 || mask_words > 64) return fail(IMP_ERR_INVALID, "imp_ctx_create_masked: bad CU mask");
+  return ctx_create_impl(device_id, cu_mask, mask_words, out);
 }
 
 extern "C" int imp_ctx_set_stream(imp_ctx* ctx, void* hip_stream) {
@@ -1426,7 +1447,7 @@ extern "C" int imp_plan_set_overlap(imp_plan* p, int lanes) {
   if ((rc = plan_sync_lanes(p))) return rc;
   while ((int)p->ctx->side_streams.size() < lanes - 1) {
     hipStream_t st;
-    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if ((rc = ctx_new_stream(p->ctx, &st))) return rc;
     p->ctx->side_streams.push_back(st);
   }
   p->lanes = lanes;
@@ -1628,9 +1649,11 @@ struct imp_chain {
   int64_t B = 0, n = 0, head = 0, fade_in = 0, fade_out = 0, pitch_ir = 0;
   double peak_height = 0.12589;
   int lanes = 1;
+  int sets = 1;                     // buffer sets in rotation: the lanes, and one more when the tail has a stream of its own
+  int64_t calls = 0;
   int tiles = 0;
   int64_t chunks = 0;               // chunks per channel: N1 of the deconvolution (pair mode: N1 / 2)
-  // one set per lane of the deconvolution plan
+  // buffer sets, used round robin: call i may deconvolve into one set while the tail of call i - 1 still reads another
   std::vector<float*> d_ir;         // [B][pitch_ir]: the deconvolved columns
   std::vector<unsigned*> d_tile;    // [B][column tiles][chunks]: max|y| per tile and 8 192-sample chunk, left by pass C
   std::vector<imp::RowPeak*> d_res;
@@ -1712,6 +1735,7 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
   c->fade_out = fade_out;
   c->peak_height = peak_height;
   c->lanes = deconv->lanes;
+  c->sets = deconv->ctx == fir->ctx ? 1 : c->lanes + 1;
   c->pitch_ir = (deconv->out_len + 63) / 64 * 64;
   std::vector<int64_t> meta((size_t)(2 * B));
   for (int64_t b = 0; b < B; ++b) {
@@ -1729,7 +1753,7 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
                        c->d_win, (long long)fade_in, (long long)fade_out);
     ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(deconv->ctx->stream) == hipSuccess;
   }
-  for (int l = 0; l < c->lanes && ok; ++l) {
+  for (int l = 0; l < c->sets && ok; ++l) {
     float* ir = nullptr;
     unsigned* tile = nullptr;
     imp::RowPeak* res = nullptr;
@@ -1745,7 +1769,7 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
     ok = ok && hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
     if (e2) c->ir_free.push_back(e2);
   }
-  c->ir_busy.assign((size_t)c->lanes, 0);
+  c->ir_busy.assign((size_t)c->sets, 0);
   if (!ok) {
     (void)hipGetLastError();
     imp_chain_destroy(c);
@@ -1769,8 +1793,9 @@ extern "C" int imp_chain_execute_device(imp_chain* c, const float* d_x, int64_t 
     return fail(IMP_ERR_INVALID, "imp_chain_execute_device: a plan's overlap / resident setting changed since the chain was made");
   int rc = ctx_bind(c->ctx);
   if (rc) return rc;
-  const int l = c->lanes > 1 ? (int)(c->deconv->group_counter_lane % c->lanes) : 0;      // the lane run_group will pick
-  hipStream_t lane_stream = l ? c->ctx->side_streams[(size_t)(l - 1)] : c->ctx->stream;
+  const int lane = c->lanes > 1 ? (int)(c->deconv->group_counter_lane % c->lanes) : 0;   // the lane run_group will pick
+  const int l = (int)(c->calls++ % c->sets);                                              // this call's buffer set
+  hipStream_t lane_stream = lane ? c->ctx->side_streams[(size_t)(lane - 1)] : c->ctx->stream;
   hipStream_t tail = c->tail_ctx->stream;
   if (c->ir_busy[(size_t)l] && tail != lane_stream) HIP_TRY(hipStreamWaitEvent(lane_stream, c->ir_free[(size_t)l], 0));
   c->deconv->tile_max = c->d_tile[(size_t)l];
@@ -1782,10 +1807,14 @@ extern "C" int imp_chain_execute_device(imp_chain* c, const float* d_x, int64_t 
     HIP_TRY(hipEventRecord(c->k1_done[(size_t)l], lane_stream));
     HIP_TRY(hipStreamWaitEvent(tail, c->k1_done[(size_t)l], 0));
   }
+  // measurement switch (tools/chain_rate.py): 1 = stop after the peak search, 2 = stop after K1 - the outputs are then stale
+  static const int skip = [] { const char* e = std::getenv("IMPULSE_HIP_CHAIN_SKIP"); return e ? atoi(e) : 0; }();
+  if (skip >= 2) return IMP_OK;
   hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)c->B), dim3(imp::kPeakThreads), 0, tail, c->d_ir[(size_t)l],
                      c->d_meta, c->d_meta + c->B, c->deconv->out_start, (const unsigned*)c->d_tile[(size_t)l], c->tiles,
                      (const unsigned*)nullptr, c->chunks, c->d_res[(size_t)l], c->peak_height, d_peaks_out);
   HIP_TRY(hipGetLastError());
+  if (skip >= 1) return IMP_OK;
   imp::LoadCropAtPeak ld{c->d_ir[(size_t)l], c->pitch_ir, c->deconv->out_len, c->d_res[(size_t)l], c->n, c->head, c->fade_in, c->fade_out,
                          c->d_win};
   if ((rc = run_group_with(c->fir, ld, c->B, d_out, chan_stride_out, 0, 2))) return rc;

@@ -58,6 +58,7 @@ SIGNATURES = {
     "imp_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "imp_ctx_synchronize": (C.c_int, [_vp]),
     "imp_ctx_destroy": (None, [_vp]),
+    "imp_ctx_create_masked": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(_vp)]),
     "imp_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "imp_free": (C.c_int, [_vp, _vp]),
     "imp_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -86,6 +87,8 @@ SIGNATURES = {
     "imp_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "imp_comm_create": (C.c_int, [_vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(_vp)]),
     "imp_comm_destroy": (None, [_vp]),
+    "imp_comm_probe": (C.c_int, []),
+    "imp_comm_nranks": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "imp_comm_broadcast": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
     "imp_plan_broadcast_spectrum": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(C.c_size_t)]),
     "imp_plan_set_filters": (C.c_int, [_vp, _pd, _i64]),
@@ -192,14 +195,22 @@ def _ptr_i64(a):
 class Context:
     """One GPU + one stream (imp_ctx)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, cus=None):
+        """cus: optional iterable of CU indices this context's streams are restricted to (imp_ctx_create_masked)"""
         lib = load_library()
         n = C.c_int(0)
         rc = lib.imp_device_count(C.byref(n))
         if rc != 0 or n.value <= 0:
             raise NativeUnavailable("no HIP device visible: the impulse_hip product path needs an MI355X (gfx950)")
         h = _vp()
-        rc = lib.imp_ctx_create(int(device), C.byref(h))
+        if cus is None:
+            rc = lib.imp_ctx_create(int(device), C.byref(h))
+        else:
+            cus = sorted(set(int(c) for c in cus))
+            words = (C.c_uint32 * (max(cus) // 32 + 1))()
+            for c in cus:
+                words[c // 32] |= 1 << (c % 32)
+            rc = lib.imp_ctx_create_masked(int(device), words, len(words), C.byref(h))
         if rc != 0:
             msg = lib.imp_last_error().decode("utf-8", "replace")
             raise NativeUnavailable(f"imp_ctx_create({device}) failed: {msg}")
@@ -540,6 +551,11 @@ class FirChain:
             pass
 
 
+def comm_probe():
+    """True if librccl loads with every entry point the library uses (no communicator is made)."""
+    return load_library().imp_comm_probe() == 0
+
+
 def comm_unique_id():
     """128 bytes that identify a new RCCL communicator (rank 0 makes them and shares them with the other ranks)."""
     buf = (C.c_ubyte * 128)()
@@ -560,6 +576,12 @@ class Comm:
         _check(self._lib.imp_comm_create(ctx.handle, buf, self.rank, self.nranks, C.byref(h)))
         self._h = h
         ctx._plans.add(self)
+
+    def nranks_seen(self):
+        """ranks of the communicator as RCCL itself counts them"""
+        n = C.c_int(0)
+        _check(self._lib.imp_comm_nranks(self._h, C.byref(n)))
+        return int(n.value)
 
     def broadcast(self, dptr, nbytes, root=0):
         _check(self._lib.imp_comm_broadcast(self._h, _vp(int(dptr)), int(nbytes), int(root)))

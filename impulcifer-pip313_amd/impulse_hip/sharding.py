@@ -62,6 +62,10 @@ def share_unique_id(rank, path, make_id=None, timeout_s=120.0):
     import os
     import time
     if rank == 0:
+        try:
+            os.remove(path)                               # a stale id left by an earlier launch must not be picked up
+        except OSError:
+            pass
         uid = make_id()
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "wb") as fh:
@@ -95,7 +99,9 @@ def broadcast_plan_spectrum_rccl(plan, ctx, rank, world_size, unique_id=None, re
         unique_id = share_unique_id(rank, rendezvous_path, _native.comm_unique_id)
     comm = _native.Comm(ctx, unique_id, rank, world_size)
     try:
-        return comm.broadcast_plan_spectrum(plan, root=src)
+        nbytes = comm.broadcast_plan_spectrum(plan, root=src)
+        broadcast_plan_spectrum_rccl.last_nranks = comm.nranks_seen()      # ranks as RCCL counted them
+        return nbytes
     finally:
         comm.close()
         if rank == 0 and rendezvous_path is not None:

@@ -46,6 +46,11 @@ const char* imp_version(void);
 const char* imp_last_error(void);
 int imp_device_count(int* n);
 int imp_ctx_create(int device_id, imp_ctx** out);
+/* A context whose streams (its own and the lanes of imp_plan_set_overlap) run on a SUBSET of the CUs: bit i of cu_mask =
+ * CU i (mask_words 32-bit words, hipExtStreamCreateWithCUMask).  Two contexts with complementary masks share the GPU
+ * without competing for CUs: the deconvolution + FIR chain keeps the latency-bound tail kernels (peak search, fused K5 -
+ * workgroups that need a whole CU) on a few CUs of their own while the bandwidth-bound K1 passes fill the rest. */
+int imp_ctx_create_masked(int device_id, const uint32_t* cu_mask, int mask_words, imp_ctx** out);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int imp_ctx_set_stream(imp_ctx* ctx, void* hip_stream);
 int imp_ctx_synchronize(imp_ctx* ctx);
@@ -390,6 +395,12 @@ typedef struct imp_comm imp_comm;
 int imp_comm_unique_id(unsigned char id_out[128]);
 int imp_comm_create(imp_ctx* ctx, const unsigned char id[128], int rank, int nranks, imp_comm** out);
 void imp_comm_destroy(imp_comm* c);
+/* 0 if librccl can be loaded and has every entry point used here (no communicator, no device work).  ncclCommInitRank
+ * has no timeout, so the ranks should agree on this over the launcher's control plane BEFORE any of them creates a
+ * communicator. */
+int imp_comm_probe(void);
+/* ranks of the communicator as RCCL counts them (ncclCommCount) */
+int imp_comm_nranks(imp_comm* c, int* nranks);
 /* in-place broadcast of `bytes` at device pointer dptr from rank `root`; returns when the data has arrived */
 int imp_comm_broadcast(imp_comm* c, void* dptr, size_t bytes, int root);
 /* imp_plan_spectrum + imp_comm_broadcast; *bytes_out (may be NULL) = bytes moved */

@@ -1411,8 +1411,9 @@ def _bench_line(res):
 
 def test_bench_contract_line(gpu_ctx):
     """bench.py prints exactly one JSON line on stdout with the contract's keys, BASELINE.json's metric, a
-    roofline block and (at N = 1) a cpu_baseline block; everything else goes to stderr.  A step is one pass over
-    all resident measurements, so even the contract's short runs time tens of milliseconds."""
+    roofline block and (at N = 1) a cpu_baseline block; everything else goes to stderr.  `value` times the metric's own
+    wording - the deconvolution + FIR chain - and K1 alone is given beside it (`deconv_only`).  A step is one pass over all
+    resident measurements (8 704 IRs), so the contract's 20 steps time about half a second."""
     import json
     import subprocess
     import sys
@@ -1427,24 +1428,31 @@ def test_bench_contract_line(gpu_ctx):
         assert key in d, key
     assert (d["n_gpus"], d["steps"], d["warmup"], d["scaling"], d["higher_is_better"]) == (1, 10, 2, "weak", True)
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
-    assert d["ms_per_step"] * d["steps"] >= 10.0 and abs(d["timed_region_s"] * 1e3 - d["ms_per_step"] * 10) < 1e-6
+    assert d["ms_per_step"] * d["steps"] >= 100.0 and abs(d["timed_region_s"] * 1e3 - d["ms_per_step"] * 10) < 1e-6
     assert abs(d["value"] - d["irs_per_step"] * d["steps"] / d["timed_region_s"]) <= 1e-6 * d["value"]
     cfg = d["config"]
-    assert cfg["channels_per_gpu_per_measurement"] == 16 and cfg["measurements_per_launch_group"] == 2
-    assert cfg["channels_per_launch_group"] == 32 and d["irs_per_step"] == 16 * cfg["measurements_per_step"]
+    assert cfg["channels_per_gpu_per_measurement"] == 16 and cfg["measurements_per_call"] == 2
+    assert cfg["channels_per_launch_group"] == 32 and d["irs_per_step"] == 16 * cfg["measurements_per_step"] == 8704
+    assert "FIR" in cfg["stage"] and cfg["fir_taps"] == 9600 and cfg["crop_samples"] == 32640
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
-    assert 0 < r["path_frac"] < 1 and 0 < r["isolated"]["frac"] < 1
+    assert 0 < r["path_frac"] < r["deconv_only_path_frac"] < 1 and 0 < r["isolated"]["frac"] < 1
     # the counters behind `traffic` are collected by this very run (two rocprofv3 --pmc child runs); the row pass moves
     # its workspace once each way plus alpha/beta: between 1.2 and 1.7 times the algorithmic bytes of a launch group
     assert r["traffic_source"] == "live", r["traffic_note"]
     assert 1.2 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.7
+    assert r["l2_fabric_traffic"]["peak_search_plus_fused_k5_bytes_per_call"] > 0
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["sample"]
-    assert d["parity"]["peak_indices_exact"] and d["parity"]["spectrum_max_rel_err"] <= 1e-6
-    assert d["parity"]["real_demo_column"]["peak_index_equal"]
+    assert c["kind"] == "port" and c["cores"] > 1 and c["value"] > 0 and c["sample"] and "FIR" in c["work"]
+    assert c["serial"]["cores"] == 1 and 0 < c["serial"]["value"] < c["value"]
+    p = d["parity"]
+    assert p["peak_indices_exact"] and p["spectrum_max_rel_err"] <= 1e-6 and p["chain_time_max_rel_err"] <= 1e-6
+    assert p["real_demo_column"]["peak_index_equal"]
     assert d["value"] > 100 * c["value"]
+    k1 = d["deconv_only"]
+    assert k1["value"] > d["value"] and 0 < k1["path_frac"] < 1
+    assert k1["pair_mode"]["peak_indices_exact"] and k1["pair_mode"]["rows"] == 132 and k1["pair_mode"]["max_rel_diff_vs_mono"] < 2e-6
 
 
 def test_bench_two_ranks_started_plainly(gpu_ctx):
@@ -1457,7 +1465,7 @@ def test_bench_two_ranks_started_plainly(gpu_ctx):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["IMPULSE_BENCH_BACKEND"] = "gloo"
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-                          "--strong-channels", "128", "--strong-passes", "2"],
+                          "--blocks", "24", "--strong-channels", "128", "--strong-passes", "2"],
                          capture_output=True, text=True, timeout=900, cwd=root, env=env)
     d = _bench_line(res)
     assert (d["n_gpus"], d["ranks_seen"], d["scaling"]) == (2, 2, "weak") and d["value"] > 0

@@ -10,7 +10,13 @@ from collections import defaultdict
 def short(name):
     if "rows_kernel" in name:
         return "rows_kernel"
-    if "cols_kernel" in name or "cols_mixed_kernel" in name:
+    if "rows_single_kernel" in name:
+        return "rows_single"
+    if "fir_block_kernel" in name:
+        return "fir_block"
+    if "row_first_peak_chunked_kernel" in name:
+        return "peak_search"
+    if "cols_kernel" in name or "cols_mixed_kernel" in name or "cols_small_kernel" in name:
         return "cols_fwd" if ", -1, " in name else "cols_inv"
     return name[:40]
 
