@@ -60,7 +60,9 @@ WORKLOADS = {
 GROUP_CHANNELS = {"c2": 32, "c3": 13, "c4": 8, "c5": 8}
 MEASUREMENTS_PER_BLOCK = {"c2": 2, "c3": 1}
 DEFAULT_BLOCKS = {"c2": 272, "c3": 96, "c4": 12, "c5": 12}
-CHAINS = 3                     # chains (K1 launch groups) in flight
+# calls (chains / K1 launch groups) in flight = streams.  C3's 26-channel calls carry 2.4x the workspace of C2's 32: two of
+# them fill the Infinity Cache (26 ch x 2: 204 k IR/s K1, 26 x 3: 160 k)
+CHAINS = {"c2": 3, "c3": 2, "c4": 3, "c5": 3}
 
 
 def parse_args(argv=None):
@@ -70,8 +72,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, default=CHAINS,
-                    help="chains / K1 launch groups in flight; 1 = strictly serial kernels")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="chains / K1 launch groups in flight (0: 3, 2 at C3); 1 = strictly serial kernels")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not collect FETCH_SIZE / WRITE_SIZE with rocprofv3 child runs (roofline.traffic then comes from "
@@ -244,19 +246,32 @@ def copy_spectrum(dst_plan, src_plan, ctx):
 
 
 class ChainTeam:
-    """`chains` deconvolution + FIR chains, each on its own pair of contexts (K1 on one stream; peak search + fused K5 on a
-    second one, so the next call's K1 runs beside them), fed round robin with the blocks of the input ring."""
+    """One deconvolution + FIR chain per context, fed round robin with the blocks of the input ring.  Each chain is five
+    launches in ONE stream (K1's three passes, the peak search, the fused K5): three chains = three streams, fewer than the
+    four hardware queues a HIP process gets, so none of them is multiplexed with another.  (A tail stream per chain for the
+    peak search and K5 - tails="own" / "shared", the library supports it - measured 15 % slower: 320 k against 375 k IR/s;
+    the event edges between streams cost more than the overlap buys.  tools/chain_team_rate.py.)"""
 
-    def __init__(self, dev_index, est, inv, ring, L, pitch, B, chains, firs=None, k1_plan0=None):
+    def __init__(self, contexts, est, inv, ring, L, pitch, B, firs=None, k1_plan0=None, tails="none"):
         from impulse_hip import Context, ConvPlan
         from impulse_hip._native import FirChain
         self.ring, self.L, self.pitch, self.B = ring, L, pitch, B
         self.n, self.K, self.head, self.fade = fir_stage_shape(est)
         self.firs = synth_firs(B, self.K) if firs is None else firs
         self.po = (self.n + self.K - 1 + 63) // 64 * 64
-        self.lanes = []
-        for i in range(chains):
-            ctx, tail = Context(dev_index), Context(dev_index)
+        self.lanes, self.owned = [], []
+        shared_tail = None
+        if tails == "shared":
+            shared_tail = Context(contexts[0].device)
+            self.owned.append(shared_tail)
+        for i, ctx in enumerate(contexts):
+            if tails == "none":
+                tail = ctx
+            elif tails == "shared":
+                tail = shared_tail
+            else:
+                tail = Context(ctx.device)
+                self.owned.append(tail)
             if i == 0 and k1_plan0 is not None:
                 plan1 = k1_plan0(ctx)                               # rank 0: from the filter; other ranks: empty + broadcast
             elif i == 0:
@@ -323,61 +338,102 @@ class ChainTeam:
             ln["plan5"].close()
             for p in ln["outs"] + [ln["d_pk"]]:
                 ln["ctx"].free(p)
-            ln["tail"].close()
-            ln["ctx"].close()
-        self.lanes = []
+        for c in reversed(self.owned):
+            c.close()
+        self.lanes, self.owned = [], []
 
 
-class DeconvOnly:
-    """K1 alone over the input ring: one plan, `lanes` launch groups in flight, one output buffer per lane."""
+class K1Team:
+    """K1 alone over the input ring: one plan per context (= one launch group in flight per stream), fed round robin."""
 
-    def __init__(self, ctx, plan, ring, B, L, pitch, M, lanes):
-        self.ctx, self.plan, self.ring, self.B, self.L, self.pitch = ctx, plan, ring, B, L, pitch
-        self.lanes = max(1, min(lanes, 4))
-        plan.set_overlap(self.lanes)
+    def __init__(self, contexts, inv, ring, B, L, pitch, M, group_channels, plan0=None, paired=False):
+        from impulse_hip import ConvPlan
+        self.ring, self.B, self.L, self.pitch = ring, B, L, pitch
         # output rows: same pitch; the first sample of a row is placed so that the crop offset of the 'same' window
         # lands the stores on 128-byte lines (the caller chooses where results go: here (M-1)/2 mod 32 samples in)
         self.skew = ((M - 1) // 2) % 32 if os.environ.get("IMPULSE_BENCH_OUT_SKEW", "1") == "1" else 0
-        self.bufs = [ctx.malloc((B * pitch + 64) * 4) for _ in range(self.lanes)]
+        self.lanes = []
+        for i, ctx in enumerate(contexts):
+            if i == 0 and plan0 is not None:
+                plan = plan0(ctx)
+            elif i == 0:
+                plan = ConvPlan(ctx, inv, L, "same", ws_channels=group_channels, fused=False, paired=paired)
+            else:
+                plan = ConvPlan(ctx, None, L, "same", ws_channels=group_channels, empty_M=len(inv), n_filters=1, fused=False,
+                                paired=paired)
+                copy_spectrum(plan, self.lanes[0]["plan"], ctx)
+            self.lanes.append(dict(ctx=ctx, plan=plan, buf=ctx.malloc((B * pitch + 64) * 4)))
+        self.plan = self.lanes[0]["plan"]
         self.n = 0
 
-    def call(self, d_x):
-        out = self.bufs[self.n % self.lanes] + 4 * self.skew
+    def call(self, d_x, lane=None):
+        ln = self.lanes[(self.n if lane is None else lane) % len(self.lanes)]
         self.n += 1
-        self.plan.execute_device(d_x, self.B, self.pitch, out, self.pitch)
+        ln["plan"].execute_device(d_x, self.B, self.pitch, ln["buf"] + 4 * self.skew, self.pitch)
 
     def step(self):
         for p in self.ring.ptrs:
             self.call(p)
 
     def sync(self):
-        self.ctx.synchronize()
+        for ln in self.lanes:
+            ln["ctx"].synchronize()
+
+    def set_timing(self, every):
+        for ln in self.lanes:
+            ln["plan"].set_timing(every)
+            ln["plan"].get_timing(reset=True)
+
+    def timing(self, lanes=None):
+        ms, n = np.zeros(3), 0
+        for ln in (self.lanes if lanes is None else [self.lanes[i] for i in lanes]):
+            m, k = ln["plan"].get_timing(reset=True)
+            ms += np.asarray(m)
+            n += k
+        return ms, n
 
     def outputs(self):
         ys = []
-        for b in self.bufs:
+        for ln in self.lanes:
             y = np.empty((self.B, self.pitch), dtype=np.float32)
-            self.ctx.d2h(y, b + 4 * self.skew)
+            ln["ctx"].d2h(y, ln["buf"] + 4 * self.skew)
             ys.append(y[:, :self.L])
         return ys
 
     def release(self):
         self.sync()
-        self.plan.close()
-        for b in self.bufs:
-            self.ctx.free(b)
+        for ln in self.lanes:
+            ln["plan"].close()
+            ln["ctx"].free(ln["buf"])
+        self.lanes = []
 
 
 # ------------------------------------------------------------------------------------------------------
 # CPU baseline: the NumPy oracle of the same work on this box's host cores
 # ------------------------------------------------------------------------------------------------------
+def cpu_peak_index(ir):
+    """ImpulseResponse.peak_index on the host the way the reference runs it: scipy.signal.find_peaks (compiled) where SciPy
+    is present (core/impulse_response.py:52-70), else the oracle's pure-NumPy restatement of it (20x slower: a baseline
+    timed with that would flatter the GPU)."""
+    try:
+        from scipy.signal import find_peaks
+    except ImportError:
+        from oracle.impulse_response import peak_index
+        return peak_index(ir)
+    mx = np.max(np.abs(ir))
+    if mx < 1e-20:
+        return 0
+    seg = ir / mx
+    peaks = np.concatenate([find_peaks(seg, height=0.12589)[0], find_peaks(-seg, height=0.12589)[0]])
+    return int(np.min(peaks)) if len(peaks) else int(np.argmax(np.abs(seg)))
+
+
 def oracle_chain(x, inv, fir, n, head, fade):
     """estimate -> peak_index -> crop at peak - head (n samples, clamped) with Hann fades -> fir, 'full' (float64)"""
     from oracle.estimator import estimate
-    from oracle.impulse_response import peak_index
     from oracle.scipy_restated import fft_convolve, hann
     ir = estimate(x, inv)
-    pk = peak_index(ir)
+    pk = cpu_peak_index(ir)
     s0 = min(max(pk - head, 0), len(ir) - n)
     w = np.ones(n)
     w[:head] *= hann(2 * head)[:head]
@@ -543,7 +599,7 @@ def pmc_child(args):
     ctx = Context(0)
     ring = InputRing(ctx, rec, 2)
     inv = np.asarray(est.inverse_filter, dtype=np.float64)
-    team = ChainTeam(0, est, inv, ring, L, pitch, B, 1)
+    team = ChainTeam([ctx], est, inv, ring, L, pitch, B)
     for _ in range(3):
         team.step()
         team.sync()
@@ -626,7 +682,7 @@ def strong_block(args, torch, dist, comm_device, device, ctx, rank, world, backe
     # launch groups of 12 channels on two lanes: 24 workspaces of 6.3 MB in flight (tools/k1_rate.py at 2^20 x 2^20:
     # 8 ch x 3 lanes 132 k, 12 x 2 139 k, 12 x 3 126 k, 16 x 2 136 k IR/s)
     grp = 12
-    lanes = max(1, min(args.lanes, 2))
+    lanes = max(1, min(args.lanes or 2, 2))
     if rank == 0:
         plan = ConvPlan(ctx, np.asarray(est.inverse_filter, dtype=np.float64), M, "same", ws_channels=lanes * grp)
     else:
@@ -773,7 +829,7 @@ def main(argv=None):
     stage = "deconv" if strong else args.stage
     inv = np.asarray(est.inverse_filter, dtype=np.float64)
     M = len(est)
-    lanes = max(1, min(args.lanes, 4))
+    lanes = max(1, min(args.lanes or CHAINS[args.workload], 4))
     if strong:
         lo, hi = shard_channels(B_meas, world, rank)
         B = GROUP_CHANNELS[args.workload] * min(lanes, 3)     # channels per call: one launch group per lane
@@ -788,7 +844,10 @@ def main(argv=None):
         n_blocks = args.blocks or int(os.environ.get("IMPULSE_BENCH_BLOCKS", "0")) or DEFAULT_BLOCKS[args.workload]
     irs_per_step_rank = n_blocks * B
 
-    ctx = Context(dev_index)
+    # one context (= one stream) per call in flight, made once and used by every leg: K1 alone, pair mode and the chains.
+    # Three streams stay below the four hardware queues a HIP process gets by default, so no two are multiplexed.
+    contexts = [Context(dev_index) for _ in range(lanes)]
+    ctx = contexts[0]
     ring = InputRing(ctx, rec, n_blocks)
     group_channels = B if not strong else GROUP_CHANNELS[args.workload]
     bcast_bytes = [0]
@@ -828,35 +887,31 @@ def main(argv=None):
     shape = fir_stage_shape(est)
     n_fir, K_fir, head, fade = shape
     # ---------------------------------------------------------------- K1 alone (secondary; headline for C4 / C5)
-    plan = k1_plan(ctx, lanes * group_channels)
-    dec = DeconvOnly(ctx, plan, ring, B, L, pitch, M, lanes)
+    dec = K1Team(contexts, inv, ring, B, L, pitch, M, group_channels, plan0=lambda c: k1_plan(c, group_channels))
     dec_steps = args.steps if stage == "deconv" else max(2, args.steps // 4)
-    groups_per_call = -(-B // (plan.ws_channels // dec.lanes))
+    groups_per_call = -(-B // group_channels)
     groups_timed = dec_steps * n_blocks * groups_per_call
     stride = 0 if args.no_events else max(1, min(args.event_stride, groups_timed // 8))
-    plan.set_timing(stride if stage == "deconv" else 0)
+    dec.set_timing(stride if stage == "deconv" else 0)
     dec_elapsed = timed_steps(dec, dec_steps, args.warmup if stage == "deconv" else 1)
-    k1_ms, k1_n = plan.get_timing(reset=True)
-    plan.set_timing(0)
-    # the same kernels with nothing else on the chip (strictly serial launch groups), outside the timed region: under
-    # overlap a kernel's event-to-event time includes the share of the chip it cedes to the other groups in flight
+    k1_ms, k1_n = dec.timing()
+    # the same kernels with nothing else on the chip (launch groups strictly serial: one stream), outside the timed
+    # region: under overlap a kernel's event-to-event time includes the share of the chip it cedes to the other groups
     barrier(dec)
-    plan.set_overlap(1)
-    plan.set_timing(1)
+    dec.set_timing(1)
     for p in ring.ptrs[:max(4, min(40, n_blocks))]:
-        dec.call(p)
-    ctx.synchronize()
-    iso_ms, iso_n = plan.get_timing(reset=True)
-    plan.set_timing(0)
-    plan.set_overlap(dec.lanes)
-    for p in ring.ptrs[:dec.lanes]:                            # every output buffer written by the overlapped form again
-        dec.call(p)
+        dec.call(p, lane=0)
+    dec.sync()
+    iso_ms, iso_n = dec.timing(lanes=[0])
+    dec.set_timing(0)
+    for i, p in enumerate(ring.ptrs[:len(contexts)]):          # every lane's output written by the overlapped form again
+        dec.call(p, lane=i)
     dec.sync()
     ys = dec.outputs()
     for y in ys:
         peaks_ok &= all(int(np.argmax(np.abs(y[c]))) == M // 2 + delays[c] for c in range(B))
     y_k1 = ys[-1]
-    nfft, plan_ws, skew = plan.nfft, plan.ws_channels, dec.skew
+    nfft, plan_ws, skew = dec.plan.nfft, dec.plan.ws_channels * len(contexts), dec.skew
     dec.release()
     dec_rate_rank = irs_per_step_rank * dec_steps / dec_elapsed
     # pair mode on the same planar rows (two channels per complex transform), where the lengths allow it
@@ -865,15 +920,14 @@ def main(argv=None):
         try:
             from impulse_hip._native import plan_geometry_paired
             if plan_geometry_paired(M, L, "same") is not None:
-                pplan = ConvPlan(ctx, inv, L, "same", ws_channels=lanes * group_channels, fused=False, paired=True)
-                pdec = DeconvOnly(ctx, pplan, ring, B, L, pitch, M, lanes)
+                pdec = K1Team(contexts, inv, ring, B, L, pitch, M, group_channels, paired=True)
                 psteps = max(2, args.steps // 4)
                 pel = timed_steps(pdec, psteps, 1)
                 pys = pdec.outputs()
                 p_ok = all(int(np.argmax(np.abs(yy[c]))) == M // 2 + delays[c] for yy in pys for c in range(B))
                 peaks_ok &= p_ok
                 prate = irs_per_step_rank * psteps / pel
-                pair_block = dict(value=prate, unit="IR/s", rows=pplan.n1, path_frac=prate * 8.0 * L / 1e9 / HBM_PEAK_GBS,
+                pair_block = dict(value=prate, unit="IR/s", rows=pdec.plan.n1, path_frac=prate * 8.0 * L / 1e9 / HBM_PEAK_GBS,
                                   peak_indices_exact=bool(p_ok), max_rel_diff_vs_mono=float(
                                       np.max(np.abs(pys[-1].astype(np.float64) - y_k1)) / np.max(np.abs(y_k1))),
                                   note="K1 in pair mode on the same planar rows: channels (2q, 2q + 1) as ONE complex signal "
@@ -888,7 +942,8 @@ def main(argv=None):
     team, chain_elapsed, chain_k1, chain_k5, firs = None, None, None, None, None
     y_chain = pk_chain = None
     if stage == "chain":
-        team = ChainTeam(dev_index, est, inv, ring, L, pitch, B, lanes, k1_plan0=lambda c: k1_plan(c, B))
+        team = ChainTeam(contexts, est, inv, ring, L, pitch, B, k1_plan0=lambda c: k1_plan(c, B),
+                         tails=os.environ.get("IMPULSE_BENCH_CHAIN_TAILS", "none"))
         team.step()
         barrier(team)
         calls_timed = args.steps * n_blocks
@@ -1059,7 +1114,8 @@ def main(argv=None):
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
-    ctx.close()
+    for c in reversed(contexts):
+        c.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
