@@ -1226,11 +1226,35 @@ def test_conv_fuzz_layouts_and_sizes(gpu_ctx):
             assert rel(y[b], ref) <= tol, (case, layout, L, M, mode, B, b)
 
 
-def test_c3_slice_13ch_96k_against_oracle(gpu_ctx):
-    """BASELINE config C3 end to end: 13-speaker layout x 2 ears at 96 kHz (5 s sweep, N = 635 965, column
-    827 965, circular length 1 179 648) through ingest -> crop_heads -> crop_tails -> room-error FIRs ->
-    equalize -> decay window -> normalize, product (device kernels K1/K3/K4/K7/K2/K6/K5/K8) against the
-    oracle composition of the same stages."""
+def _c3_tracks(e, rng, speakers, rt60, level):
+    """[2 ears][2 s lead + 13 columns] of a 13-speaker sweep measurement at the estimator's rate (SURVEY 8d recipe family):
+    per speaker and ear a direct sound plus a decaying noise tail, -85 dBFS background, rounded to fp32"""
+    fs, N = e.fs, len(e)
+    L = N + 2 * fs
+    tracks = np.zeros((2, 2 * fs + L * len(speakers)))
+    S = np.fft.rfft(level * e.test_signal, 1 << 20)
+    t = np.arange(30000) / fs
+    for i in range(len(speakers)):
+        for ear in range(2):
+            h = rng.standard_normal(30000) * 0.04 * 10 ** (-3.0 * t / rt60)
+            d0 = 40 + 7 * i + 23 * ear
+            h[: d0 + 30] = 0.0
+            h[d0] = 1.0 - 0.3 * ear
+            y = np.fft.irfft(S * np.fft.rfft(h, 1 << 20), 1 << 20)[: N + 30000 - 1]
+            seg = tracks[ear, 2 * fs + i * L: 2 * fs + (i + 1) * L]
+            seg[: len(y)] = y
+    tracks += rng.standard_normal(tracks.shape) * 10 ** (-85 / 20)
+    return tracks.astype(np.float32).astype(np.float64)
+
+
+def test_c3_slice_13ch_96k_against_oracle(gpu_ctx, tmp_path, monkeypatch):
+    """BASELINE config C3 as it is worded - "13-ch TrueHD layout x 2 ear @96 kHz with room_correction + decay window":
+    (1) room_correction() (core/room_correction.py:78-210) on a SECOND batch of 26 synthetic room recordings at 96 kHz
+    (one mono file per ear, 13 columns each; flat target, limit 400) against the oracle composition ingest -> crop_heads ->
+    crop_tails -> specific_room_correction; (2) ITS error curves drive the measurement batch (5 s sweep, N = 635 965, column
+    827 965, circular length 1 179 648) through ingest -> crop_heads -> crop_tails -> room-error FIRs -> equalize -> decay
+    window -> normalize, product (device kernels K1/K3/K4/K7/K2/K12/K6/K5/K8) against the oracle composition of the same
+    stages."""
     from impulse_hip.constants import TRUEHD_13CH_ORDER
     from impulse_hip.frequency_response import FrequencyResponse
     from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
@@ -1245,26 +1269,52 @@ def test_c3_slice_13ch_96k_against_oracle(gpu_ctx):
     assert N == 635965 == len(oe)
     speakers = list(TRUEHD_13CH_ORDER)
     L = N + 2 * fs
-    rng = np.random.default_rng(0xC3)
-    tracks = np.zeros((2, 2 * fs + L * len(speakers)))
-    S = np.fft.rfft(0.4 * e.test_signal, 1 << 20)
-    t = np.arange(30000) / fs
-    for i in range(len(speakers)):
-        for ear in range(2):
-            h = rng.standard_normal(30000) * 0.04 * 10 ** (-3.0 * t / 0.22)
-            d0 = 40 + 7 * i + 23 * ear
-            h[: d0 + 30] = 0.0
-            h[d0] = 1.0 - 0.3 * ear
-            y = np.fft.irfft(S * np.fft.rfft(h, 1 << 20), 1 << 20)[: N + 30000 - 1]
-            seg = tracks[ear, 2 * fs + i * L: 2 * fs + (i + 1) * L]
-            seg[: len(y)] = y
-    tracks += rng.standard_normal(tracks.shape) * 10 ** (-85 / 20)
-    tracks = tracks.astype(np.float32).astype(np.float64)                 # both sides see identical inputs
     common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
     assert len(common) == 852
-    errs = {(sp, sd): 2.5 * np.sin(3 * np.log10(common) + 0.3 * k) for k, (sp, sd) in
-            enumerate((sp, sd) for sp in speakers for sd in ("left", "right"))}
-    room = {sp: {sd: FrequencyResponse("r", frequency=common.copy(), raw=0, error=errs[(sp, sd)]) for sd in ("left", "right")}
+    order26 = [(sp, sd) for sp in speakers for sd in ("left", "right")]
+
+    # ---- (1) room correction on the second batch: 26 room responses at 96 kHz
+    from impulse_hip import room_correction as rc
+    from impulse_hip.audio_io import write_wav
+    room_tracks = _c3_tracks(e, np.random.default_rng(0xC3 + 1000), speakers, rt60=0.35, level=0.3)
+    names = [f"room-{','.join(speakers)}-{sd}.wav" for sd in ("left", "right")]
+    for k, nm in enumerate(names):
+        write_wav(str(tmp_path / nm), fs, room_tracks[k], bit_depth=32)
+    # the reference levels every channel to the FIRST one it meets in os.listdir order: fix that order
+    real_listdir = os.listdir
+    monkeypatch.setattr(rc.os, "listdir", lambda p: names + [f for f in real_listdir(p) if f not in names])
+    rir, frs = rc.room_correction(e, str(tmp_path), specific_limit=400)
+    assert sorted(frs) == sorted(speakers) and all(sorted(frs[sp]) == ["left", "right"] for sp in speakers)
+    np.testing.assert_array_equal(frs["FL"]["left"].frequency, common)
+    # oracle composition of the same: what the file holds (PCM_32) -> columns -> estimate -> crops -> curves
+    from impulse_hip.audio_io import pcm_quantise
+    o_irs = {}
+    for k, sd in enumerate(("left", "right")):
+        stored = pcm_quantise(room_tracks[k], 32) / 2.0 ** 31
+        for sp, side, col in ohrir.split_recording(stored[None, :], speakers, N, fs, side=sd):
+            o_irs.setdefault(sp, {})[side] = oe.estimate(col)
+    # room_correction crops every response at ITS OWN peak - 1 ms (core/room_correction.py:160-163), not pair-wise
+    o_irs = {sp: {sd: oir.crop_head(o_irs[sp][sd], fs) for sd in ("left", "right")} for sp in speakers}
+    o_tail, o_irs = ohrir.crop_tails(o_irs, fs, N, oe.n_octaves)
+    assert o_tail == len(rir.irs["FL"]["left"].data)
+    flat = np.zeros(len(common))
+    ref_gain, worst_db = None, 0.0
+    for sd in ("left", "right"):                                     # the file of the left ears is met first: FL-left sets the level
+        for sp in speakers:
+            _, o_raw, o_err, g_ = ofr.specific_room_correction(o_irs[sp][sd], fs, flat, None, limit=400, reference_gain=ref_gain)
+            if ref_gain is None:
+                ref_gain = g_
+            fr = frs[sp][sd]
+            # dB curves from fp32 responses: 1e-6 of the spectrum peak is ~1e-3 dB on bins 40-60 dB below it
+            worst_db = max(worst_db, float(np.max(np.abs(fr.raw - o_raw))), float(np.max(np.abs(fr.error - o_err))))
+            assert np.all(fr.error[common > 400] == 0.0)             # the limit mask
+    assert worst_db < 5e-3, worst_db
+    assert max(float(np.max(np.abs(frs[sp][sd].error))) for sp, sd in order26) > 1.0    # real corrections, not zeros
+
+    # ---- (2) the measurement batch, equalised with THOSE curves
+    tracks = _c3_tracks(e, np.random.default_rng(0xC3), speakers, rt60=0.22, level=0.4)
+    errs = {(sp, sd): np.array(frs[sp][sd].error, dtype=np.float64) for sp, sd in order26}
+    room = {sp: {sd: FrequencyResponse("r", frequency=common.copy(), raw=0, error=errs[(sp, sd)].copy()) for sd in ("left", "right")}
             for sp in speakers}
     stages = {}
     hrir, gain = run_slice(e, [((fs, tracks), speakers)], room_frs=room, decay=0.12, stages=stages)
