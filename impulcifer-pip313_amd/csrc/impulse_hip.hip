@@ -19,7 +19,9 @@
 
 #include "internal.h"
 #include "conv_kernels.hip.h"
+#ifdef IMP_XCD_RESIDENT          // the XCD-resident K1 experiment (measured slower): not in the default build
 #include "xcd_kernels.hip.h"
+#endif
 #include "ir_kernels.hip.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -483,7 +485,11 @@ struct imp_plan {
   cf* xws = nullptr;                 // [8][N1][4096]
   cf* xP = nullptr;                  // digit twiddles
   cf* xQ = nullptr;
+#ifdef IMP_XCD_RESIDENT
   imp::XcdCtl* xctl = nullptr;       // two control blocks, used alternately
+#else
+  void* xctl = nullptr;
+#endif
   unsigned* xsticky = nullptr;       // [0] sticky abort
   int xparity = 0;
   int64_t xlaunches = 0;
@@ -1179,7 +1185,10 @@ static int check_input_span(const imp_plan* p, int64_t elem_stride, size_t sampl
 // ------------------------------------------------------------------------------------------------
 static void resident_shape(const imp_plan* p, int* F, int* R2) {
   *F = *R2 = 0;
-  if (p->ola || p->paired) return;
+#ifndef IMP_XCD_RESIDENT
+  return;                                   // the persistent kernel is not compiled into this build
+#endif
+  if (p->ola || p->paired || p->fused) return;
   // one channel's workspace must stay in an XCD's 4 MiB L2 beside the digit twiddles and the row tables
   if ((int64_t)p->N1 * imp::kN2 * (int64_t)sizeof(cf) > ((int64_t)2600 << 10)) return;
   switch (p->N1) {
@@ -1189,6 +1198,7 @@ static void resident_shape(const imp_plan* p, int* F, int* R2) {
   }
 }
 
+#ifdef IMP_XCD_RESIDENT
 static int resident_alloc(imp_plan* p) {
   if (p->xws) return IMP_OK;
   hipDeviceProp_t prop;
@@ -1217,6 +1227,8 @@ static int resident_alloc(imp_plan* p) {
   return IMP_OK;
 }
 
+#endif
+
 static int resident_check(imp_plan* p) {
   if (!p->xsticky || p->xunchecked == 0) return IMP_OK;
   unsigned sticky = 0;
@@ -1229,6 +1241,7 @@ static int resident_check(imp_plan* p) {
   return IMP_OK;
 }
 
+#ifdef IMP_XCD_RESIDENT
 template <int F, int R2, class Load>
 static int launch_resident_shape(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64_t chan_stride_out, int64_t first_chan) {
   using Cfg = imp::XcdCfg<F, R2>;
@@ -1249,7 +1262,7 @@ static int launch_resident_shape(imp_plan* p, Load ld, int64_t nchan, float* d_y
   a.ctl_next = p->xctl + (1 - p->xparity);
   a.sticky = p->xsticky;
   const char* to = std::getenv("IMPULSE_HIP_RESIDENT_TIMEOUT_MS");
-  a.timeout_ticks = (unsigned)((to ? std::max(1, atoi(to)) : 250) * 100000);      // 100 MHz ticks
+  a.timeout_ticks = (unsigned)std::min<long long>((long long)(to ? std::max(1, atoi(to)) : 250) * 100000ll, 0xFFFFFFFFll);   // 100 MHz ticks
   imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
   imp::DigitTwiddles dt{p->xP, p->xQ};
   static const int wg_per_cu = [] { const char* e = std::getenv("IMPULSE_HIP_RESIDENT_WG_PER_CU"); return e ? std::max(1, std::min(2, atoi(e))) : 2; }();
@@ -1281,6 +1294,14 @@ static int run_resident(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64_t
   return IMP_OK;
 }
 
+#else
+static int resident_alloc(imp_plan*) { return fail(IMP_ERR_UNSUPPORTED, "the XCD-resident kernel is not compiled into this build (-DIMP_XCD_RESIDENT)"); }
+template <class Load>
+static int run_resident(imp_plan*, Load, int64_t, float*, int64_t, int64_t) {
+  return fail(IMP_ERR_UNSUPPORTED, "the XCD-resident kernel is not compiled into this build (-DIMP_XCD_RESIDENT)");
+}
+#endif
+
 extern "C" int imp_plan_set_resident(imp_plan* p, int on, int* available) {
   if (!p) return fail(IMP_ERR_INVALID, "null plan");
   IMP_CTX_LOCK(p->ctx);
@@ -1288,7 +1309,7 @@ extern "C" int imp_plan_set_resident(imp_plan* p, int on, int* available) {
   resident_shape(p, &f, &r2);
   if (available) *available = f ? 1 : 0;
   if (!on) {
-    p->resident = false;
+    if (!available) p->resident = false;      // with `available` given and on = 0 the call is a pure query
     return IMP_OK;
   }
   if (!f) return fail(IMP_ERR_UNSUPPORTED, "this plan (%d rows%s) does not qualify for the XCD-resident path", p->N1,
@@ -1309,6 +1330,7 @@ extern "C" int imp_plan_resident_status(imp_plan* p, int* aborted, unsigned* xcc
   if (xcc_seen) *xcc_seen = 0;
   if (wait_ticks) *wait_ticks = 0;
   if (!p->xctl) return IMP_OK;
+#ifdef IMP_XCD_RESIDENT
   int rc = ctx_bind(p->ctx);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
@@ -1327,6 +1349,7 @@ extern "C" int imp_plan_resident_status(imp_plan* p, int* aborted, unsigned* xcc
     if (last.clk[1].v) fprintf(stderr, "  xcd diag shader clock %.3f GHz (s_memtime / s_memrealtime x 100 MHz)\n",
                                0.1 * (double)last.clk[0].v / (double)last.clk[1].v);
   }
+#endif
   return IMP_OK;
 }
 

@@ -166,12 +166,15 @@ int imp_plan_set_overlap(imp_plan* plan, int lanes);
  * FIRs change: HRIR.equalize_channels gets new FIRs for every measurement (core/pipeline.py:690-691). */
 int imp_plan_set_filters(imp_plan* plan, const double* filter, int64_t filter_ld);
 
-/* XCD-resident execution (one persistent launch per call instead of three launches per group): available when one
+/* EXPERIMENT, compiled only with -DIMP_XCD_RESIDENT (python build.py --variant xcd IMP_XCD_RESIDENT; measured 163 k against
+ * 390 k IR/s): in the default build *available is 0 and enabling it fails with IMP_ERR_UNSUPPORTED.
+ * XCD-resident execution (one persistent launch per call instead of three launches per group): available when one
  * channel's workspace (nfft * 4 bytes) fits an XCD's 4 MiB L2 beside the tables, i.e. nfft <= 589 824 (the 7.1 x
  * 6.15 s configuration), on a device that exposes all 8 XCDs.  Channel c is processed on XCD c mod 8 and its
  * workspace never leaves that XCD's L2.  on = 1 enables it for imp_conv_execute_device(_pcm) (launches go to the
  * context stream in order; imp_plan_set_overlap does not apply to them); on = 0 restores the three-launch path.
- * *available (may be NULL) says whether the plan qualifies; enabling an unqualified plan is an error. */
+ * *available (may be NULL) says whether the plan qualifies; enabling an unqualified plan is an error; on = 0 WITH
+ * `available` given is a pure query and leaves the setting alone. */
 int imp_plan_set_resident(imp_plan* plan, int on, int* available);
 /* Synchronises and reports the resident launches since the last call: *aborted != 0 if a bounded in-kernel wait
  * expired (the outputs of that call are invalid; imp_ctx_synchronize returns an error too), *xcc_seen = OR of

