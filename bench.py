@@ -45,6 +45,7 @@ PITCH_ALIGN = int(os.environ.get("IMPULSE_BENCH_PITCH_ALIGN", "64"))     # sampl
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BROADCAST_VIA = None           # set when the in-library RCCL broadcast had to be replaced
 RCCL_RANKS_SEEN = None         # ranks the library's own communicator counted (ncclCommCount), set by spectrum_broadcast
+RCCL_COMM = None               # the rank's communicator (impulse_hip._native.Comm), made at the first broadcast
 METRIC = "impulse responses/sec (sweep deconv+FIR), 7.1×2-ear @48kHz, 1/2/4/8 GPU"
 
 WORKLOADS = {
@@ -646,8 +647,8 @@ def spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world):
     """The path's one collective.  With the RCCL backend the LIBRARY does it (imp_comm_* over librccl; the 128-byte
     communicator id is handed round by the launcher's process group) - torch.distributed only provides the launcher's barriers
     and clock reductions; the gloo rehearsal stages the bytes through host memory instead."""
-    global BROADCAST_VIA, RCCL_RANKS_SEEN
-    from impulse_hip.sharding import broadcast_plan_spectrum, broadcast_plan_spectrum_rccl
+    global BROADCAST_VIA, RCCL_RANKS_SEEN, RCCL_COMM
+    from impulse_hip.sharding import broadcast_plan_spectrum
     if backend != "nccl" or os.environ.get("IMPULSE_BENCH_BCAST", "lib") != "lib":
         return broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0, via_host=(backend != "nccl"))
     from impulse_hip._native import comm_probe, comm_unique_id
@@ -660,15 +661,21 @@ def spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world):
         sys.stderr.write(f"[bench] rank {rank}: librccl not loadable by the library on some rank; using torch.distributed\n")
         BROADCAST_VIA = "torch.distributed (librccl could not be opened by the library on every rank: see stderr)"
         return broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0, via_host=False)
-    # the communicator id is 128 bytes of control plane: rank 0 makes it, the launcher's process group hands it round
-    box = [comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    n = broadcast_plan_spectrum_rccl(plan, ctx, rank, world, unique_id=box[0])
-    seen = torch.tensor([getattr(broadcast_plan_spectrum_rccl, "last_nranks", 0)], dtype=torch.int32, device=device)
-    dist.all_reduce(seen, op=dist.ReduceOp.MIN)
-    RCCL_RANKS_SEEN = int(seen.item())
+    # the communicator id is 128 bytes of control plane: rank 0 makes it, the launcher's process group hands it round.
+    # ONE communicator per rank serves every broadcast of the run (the K1 plan, the chain's plan, the strong block's).
+    if RCCL_COMM is None:
+        from impulse_hip._native import Comm
+        box = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        RCCL_COMM = Comm(ctx, box[0], rank, world)
+        seen = torch.tensor([RCCL_COMM.nranks_seen()], dtype=torch.int32, device=device)
+        dist.all_reduce(seen, op=dist.ReduceOp.MIN)
+        RCCL_RANKS_SEEN = int(seen.item())
+    dptr, nbytes = plan.spectrum_buffer()
+    ctx.synchronize()
+    RCCL_COMM.broadcast(dptr, nbytes, root=0)
     dist.barrier()
-    return n
+    return nbytes
 
 
 def strong_block(args, torch, dist, comm_device, device, ctx, rank, world, backend):
@@ -1114,6 +1121,8 @@ def main(argv=None):
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    if RCCL_COMM is not None:
+        RCCL_COMM.close()
     for c in reversed(contexts):
         c.close()
     if dist is not None:

@@ -1860,6 +1860,10 @@ struct imp_segset {
   std::vector<int64_t> h_len;
   void* qbuf = nullptr;              // query staging: 3 x int64 + 1 x double per query
   size_t qcap = 0;
+  // imp_segset_create_device without maxabs_out does not drain the stream: its staging lives as long as the set
+  void* keep_a = nullptr;
+  void* keep_b = nullptr;
+  std::vector<int64_t> keep_host;
 };
 
 extern "C" void imp_segset_destroy(imp_segset* s) {
@@ -1870,6 +1874,8 @@ extern "C" void imp_segset_destroy(imp_segset* s) {
   (void)ctx_block_put(s->ctx, s->e);
   (void)ctx_block_put(s->ctx, s->off);
   (void)ctx_block_put(s->ctx, s->qbuf);
+  (void)ctx_block_put(s->ctx, s->keep_a);
+  (void)ctx_block_put(s->ctx, s->keep_b);
   delete s;
 }
 
@@ -1979,9 +1985,13 @@ extern "C" int imp_segset_create_device(imp_ctx* ctx, const float* d_x, const in
       for (int64_t b = 0; b < B; ++b) maxabs_out[b] = 0.0;
     return IMP_OK;
   }
-  if (hipMemcpyAsync(s->off, packed.data(), (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(s->len, len, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(d_src_off, off, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+  // the three small tables travel as ONE block (host copy kept by the set: without maxabs_out nothing below waits)
+  s->keep_host.resize((size_t)(3 * B));
+  std::copy(packed.begin(), packed.begin() + B, s->keep_host.begin());
+  std::copy(len, len + B, s->keep_host.begin() + B);
+  std::copy(off, off + B, s->keep_host.begin() + 2 * B);
+  if (hipMemcpyAsync(s->off, s->keep_host.data(), (size_t)(2 * B) * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(d_src_off, s->keep_host.data() + 2 * B, (size_t)B * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemsetAsync(d_max, 0, (size_t)B * sizeof(unsigned long long), st) != hipSuccess)
     return bail(fail(IMP_ERR_HIP, "imp_segset_create_device: upload failed"));
   const int bpr = (int)std::max<int64_t>(1, std::min<int64_t>(256, (maxlen + 4095) / 4096));
@@ -1990,14 +2000,20 @@ extern "C" int imp_segset_create_device(imp_ctx* ctx, const float* d_x, const in
   hipLaunchKernelGGL(imp::seg_maxabs_kernel, grid, block, 0, st, s->e, s->off, s->len, d_max);
   hipLaunchKernelGGL(imp::seg_square_kernel, grid, block, 0, st, s->e, s->off, s->len, d_max);
   if (hipGetLastError() != hipSuccess) return bail(fail(IMP_ERR_HIP, "imp_segset_create_device: launch failed"));
+  if (!maxabs_out) {
+    // stream-ordered: the first imp_segset_range_means call waits for all of it; the staging goes with the set
+    s->keep_a = d_max;
+    s->keep_b = d_src_off;
+    *out = s;
+    return IMP_OK;
+  }
   std::vector<unsigned long long> h((size_t)B);
   if (hipMemcpyAsync(h.data(), d_max, (size_t)B * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)
     return bail(fail(IMP_ERR_HIP, "imp_segset_create_device: readback failed"));
   (void)ctx_block_put(ctx, d_max);
   (void)ctx_block_put(ctx, d_src_off);
-  if (maxabs_out)
-    for (int64_t b = 0; b < B; ++b) std::memcpy(&maxabs_out[b], &h[(size_t)b], sizeof(double));
+  for (int64_t b = 0; b < B; ++b) std::memcpy(&maxabs_out[b], &h[(size_t)b], sizeof(double));
   *out = s;
   return IMP_OK;
 }

@@ -477,8 +477,9 @@ class SegSet:
         ctx._plans.add(self)
 
     @classmethod
-    def from_device(cls, ctx, dptr, offs, lens):
-        """Segments cut from fp32 device rows (dptr + offs[b], lens[b] samples), converted on the device."""
+    def from_device(cls, ctx, dptr, offs, lens, want_max=True):
+        """Segments cut from fp32 device rows (dptr + offs[b], lens[b] samples), converted on the device.  want_max=False:
+        the row maxima stay on the device and the call returns without waiting for it."""
         self = cls.__new__(cls)
         self.ctx = ctx
         self._lib = ctx._lib
@@ -488,7 +489,9 @@ class SegSet:
         self.maxabs = np.zeros(max(B, 1), dtype=np.float64)[:B]
         h = _vp()
         _check(self._lib.imp_segset_create_device(ctx.handle, _vp(int(dptr)), _ptr_i64(offs), _ptr_i64(self.lens), B,
-                                                  C.byref(h), self.maxabs.ctypes.data_as(_pd)))
+                                                  C.byref(h), self.maxabs.ctypes.data_as(_pd) if want_max else None))
+        if not want_max:
+            self.maxabs = None
         self._h = h
         ctx._plans.add(self)
         return self

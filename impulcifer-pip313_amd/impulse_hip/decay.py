@@ -251,7 +251,8 @@ def decay_params_rows(rows, fs):
     peaks, _ = ctx.peak_index_device(base, offs, lens)
 
     def segset_for(idx, starts, seg_lens):
-        return _native.SegSet.from_device(ctx, base, [offs[k] + a for k, a in zip(idx, starts)], seg_lens)
+        # (the row maxima stay on the device: the set is ready in stream order, no round trip of its own)
+        return _native.SegSet.from_device(ctx, base, [offs[k] + a for k, a in zip(idx, starts)], seg_lens, want_max=False)
 
     return _knee_searches(ctx, lengths, peaks, segset_for, fs)
 

@@ -352,7 +352,8 @@ int imp_apply_window(imp_ctx* ctx, float* x, const int64_t* off, const int64_t* 
  * (len[b] samples; the two may be the same memory for an in-place window) */
 int imp_apply_window_device(imp_ctx* ctx, const float* d_src, const int64_t* src_off, float* d_dst,
                             const int64_t* dst_off, const int64_t* len, int64_t B, const imp_window_params* params);
-/* imp_segset_create on fp32 device rows (converted exactly to fp64 on the device) */
+/* imp_segset_create on fp32 device rows (converted exactly to fp64 on the device).  With maxabs_out = NULL the call does
+ * not wait for the device (the first imp_segset_range_means does): one round trip less per knee search. */
 int imp_segset_create_device(imp_ctx* ctx, const float* d_x, const int64_t* off, const int64_t* len, int64_t B,
                              imp_segset** out, double* maxabs_out);
 /* HRIR.write_wav (core/hrir.py:426-455 -> core/audio_io.py:82-97) for responses on the device: the interleaved PCM
