@@ -61,8 +61,8 @@ WORKLOADS = {
 GROUP_CHANNELS = {"c2": 32, "c3": 13, "c4": 8, "c5": 8}
 MEASUREMENTS_PER_BLOCK = {"c2": 2, "c3": 1}
 DEFAULT_BLOCKS = {"c2": 272, "c3": 96, "c4": 12, "c5": 12}
-# calls (chains / K1 launch groups) in flight = streams.  C3's 26-channel calls carry 2.4x the workspace of C2's 32: two of
-# them fill the Infinity Cache (26 ch x 2: 204 k IR/s K1, 26 x 3: 160 k)
+# calls (chains / K1 launch groups) in flight = streams, measured per workload (IMPULSE_BENCH_GROUP / --lanes; C3: 2 streams
+# x 13-channel groups 194 k IR/s K1 and 154 k chain, 3 x 13: 197 k / 135 k, 3 x 26: 160 k / 135 k)
 CHAINS = {"c2": 3, "c3": 2, "c4": 3, "c5": 3}
 
 
@@ -856,7 +856,7 @@ def main(argv=None):
     contexts = [Context(dev_index) for _ in range(lanes)]
     ctx = contexts[0]
     ring = InputRing(ctx, rec, n_blocks)
-    group_channels = B if not strong else GROUP_CHANNELS[args.workload]
+    group_channels = int(os.environ.get("IMPULSE_BENCH_GROUP", "0")) or (B if args.workload == "c2" else GROUP_CHANNELS[args.workload])
     bcast_bytes = [0]
 
     def k1_plan(c, ws_channels, paired=False):
