@@ -23,7 +23,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SPEC_TOL = 1e-6            # max |dA| / max |A| on |rfft(cropped ir)|  (and on whole noise-like outputs)
-FULL_COLUMN_TOL = 3e-6     # same metric on an un-cropped sweep-recording column (fp32 FFT floor)
+# The same metric on an UN-CROPPED sweep-recording column at 48 kHz (1.0 s and 6.15 s sweeps: the only sizes it is asserted
+# on).  Measured floor of every fp32 transform there (profiles/r03_column_error.txt): this path 1.2-2.3e-6
+# depending on the plan's row count, pocketfft in single precision 2.5e-6 on the same input.  A maximum over 2-4 x 10^5 bins
+# of white rounding noise (time-domain rms 3-5e-10 of the peak), it moves by up to 2x between channels of one plan.  Nothing
+# the reference computes sees it: magnitude_response only ever runs on cropped responses (SPEC_TOL).  C3 / C5 whole-column
+# figures are reported by bench.py, not asserted (the C3 excess is located in DESIGN.md section 5).
+FULL_COLUMN_TOL = 3e-6
 TIME_TOL = 1e-6            # max |dy| / max |y|
 
 
