@@ -604,9 +604,10 @@ struct MixCfg {
   static constexpr int T = TC * R2;
   static constexpr int G = (F + R2 - 1) / R2;
   static constexpr size_t lds_bytes = sizeof(cf) * F * T;
-  // the 12-wave workgroups of 11 x 12 (pair mode's 132 rows) fit a CU twice only below 81 VGPRs: ask for 6 waves per SIMD
-  // (HIP's second launch-bounds figure is waves per execution unit)
-  static constexpr int min_waves = (T >= 704 && lds_bytes <= 80 * 1024) ? 6 : 1;
+  // the 12-wave workgroups of 11 x 12 (pair mode's 132 rows) fit a CU twice only below 81 VGPRs, the 9-wave ones of
+  // 16 x 18 (288 rows) below 97: ask for the waves per SIMD that two workgroups need (HIP's second launch-bounds figure is
+  // waves per execution unit)
+  static constexpr int min_waves = (T >= 512 && lds_bytes <= 80 * 1024) ? (2 * (T / 64) + 3) / 4 : 1;
 };
 
 template <int F, int R2, int DIR, class Load, class Store>

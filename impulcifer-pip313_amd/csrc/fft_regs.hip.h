@@ -276,10 +276,25 @@ __host__ __device__ __forceinline__ void bfly5(cf& a, cf& b, cf& c, cf& d, cf& e
 }
 
 
-// R-point DFT of x[0..R-1] in place, natural order in and out, R in {3, 5, 6, 9, 10, 11, 12}.
+// R-point DFT of x[0..R-1] in place, natural order in and out, R in {3, 5, 6, 9, 10, 11, 12, 18}.
 template <int DIR, int R>
 __host__ __device__ __forceinline__ void fft_small(cf* x) {
-  if constexpr (R == 3) {
+  if constexpr (R == 18) {
+    // N1 = 2, N2 = 9 (prime-factor mapping, no twiddles between the factors): n = (9 n1 + 2 n2) mod 18 ; k = (9 k1 + 10 k2) mod 18
+    cf a[2][9];
+#pragma unroll
+    for (int n1 = 0; n1 < 2; ++n1)
+#pragma unroll
+      for (int n2 = 0; n2 < 9; ++n2) a[n1][n2] = x[(9 * n1 + 2 * n2) % 18];
+    fft_small<DIR, 9>(a[0]);
+    fft_small<DIR, 9>(a[1]);
+#pragma unroll
+    for (int k2 = 0; k2 < 9; ++k2) bfly2<DIR>(a[0][k2], a[1][k2]);
+#pragma unroll
+    for (int k1 = 0; k1 < 2; ++k1)
+#pragma unroll
+      for (int k2 = 0; k2 < 9; ++k2) x[(9 * k1 + 10 * k2) % 18] = a[k1][k2];
+  } else if constexpr (R == 3) {
     bfly3<DIR>(x[0], x[1], x[2]);
   } else if constexpr (R == 11) {
     fft11<DIR>(x);

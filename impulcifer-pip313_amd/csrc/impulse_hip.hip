@@ -579,6 +579,7 @@ static int launch_cols_any(imp_plan* p, int64_t nchan, Load ld, Store st) {
     case 9: return launch_cols_mixed<16, 9, DIR>(p, nchan, ld, st);
     case 10: return launch_cols_mixed<16, 10, DIR>(p, nchan, ld, st);
     case 12: return launch_cols_mixed<16, 12, DIR>(p, nchan, ld, st);
+    case 18: return launch_cols_mixed<16, 18, DIR>(p, nchan, ld, st);
   }
   return fail(IMP_ERR_UNSUPPORTED, "unsupported column radix %d", p->R2);
 }
@@ -646,7 +647,7 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   static const struct { int f, r2; bool pair_only; } kShapes[] = {
       {4, 1, false},  {8, 1, false},  {16, 1, false}, {8, 3, false},  {16, 2, false},  {8, 5, false},
       {16, 3, false}, {16, 4, false}, {11, 6, false}, {8, 9, false},  {16, 5, false},  {16, 6, false},
-      {16, 8, false}, {11, 12, true}, {16, 9, false}, {16, 10, false}, {16, 12, false}, {16, 16, false}};
+      {16, 8, false}, {11, 12, true}, {16, 9, false}, {16, 10, false}, {16, 12, false}, {16, 16, false}, {16, 18, true}};
   const int64_t samples_per_row = paired ? imp::kN2 : 2 * imp::kN2;
   if (paired && n_filters != 1) return fail(IMP_ERR_INVALID, "pair mode needs ONE filter shared by both channels of a pair");
   // Short filters (every FIR of the path: 9 600 taps at 48 kHz, 19 200 at 96 kHz): one launch of overlap-save blocks that stay
@@ -694,7 +695,7 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   p->ola = false;
   p->paired = paired;
   if (!r2 && paired)
-    return fail(IMP_ERR_UNSUPPORTED, "pair mode covers circular lengths up to 2^20 samples (256 rows); this plan needs %lld",
+    return fail(IMP_ERR_UNSUPPORTED, "pair mode covers circular lengths up to 1 179 648 samples (288 rows); this plan needs %lld",
                 (long long)need_eff);
   if (!r2) {
     // Longer than one two-level transform (2^21 points): overlap-add.  The input is cut into blocks and, when
@@ -1742,7 +1743,8 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
   if (n > deconv->out_len || head < 0 || fade_in < 0 || fade_out < 0 || fade_in > n || fade_out > n)
     return fail(IMP_ERR_INVALID, "imp_chain_create: crop of %lld samples with fades %lld / %lld does not fit", (long long)n,
                 (long long)fade_in, (long long)fade_out);
-  if (deconv->N1 > imp::kMaxPlanRows) return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: deconvolution plan of %d rows", deconv->N1);
+  if ((deconv->paired ? deconv->N1 / 2 : deconv->N1) > imp::kMaxPlanRows)
+    return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: deconvolution plan of %d rows", deconv->N1);
   int rc = ctx_bind(deconv->ctx);
   if (rc) return rc;
   imp_chain* c = new (std::nothrow) imp_chain();

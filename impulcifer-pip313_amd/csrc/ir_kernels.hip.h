@@ -324,7 +324,7 @@ struct StoreRealCropMax {
 // The same in pair mode: sample n of BOTH channels sits in point p = n, a four-step row holds 4 096 samples of each channel,
 // and the maxima are kept per channel and per 8 192-sample chunk (two four-step rows): tile_max[channel][tile][n1 / 2].
 __device__ __forceinline__ unsigned* crop_max_lds_r() {
-  __shared__ unsigned rows_r[kMaxPlanRows / 2];
+  __shared__ unsigned rows_r[kMaxPlanRows];
   return rows_r;
 }
 
@@ -344,7 +344,7 @@ struct StorePairCropMax {
   __device__ __forceinline__ __amdgpu_buffer_rsrc_t bind(int p) const { return crop.bind(p); }
   __device__ __forceinline__ void begin(int tid, int threads) const {
     unsigned *rl = crop_max_lds(), *rr = crop_max_lds_r();
-    for (int r = tid; r < kMaxPlanRows / 2; r += threads) rl[r] = rr[r] = 0u;
+    for (int r = tid; r < kMaxPlanRows; r += threads) rl[r] = rr[r] = 0u;
     __syncthreads();
   }
   __device__ __forceinline__ void put(__amdgpu_buffer_rsrc_t r, int p, unsigned e, unsigned step_elems, cf v) const {

@@ -18,19 +18,22 @@ def test_pair_plan_geometry_needs_no_gpu():
     assert plan_geometry_paired(9600, 32640, "full")[3] == 16             # 42 239 samples -> 11 rows -> the 16-row plan
     assert plan_geometry_paired(5, 17, "same")[3] == 4
     assert plan_geometry_paired(400000, 648576, "full")[3] == 256         # exactly 2^20 samples
-    # C3 (96 kHz) and C5 (2^20 x 2^20) need more than 256 rows: not available, the caller keeps the mono plan
-    assert plan_geometry_paired(635965, 827965, "same") is None
+    # C3 (96 kHz): 1 145 947 samples -> 280 rows -> the 288-row plan (16 x 18), the same circular length as the mono plan's 144
+    assert plan_geometry_paired(635965, 827965, "same") == (288 * 4096, (635965 - 1) // 2, 827965, 288)
+    assert plan_geometry(635965, 827965, "same")[0] == 288 * 4096
+    # C5 (2^20 x 2^20) needs 384 rows: not available, the caller keeps the mono plan
     assert plan_geometry_paired(1 << 20, 1 << 20, "same") is None
 
 
-# every column shape of pair mode: N1 = 4, 4, 8, 16, 24, 32, 40, 48, 64, 66, 72, 80, 96, 128, 132, 144, 160, 192, 256
+# every column shape of pair mode: N1 = 4, 4, 8, 16, 24, 32, 40, 48, 64, 66, 72, 80, 96, 128, 132, 144, 160, 192, 256, 288 (C3)
 @pytest.mark.gpu
 @pytest.mark.parametrize("L,M,mode", [(1, 1, "same"), (17, 5, "full"), (20000, 9600, "full"), (32640, 9600, "full"),
                                       (70001, 61000, "same"), (100000, 30000, "full"), (150000, 20000, "same"),
                                       (150000, 40000, "full"), (243635, 30000, "same"), (243635, 147635, "same"),
                                       (270000, 60000, "same"), (300000, 50000, "same"), (300000, 150000, "same"),
                                       (391270, 200000, "same"), (391270, 295270, "same"), (500000, 150000, "same"),
-                                      (500000, 300000, "same"), (500000, 250000, "full"), (800000, 400000, "same")])
+                                      (500000, 300000, "same"), (500000, 250000, "full"), (800000, 400000, "same"),
+                                      (827965, 635965, "same")])
 def test_pair_conv_matches_oracle(gpu_ctx, L, M, mode):
     from impulse_hip import ConvPlan
     from impulse_hip._native import plan_geometry_paired
@@ -207,11 +210,58 @@ def test_pair_plan_refill_and_errors(gpu_ctx):
     with pytest.raises(ValueError):
         ConvPlan(gpu_ctx, np.stack([h1, h2]), L, "full", paired=True)          # per-channel filters cannot pair
     with pytest.raises(NativeError):
-        ConvPlan(gpu_ctx, rng.standard_normal(635965), 827965, "same", paired=True)   # C3: beyond 256 rows
-    auto = ConvPlan(gpu_ctx, rng.standard_normal(635965), 827965, "same", paired="auto")
+        ConvPlan(gpu_ctx, rng.standard_normal(1 << 20), 1 << 20, "same", paired=True)   # C5: beyond 288 rows
+    auto = ConvPlan(gpu_ctx, rng.standard_normal(1 << 20), 1 << 20, "same", paired="auto")
     assert not auto.paired
     auto.close()
     mono = ConvPlan(gpu_ctx, h1, L, "full")
     with pytest.raises(NativeError):
         mono.execute_device_pairs(0x1000, 0, 1, 2, 1, 2, 0x1000, L + M)
     mono.close()
+
+
+@pytest.mark.gpu
+def test_pair_mode_c3_size_all_loaders(gpu_ctx):
+    """C3's shape (96 kHz: L = 827 965, M = 635 965, 288 rows = 16 x 18) through the three ways a recording reaches pair mode
+    - planar rows, interleaved fp32 frames, the WAV's own PCM_32 frames - on a synthetic sweep recording: analytic peaks, the
+    oracle in time and on the cropped spectrum, and the whole column, which in pair mode has no even/odd packing to couple
+    the bins near Nyquist with the strong ones near DC."""
+    from impulse_hip import ConvPlan
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from oracle.estimator import estimate
+    fs = 96000
+    e = ImpulseResponseEstimator(min_duration=5.0, fs=fs)
+    N = len(e)
+    L = N + 2 * fs
+    assert (N, L) == (635965, 827965)
+    rng = np.random.default_rng(0xC3)
+    x = np.zeros((2, L))
+    delays = (64, 101)
+    for c, d0 in enumerate(delays):
+        x[c, d0:d0 + N] += 0.5 * e.test_signal
+        for _ in range(3):
+            d = int(rng.integers(200, 48000))
+            x[c, d0 + d:d0 + d + N] += 0.15 * np.exp(-d / 19200.0) * rng.standard_normal() * e.test_signal[:min(N, L - d0 - d)]
+    x += rng.standard_normal(x.shape) * 10 ** (-70 / 20)
+    x32 = x.astype(np.float32)
+    inv = np.asarray(e.inverse_filter, dtype=np.float64)
+    plan = ConvPlan(gpu_ctx, inv, L, "same", paired=True)
+    assert plan.paired and plan.n1 == 288
+    y_planar = plan.execute(x32)
+    y_frames = plan.execute_interleaved(np.ascontiguousarray(x32.T))
+    assert np.array_equal(y_planar, y_frames)
+    pcm = np.clip(np.rint(x.T * 2.0 ** 31), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int32)          # [frames, 2]
+    y_pcm = plan.execute_pcm_columns(pcm, [0])[0]
+    plan.close()
+    mono = ConvPlan(gpu_ctx, inv, L, "same")
+    y_mono = mono.execute(x32)
+    mono.close()
+    for c in range(2):
+        ref = estimate(x32[c].astype(np.float64), inv)
+        assert int(np.argmax(np.abs(y_planar[c]))) == int(np.argmax(np.abs(ref))) == N // 2 + delays[c]
+        assert rel(y_planar[c], ref) <= TIME_TOL and spec_rel_cropped(y_planar[c], ref, fs=fs) <= SPEC_TOL
+        ref_pcm = estimate((pcm[:, c].astype(np.float64) / 2.0 ** 31).astype(np.float32).astype(np.float64), inv)
+        assert rel(y_pcm[c], ref_pcm) <= TIME_TOL and spec_rel_cropped(y_pcm[c], ref_pcm, fs=fs) <= SPEC_TOL
+        whole_pair, whole_mono = spec_rel(y_planar[c], ref), spec_rel(y_mono[c], ref)
+        print(f"C3 whole column ch{c}: pair mode {whole_pair:.2e}, mono plan {whole_mono:.2e}")
+        assert whole_pair <= FULL_COLUMN_TOL
