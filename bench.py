@@ -810,11 +810,23 @@ def main(argv=None):
     # IMPULSE_BENCH_FORCE_DIST=1 takes the collective path with a single rank too (a one-GPU box can
     # then exercise RCCL init, the spectrum broadcast and the reductions).  torch is the LAUNCHER's control plane
     # (rendezvous, barriers, clock reductions) and is imported for N > 1 only.
-    if world > 1 or os.environ.get("IMPULSE_BENCH_FORCE_DIST") == "1":
+    use_dist = world > 1 or os.environ.get("IMPULSE_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch
         import torch.distributed as dist
         if backend == "gloo":
             dev_index = local_rank % max(torch.cuda.device_count(), 1)
+
+    from impulse_hip import Context, ConvPlan
+    from impulse_hip.sharding import shard_channels
+
+    lanes = max(1, min(args.lanes or CHAINS[args.workload], 4))
+    # one context (= one stream) per call in flight, made once - BEFORE the launcher's process group brings its own streams -
+    # and used by every leg: K1 alone, pair mode and the chains.  Three streams stay below the four hardware queues a HIP
+    # process gets by default, so no two of them are multiplexed.
+    contexts = [Context(dev_index) for _ in range(lanes)]
+    ctx = contexts[0]
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -827,16 +839,12 @@ def main(argv=None):
         device = torch.device("cuda", dev_index)
         comm_device = device if backend == "nccl" else torch.device("cpu")
 
-    from impulse_hip import Context, ConvPlan
-    from impulse_hip.sharding import shard_channels
-
     fs, dur, B_meas, desc = WORKLOADS[args.workload]
     est = make_estimator(args.workload)
     strong = args.workload in ("c4", "c5")
     stage = "deconv" if strong else args.stage
     inv = np.asarray(est.inverse_filter, dtype=np.float64)
     M = len(est)
-    lanes = max(1, min(args.lanes or CHAINS[args.workload], 4))
     if strong:
         lo, hi = shard_channels(B_meas, world, rank)
         B = GROUP_CHANNELS[args.workload] * min(lanes, 3)     # channels per call: one launch group per lane
@@ -851,10 +859,6 @@ def main(argv=None):
         n_blocks = args.blocks or int(os.environ.get("IMPULSE_BENCH_BLOCKS", "0")) or DEFAULT_BLOCKS[args.workload]
     irs_per_step_rank = n_blocks * B
 
-    # one context (= one stream) per call in flight, made once and used by every leg: K1 alone, pair mode and the chains.
-    # Three streams stay below the four hardware queues a HIP process gets by default, so no two are multiplexed.
-    contexts = [Context(dev_index) for _ in range(lanes)]
-    ctx = contexts[0]
     ring = InputRing(ctx, rec, n_blocks)
     group_channels = int(os.environ.get("IMPULSE_BENCH_GROUP", "0")) or (B if args.workload == "c2" else GROUP_CHANNELS[args.workload])
     bcast_bytes = [0]

@@ -15,8 +15,8 @@
  *   - a context owns one GPU and one stream; calls on one context are stream ordered.  Every entry
  *     point is thread safe: calls that share a context (or plans of one context) serialise on the
  *     context's lock, distinct contexts run concurrently
- *   - arithmetic is IEEE fp32 on the device; filter spectra of deconvolution plans are prepared
- *     in fp64 on the host and rounded once
+ *   - the convolutions (K1, K5) are IEEE fp32 on the device; their filter spectra are prepared in fp64 (on the device)
+ *     and rounded once; curve conditioning, FIR design, magnitude responses, decay reductions and IIR filtering are fp64
  */
 #ifndef IMPULSE_HIP_H_
 #define IMPULSE_HIP_H_
@@ -75,11 +75,13 @@ int imp_memset(imp_ctx* ctx, void* dptr, int value, size_t bytes);
  *   core/impulse_response.py:110-119, 126-135    ImpulseResponse.equalize / convolve (mode 'full')
  *   core/parallel_workers.py:9-21                process_plot_worker (mode 'full')
  *
- * A plan fixes (filter, M, L, mode).  The circular length is nfft = 8192*N1 with
- * N1 in {16,24,32,40,48,64,72,80,96,128,144,160,192,256}: the smallest that covers L+M-1 ('full') or
- * L + M/2 ('same': wrap-around may fall into the part of the linear convolution that the window
- * discards).  Beyond 2^21 points the plan runs overlap-add: input blocks x filter partitions of at most
- * 2^21 points each through the same kernels, accumulated on the device (L, M < 2^29).
+ * A plan fixes (filter, M, L, mode) and is one of three kinds (imp_plan_kind):
+ *   0  three-launch transform: circular length nfft = 8192*N1, N1 in {4,8,16,24,32,40,48,64,66,72,80,96,128,144,160,192,256}:
+ *      the smallest that covers L+M-1 ('full') or L + M/2 ('same': wrap-around may fall into the part of the linear
+ *      convolution that the window discards).  Beyond 2^21 points the plan runs overlap-add: input blocks x filter
+ *      partitions of at most 2^21 points each through the same kernels, accumulated on the device (L, M < 2^29).
+ *   1  pair mode (imp_conv_plan_create_paired): two channels per complex transform, see below.
+ *   2  fused FIR (what imp_conv_plan_create makes for M <= 24 577): overlap-save blocks in ONE launch, see below.
  * ws_channels = channels processed per launch group (0 = choose so that the workspace stays
  * resident in the 256 MiB Infinity Cache).
  */
