@@ -2208,6 +2208,67 @@ def test_fir_chain_without_host_round_trip(gpu_ctx):
             gpu_ctx.free(p)
 
 
+@pytest.mark.parametrize("paired", [False, True])
+def test_fir_chain_with_lanes_tail_stream_and_cu_masks(paired):
+    """The arrangement the library offers beside the one-stream chain (and bench.py measured slower):
+    the deconvolution plan on TWO lanes of a context restricted to CUs 32..255, the FIR plan on a second context restricted
+    to CUs 0..31 whose stream carries the peak search and K5 of every call (events order them; buffer sets rotate so that the
+    next call's K1 runs beside the previous call's tail).  Seven calls in flight with distinct inputs and outputs, every one
+    against the oracle; the deconvolution in mono and in pair mode."""
+    from impulse_hip import Context, ConvPlan
+    from impulse_hip._native import FirChain
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from oracle.estimator import estimate
+    from oracle.impulse_response import peak_index
+    from oracle.scipy_restated import fft_convolve, hann
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+    N, fs = len(e), 48000
+    L, n, K, head, fade, B, calls = N + 2 * fs, 20000, 3000, 48, 400, 4, 7
+    rng = np.random.default_rng(77)
+    firs = rng.standard_normal((B, K)) * np.exp(-np.arange(K) / 200.0)
+    main, tail = Context(0, cus=range(32, 256)), Context(0, cus=range(0, 32))
+    plan1 = ConvPlan(main, np.asarray(e.inverse_filter), L, "same", ws_channels=2 * B, fused=False, paired=paired)
+    plan1.set_overlap(2)
+    plan5 = ConvPlan(tail, firs, n, "full", ws_channels=B)
+    assert plan1.paired == paired and plan5.fused
+    chain = FirChain(plan1, plan5, B, head, head, fade)
+    po = n + K - 1 + 1
+    recs, bufs = [], []
+    for j in range(calls):
+        rec = (rng.standard_normal((B, L)) * 1e-4).astype(np.float32)
+        for c in range(B):
+            d = 50 + 211 * j + 37 * c
+            rec[c, d:d + N] += (0.5 * e.test_signal).astype(np.float32)
+        d_x, d_out, d_pk = main.malloc(rec.nbytes), main.malloc(B * po * 4), main.malloc(B * 8)
+        main.h2d(d_x, rec)
+        recs.append(rec)
+        bufs.append((d_x, d_out, d_pk))
+    w = np.ones(n)
+    w[:head] *= hann(2 * head)[:head]
+    w[n - fade:] *= hann(2 * fade)[fade:]
+    try:
+        for d_x, d_out, d_pk in bufs:                               # all in flight: nothing waits between the calls
+            chain.execute_device(d_x, L, d_out, po, d_pk)
+        main.synchronize()
+        tail.synchronize()
+        for j, (d_x, d_out, d_pk) in enumerate(bufs):
+            y, pk = np.empty((B, po), dtype=np.float32), np.empty(B, dtype=np.int64)
+            main.d2h(y, d_out)
+            main.d2h(pk, d_pk)
+            for c in range(B):
+                ir = estimate(recs[j][c].astype(np.float64), e.inverse_filter)
+                want_pk = peak_index(ir)
+                assert int(pk[c]) == want_pk == N // 2 + 50 + 211 * j + 37 * c
+                s0 = min(max(want_pk - head, 0), L - n)
+                assert rel(y[c, :n + K - 1], fft_convolve(ir[s0:s0 + n] * w, firs[c], "full")) <= TIME_TOL
+    finally:
+        chain.close()
+        plan1.close()
+        plan5.close()
+        tail.close()
+        main.close()
+
+
 @pytest.mark.parametrize("L,M,rows,n,K", [(52000, 20001, 8, 20000, 3000), (100000, 50001, 16, 20000, 3000),
                                           (150000, 60001, 24, 20000, 3000), (1100000, 300001, 160, 20000, 3000),
                                           (1400000, 300001, 192, 20000, 3000), (1800000, 300001, 256, 20000, 3000),
