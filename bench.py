@@ -16,7 +16,7 @@ column L = N + 2 fs = 391 270 samples)
 
 as ONE device chain per call (imp_chain: five launches, nothing crosses the bus, crop offsets taken from the peak search
 on the device).  `value` is that chain; `deconv_only` (K1 alone, last round's headline) is given beside it with the
-roofline of its dominant kernel.  The default step holds 272 blocks of two measurements = 8 704 IRs per GPU (13 GiB of
+roofline of its dominant kernel.  The default step holds 320 blocks of two measurements = 10 240 IRs per GPU (15 GiB of
 inputs in rotation, so no input line survives in the 256 MiB Infinity Cache between two uses, and 20 steps time ~0.5 s).
 Channels shard across ranks with no data-path collective ("weak": one stream of measurements per GPU); the only
 collective is the one-off RCCL broadcast of the prepared inverse-sweep spectrum.
@@ -60,7 +60,7 @@ WORKLOADS = {
 # 256 MiB Infinity Cache with their inputs and outputs.  C2: two measurements = 32 channels; C3: 13
 GROUP_CHANNELS = {"c2": 32, "c3": 13, "c4": 8, "c5": 8}
 MEASUREMENTS_PER_BLOCK = {"c2": 2, "c3": 1}
-DEFAULT_BLOCKS = {"c2": 272, "c3": 96, "c4": 12, "c5": 12}
+DEFAULT_BLOCKS = {"c2": 320, "c3": 96, "c4": 12, "c5": 12}
 # calls (chains / K1 launch groups) in flight = streams, measured per workload (IMPULSE_BENCH_GROUP / --lanes; C3: 2 streams
 # x 13-channel groups 194 k IR/s K1 and 154 k chain, 3 x 13: 197 k / 135 k, 3 x 26: 160 k / 135 k)
 CHAINS = {"c2": 3, "c3": 2, "c4": 3, "c5": 3}
@@ -83,7 +83,7 @@ def parse_args(argv=None):
                     help="bracket the passes of every n-th K1 launch group with HIP events (sampling keeps the event "
                          "records from perturbing the throughput being measured)")
     ap.add_argument("--blocks", type=int, default=0,
-                    help="resident input blocks per step (0: 272 at C2 = 13 GiB; a block = the measurements of one chain call)")
+                    help="resident input blocks per step (0: 320 at C2 = 15 GiB; a block = the measurements of one chain call)")
     ap.add_argument("--stage", default="chain", choices=["chain", "deconv"],
                     help="what `value` times: the deconvolution + FIR chain (the metric) or K1 alone (C4 / C5 always K1)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -855,7 +855,7 @@ def main(argv=None):
         mpb = MEASUREMENTS_PER_BLOCK[args.workload]
         B = B_meas * mpb                                      # a resident block = mpb measurements, rows contiguous
         rec, L, pitch, delays = synth_recordings(est, B, seed0=0xC2 + 1000 * rank)
-        # C2: 272 blocks x 2 measurements x 16 channels = 8 704 IRs per step: 20 steps time ~0.5 s at 340 k IR/s
+        # C2: 320 blocks x 2 measurements x 16 channels = 10 240 IRs per step: 20 steps time 0.55 s at 370 k IR/s
         n_blocks = args.blocks or int(os.environ.get("IMPULSE_BENCH_BLOCKS", "0")) or DEFAULT_BLOCKS[args.workload]
     irs_per_step_rank = n_blocks * B
 

@@ -1469,7 +1469,7 @@ def test_bench_contract_line(gpu_ctx):
     """bench.py prints exactly one JSON line on stdout with the contract's keys, BASELINE.json's metric, a
     roofline block and (at N = 1) a cpu_baseline block; everything else goes to stderr.  `value` times the metric's own
     wording - the deconvolution + FIR chain - and K1 alone is given beside it (`deconv_only`).  A step is one pass over all
-    resident measurements (8 704 IRs), so the contract's 20 steps time about half a second."""
+    resident measurements (10 240 IRs), so the contract's 20 steps time about half a second."""
     import json
     import subprocess
     import sys
@@ -1488,7 +1488,7 @@ def test_bench_contract_line(gpu_ctx):
     assert abs(d["value"] - d["irs_per_step"] * d["steps"] / d["timed_region_s"]) <= 1e-6 * d["value"]
     cfg = d["config"]
     assert cfg["channels_per_gpu_per_measurement"] == 16 and cfg["measurements_per_call"] == 2
-    assert cfg["channels_per_launch_group"] == 32 and d["irs_per_step"] == 16 * cfg["measurements_per_step"] == 8704
+    assert cfg["channels_per_launch_group"] == 32 and d["irs_per_step"] == 16 * cfg["measurements_per_step"] == 10240
     assert "FIR" in cfg["stage"] and cfg["fir_taps"] == 9600 and cfg["crop_samples"] == 32640
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
