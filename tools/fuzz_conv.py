@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Wide seeded fuzz of the convolution plans against the oracle: every column shape, both modes, all input
+"""Wide seeded fuzz of the convolution plans against the oracle: every plan kind (three launches, fused
+overlap-save, pair mode), every column shape, both modes, all input
 layouts (planar with odd pitches, interleaved frames, PCM16/32 columns), per-channel filters, lanes, and a few
 overlap-add sizes.  python tools/fuzz_conv.py [cases] [seed]"""
 import os
@@ -23,6 +24,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     ctx = _native.default_context()
     worst = 0.0
+    kinds = {"pairs": 0, "fused": 0, "three-launch": 0}
     sizes = [(1, 50), (50, 3000), (3000, 60000), (60000, 250000), (250000, 700000), (700000, 1100000)]
     for case in range(cases):
         lo, hi = sizes[int(rng.integers(0, len(sizes)))]
@@ -38,7 +40,10 @@ def main():
         layout = ("planar", "frames", "pcm16", "pcm32", "device")[case % 5]
         filt = h if per_channel else h[0]
         ws = B if layout in ("pcm16", "pcm32", "frames", "device") else int(rng.integers(1, B + 1))
-        plan = _native.ConvPlan(ctx, filt, L, mode, ws_channels=ws)
+        kind = ("default", "three-launch", "pairs")[int(rng.integers(0, 3))]    # default fuses short filters
+        plan = _native.ConvPlan(ctx, filt, L, mode, ws_channels=ws, fused=kind != "three-launch",
+                                paired="auto" if kind == "pairs" and not per_channel else False)
+        kinds[("pairs" if plan.paired else "fused" if plan.fused else "three-launch")] += 1
         if layout == "planar":
             x = rng.standard_normal((B, L)).astype(np.float32)
             y = plan.execute(x)
@@ -80,9 +85,9 @@ def main():
             tol = 1e-6 * (2 if layout == "pcm32" else 1) * (1.5 if (mode == "same" and M > 4 * L) else 1) * (2 if L > 2_000_000 else 1)
             worst = max(worst, e / tol)
             if e > tol:
-                print(f"FAIL case {case}: {layout} L={L} M={M} {mode} B={B} per_channel={per_channel} nfft={nfft} b={b}: {e:.3e} > {tol:.1e}")
+                print(f"FAIL case {case}: {kind} {layout} L={L} M={M} {mode} B={B} per_channel={per_channel} nfft={nfft} b={b}: {e:.3e} > {tol:.1e}")
                 sys.exit(1)
-    print(f"{cases} cases ok; worst error / tolerance = {worst:.2f}")
+    print(f"{cases} cases ok ({kinds}); worst error / tolerance = {worst:.2f}")
 
 
 if __name__ == "__main__":
