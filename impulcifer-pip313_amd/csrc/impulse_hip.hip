@@ -23,6 +23,7 @@
 #include "xcd_kernels.hip.h"
 #endif
 #include "ir_kernels.hip.h"
+#include "decay_kernels.hip.h"      // last: it switches fp contraction off for what follows
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -2058,6 +2059,97 @@ extern "C" int imp_segset_range_means(imp_segset* s, const int64_t* q_seg, const
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(mean_out, d_m, (size_t)Q * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  return IMP_OK;
+}
+
+// K7c: peak search + Lundeby knee search of B device-resident responses without a host round trip in between
+// (decay_kernels.hip.h).  flags_out[b] != 0: the device search left row b to the host search (a decision inside its
+// guard band, or a shape outside the device path's limits); peak_out[b] is valid either way.
+extern "C" int imp_decay_knees_device(imp_ctx* ctx, const float* d_x, const int64_t* off, const int64_t* len, int64_t B,
+                                      double fs, double peak_height, int64_t* peak_out, int64_t* knee_out,
+                                      double* floor_out, int64_t* window_out, int32_t* flags_out) {
+  if (!ctx || (B && (!d_x || !off || !len || !peak_out || !knee_out || !floor_out || !window_out || !flags_out)))
+    return fail(IMP_ERR_INVALID, "imp_decay_knees_device: null argument");
+  IMP_CTX_LOCK(ctx);
+  if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
+  if (!(fs > 0.0) || !(fs < 1e9)) return fail(IMP_ERR_INVALID, "imp_decay_knees_device: fs must be positive (got %g)", fs);
+  if (!(peak_height > 0.0)) return fail(IMP_ERR_INVALID, "peak_height must be positive (got %g)", peak_height);
+  if (B == 0) return IMP_OK;
+  int64_t maxlen = 0;
+  for (int64_t b = 0; b < B; ++b) {
+    if (len[b] < 0 || off[b] < 0) return fail(IMP_ERR_INVALID, "negative offset/length in row %lld", (long long)b);
+    if (len[b] >= ((int64_t)1 << 31)) return fail(IMP_ERR_INVALID, "row %lld is too long (%lld samples)", (long long)b, (long long)len[b]);
+    maxlen = std::max(maxlen, len[b]);
+  }
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  const int64_t two_fs = (int64_t)(2 * fs);               // int(2 * fs), core/decay.py:84
+  const int64_t seg_pitch = std::max<int64_t>(1, std::min(two_fs, maxlen));
+  const int64_t chunks = std::max<int64_t>(1, (maxlen + imp::kPeakChunk - 1) / imp::kPeakChunk);
+  const int mean_pitch = imp::kKneeMaxWindows + 1;
+  // scratch: off, len, seg_src, seg_dst, seg_len [B] | row maxima bits [B] | peak results [B] | search state [B] |
+  // window means [B][mean_pitch] | chunk maxima [B][chunks]
+  const size_t meta = (size_t)B * sizeof(int64_t);
+  size_t bytes = 5 * meta + (size_t)B * sizeof(unsigned long long) + (size_t)B * sizeof(imp::RowPeak) +
+                 (size_t)B * sizeof(imp::KneeRow) + (size_t)B * mean_pitch * sizeof(double) +
+                 (size_t)(B * chunks) * sizeof(unsigned);
+  void* scr = nullptr;
+  if ((rc = ctx_scratch(ctx, bytes, &scr))) return rc;
+  int64_t* d_off = (int64_t*)scr;
+  int64_t* d_len = d_off + B;
+  int64_t* d_seg_src = d_len + B;
+  int64_t* d_seg_dst = d_seg_src + B;
+  int64_t* d_seg_len = d_seg_dst + B;
+  unsigned long long* d_max = (unsigned long long*)(d_seg_len + B);
+  imp::RowPeak* d_res = (imp::RowPeak*)(d_max + B);
+  imp::KneeRow* d_rows = (imp::KneeRow*)(d_res + B);
+  double* d_means = (double*)(d_rows + B);
+  unsigned* d_chunk = (unsigned*)(d_means + (size_t)B * mean_pitch);
+  double* d_e = nullptr;
+  if ((rc = ctx_block_get(ctx, (size_t)(B * seg_pitch) * sizeof(double), (void**)&d_e))) return rc;
+  hipStream_t s = ctx->stream;
+  auto bail = [&](int code) {
+    (void)hipStreamSynchronize(s);
+    (void)ctx_block_put(ctx, d_e);
+    return code;
+  };
+  std::vector<imp::KneeRow> h((size_t)B);
+  if (hipMemcpyAsync(d_off, off, meta, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(d_len, len, meta, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemsetAsync(d_max, 0, (size_t)B * sizeof(unsigned long long), s) != hipSuccess)
+    return bail(fail(IMP_ERR_HIP, "imp_decay_knees_device: upload failed"));
+  hipLaunchKernelGGL(imp::row_chunk_max_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, s, d_x, d_off, d_len,
+                     (int64_t)0, d_chunk, chunks);
+  hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)B), dim3(imp::kPeakThreads), 0, s, d_x, d_off, d_len,
+                     (int64_t)0, (const unsigned*)nullptr, 0, (const unsigned*)d_chunk, chunks, d_res, peak_height,
+                     (long long*)nullptr);
+  hipLaunchKernelGGL(imp::knee_span_kernel, dim3((unsigned)B), dim3(64), 0, s, (const imp::RowPeak*)d_res, d_off, d_len,
+                     (long long)two_fs, fs, (long long)seg_pitch, d_rows, d_seg_src, d_seg_dst, d_seg_len);
+  const int bpr = (int)std::max<int64_t>(1, std::min<int64_t>(256, (seg_pitch + 4095) / 4096));
+  dim3 grid((unsigned)bpr, (unsigned)B), block(256);
+  hipLaunchKernelGGL(imp::seg_from_float_kernel, grid, block, 0, s, d_x, d_seg_src, d_e, d_seg_dst, d_seg_len);
+  hipLaunchKernelGGL(imp::seg_maxabs_kernel, grid, block, 0, s, d_e, d_seg_dst, d_seg_len, d_max);
+  hipLaunchKernelGGL(imp::seg_square_kernel, grid, block, 0, s, d_e, d_seg_dst, d_seg_len, d_max);
+  hipLaunchKernelGGL(imp::knee_windows_kernel, dim3(imp::kKneeRound1, (unsigned)B), block, 0, s, (const imp::KneeRow*)d_rows,
+                     (const double*)d_e, (long long)seg_pitch, d_means, mean_pitch, 1);
+  hipLaunchKernelGGL(imp::knee_stage1_kernel, dim3((unsigned)B), dim3(64), 0, s, d_rows, (const double*)d_means, mean_pitch, fs);
+  hipLaunchKernelGGL(imp::knee_windows_kernel, dim3(64, (unsigned)B), block, 0, s, (const imp::KneeRow*)d_rows,
+                     (const double*)d_e, (long long)seg_pitch, d_means, mean_pitch, 0);
+  hipLaunchKernelGGL(imp::knee_stage2_kernel, dim3((unsigned)B), block, 0, s, d_rows, (const double*)d_means, mean_pitch,
+                     (const double*)d_e, (long long)seg_pitch, fs);
+  if (hipGetLastError() != hipSuccess) return bail(fail(IMP_ERR_HIP, "imp_decay_knees_device: launch failed"));
+  if (hipMemcpyAsync(h.data(), d_rows, (size_t)B * sizeof(imp::KneeRow), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess)
+    return bail(fail(IMP_ERR_HIP, "imp_decay_knees_device: readback failed"));
+  (void)ctx_block_put(ctx, d_e);
+  for (int64_t b = 0; b < B; ++b) {
+    const imp::KneeRow& r = h[(size_t)b];
+    peak_out[b] = r.peak;
+    flags_out[b] = r.done ? r.flags : (r.flags ? r.flags : imp::KNEE_GUARD);
+    knee_out[b] = r.knee;
+    floor_out[b] = r.floor;
+    window_out[b] = r.window;
+  }
   return IMP_OK;
 }
 

@@ -654,19 +654,11 @@ __global__ __launch_bounds__(256) void seg_square_kernel(double* __restrict__ x,
 constexpr int kSumNodes = 256;     // nodes per level of a piece's tree (<= 8192 / 57 leaves)
 constexpr int kSumLevels = 8;      // 8192 -> 128 takes six splits
 
-__global__ __launch_bounds__(256) void seg_range_mean_kernel(const double* __restrict__ e, const int64_t* __restrict__ off,
-                                                             const int64_t* __restrict__ q_seg,
-                                                             const int64_t* __restrict__ q_a,
-                                                             const int64_t* __restrict__ q_b, long long Q,
-                                                             double* __restrict__ mean_out) {
-  const long long q = blockIdx.x;
+// np.mean(a[0:n]) by the 256 threads of a workgroup, every thread gets the value (all of them must call it)
+__device__ inline double block_np_mean(const double* __restrict__ a, long long n) {
   const int tid = threadIdx.x, lane = tid & 63;
-  const long long n = q_b[q] - q_a[q];
-  if (n <= 0) {
-    if (tid == 0) mean_out[q] = __longlong_as_double(0x7ff8000000000000ll);
-    return;
-  }
-  const double* a = e + off[q_seg[q]] + q_a[q];
+  __shared__ double s_mean;
+  if (n <= 0) return __longlong_as_double(0x7ff8000000000000ll);
   __shared__ unsigned short s_off[kSumLevels][kSumNodes], s_len[kSumLevels][kSumNodes], s_child[kSumLevels][kSumNodes];
   __shared__ double s_sum[2][kSumNodes];
   __shared__ int s_levels, s_count[kSumLevels];
@@ -760,7 +752,19 @@ __global__ __launch_bounds__(256) void seg_range_mean_kernel(const double* __res
     }
     if (tid == 0) acc = p0 == 0 ? s_sum[cur][0] : acc + s_sum[cur][0];
   }
-  if (tid == 0) mean_out[q] = acc / (double)n;
+  if (tid == 0) s_mean = acc / (double)n;
+  __syncthreads();
+  return s_mean;               // (the next call's first barrier comes before anything writes s_mean again)
+}
+
+__global__ __launch_bounds__(256) void seg_range_mean_kernel(const double* __restrict__ e, const int64_t* __restrict__ off,
+                                                             const int64_t* __restrict__ q_seg,
+                                                             const int64_t* __restrict__ q_a,
+                                                             const int64_t* __restrict__ q_b, long long Q,
+                                                             double* __restrict__ mean_out) {
+  const long long q = blockIdx.x;
+  const double m = block_np_mean(e + off[q_seg[q]] + q_a[q], q_b[q] - q_a[q]);
+  if (threadIdx.x == 0) mean_out[q] = m;
 }
 
 // ---------------------------------------------------------------------------------------------

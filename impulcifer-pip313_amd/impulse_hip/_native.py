@@ -125,6 +125,8 @@ SIGNATURES = {
     "imp_apply_window": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.POINTER(WindowParams)]),
     "imp_apply_window_device": (C.c_int, [_vp, _vp, _pi64, _vp, _pi64, _pi64, _i64, C.POINTER(WindowParams)]),
     "imp_segset_create_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, C.POINTER(_vp), _pd]),
+    "imp_decay_knees_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, C.c_double, C.c_double, _pi64, _pi64, _pd, _pi64,
+                                         C.POINTER(C.c_int32)]),
     "imp_rows_to_pcm_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, _pi64, _i64, _i64, C.c_int, _vp]),
     "imp_magnitude_db_sum_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _pi64, _i64, _i64, _i64, _pd]),
 }
@@ -312,6 +314,21 @@ class Context:
             _check(self._lib.imp_peak_index_device(self._h, _vp(int(dptr)), _ptr_i64(offs), _ptr_i64(lens), B,
                                                    float(peak_height), _ptr_i64(idx), _ptr_f(mx)))
         return idx, mx
+
+    def decay_knees_device(self, dptr, offs, lens, fs, peak_height=0.12589):
+        """Peak + Lundeby knee search of device rows in one stream-ordered sequence: (peak, knee, floor dB, window,
+        flags); flags[b] != 0 = the device left row b to the host search (include/impulse_hip.h)."""
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int64)
+        B = len(offs)
+        peak, knee, win = (np.zeros(B, dtype=np.int64) for _ in range(3))
+        floor = np.zeros(B, dtype=np.float64)
+        flags = np.zeros(B, dtype=np.int32)
+        if B:
+            _check(self._lib.imp_decay_knees_device(self._h, _vp(int(dptr)), _ptr_i64(offs), _ptr_i64(lens), B, float(fs),
+                                                    float(peak_height), _ptr_i64(peak), _ptr_i64(knee), floor.ctypes.data_as(_pd),
+                                                    _ptr_i64(win), flags.ctypes.data_as(C.POINTER(C.c_int32))))
+        return peak, knee, floor, win, flags
 
     def apply_window_device(self, d_src, src_off, d_dst, dst_off, lens, params):
         src_off = np.ascontiguousarray(src_off, dtype=np.int64)

@@ -257,6 +257,33 @@ def decay_params_rows(rows, fs):
     return _knee_searches(ctx, lengths, peaks, segset_for, fs)
 
 
+def knee_indices_rows(rows, fs, stats=None):
+    """decay_params(...)[1] of device-resident responses, for crop_tails: peak search and the whole Lundeby search run
+    on the device in one sequence of launches (K7c, csrc/decay_kernels.hip.h).  np.log10 and linregress's BLAS dot
+    product cannot be reproduced bit for bit on the device, so each decision of the device search carries a guard band;
+    rows with a decision inside its band (flags != 0) are searched again here by the host flow above - the knees
+    returned are the host search's integers either way.  stats (dict) receives the number of rows the host decided."""
+    from .device_rows import span
+    ctx = _native.default_context()
+    base, offs, lens = span(rows)
+    if not (fs > 0):
+        return [p[1] for p in decay_params_rows(rows, fs)]
+    peaks, knees, _, _, flags = ctx.decay_knees_device(base, offs, lens, fs)
+    redo = [k for k in range(len(rows)) if flags[k]]
+    if stats is not None:
+        stats["host_rows"] = stats.get("host_rows", 0) + len(redo)
+        stats["rows"] = stats.get("rows", 0) + len(rows)
+    if redo:
+        def segset_for(idx, starts, seg_lens):
+            return _native.SegSet.from_device(ctx, base, [offs[redo[k]] + a for k, a in zip(idx, starts)], seg_lens,
+                                              want_max=False)
+
+        host = _knee_searches(ctx, [int(lens[k]) for k in redo], [int(peaks[k]) for k in redo], segset_for, fs)
+        for k, res in zip(redo, host):
+            knees[k] = res[1]
+    return [int(v) for v in knees]
+
+
 def decay_params(data, fs):
     """(peak_index, knee_point_index, noise_floor_dB, window_size) by the Lundeby method."""
     return decay_params_batch([data], fs)[0]

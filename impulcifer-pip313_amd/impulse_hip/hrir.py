@@ -466,10 +466,10 @@ class HRIR(_PlotBase):
         from .decay import decay_params_batch
         dev = self._device_rows([ir for _, _, ir in items])
         if dev is not None:
-            from .decay import decay_params_rows
+            from .decay import knee_indices_rows
             from .device_rows import DeviceBlock, Row, span
             ctx = _native.default_context()
-            knees = [p[1] for p in decay_params_rows(dev, self.fs)]
+            knees = knee_indices_rows(dev, self.fs)
             per_octave = len(self.estimator) / self.estimator.fs / self.estimator.n_octaves
             fade = 2 * int(self.fs * per_octave * (1 / 24)) // 2
             keep = int(min(min(r.n for r in dev), next_fast_len(max(knees))))
