@@ -277,7 +277,9 @@ __global__ __launch_bounds__(kT) void curves_fir_gain_kernel(GainArgs a) {
     shift = s_red[0];
   }
   double* out = a.gain + (size_t)blockIdx.x * a.ntaps;
-  for (int j = threadIdx.x; j < a.ntaps; j += kT) {
+  // blockIdx.y: the channel's taps are shared out over gridDim.y workgroups (1 when normalising: the maximum above
+  // is per channel) - a binary search and a pow() per tap, 16 workgroups of 9 600 taps would leave the chip idle
+  for (int j = blockIdx.y * kT + threadIdx.x; j < a.ntaps; j += kT * gridDim.y) {
     double v = j < a.n_flat ? flat : interp_log(a.log10f, y, a.n, a.log10q[j]);
     if (a.normalize) {
       v -= shift;
@@ -609,7 +611,8 @@ static int curves_fir_from(imp_curves* c, const double* d_eq, int64_t B, double 
   a.log10_fmin = g.log10_fmin;
   a.normalize = normalize;
   hipStream_t s = c->ctx->stream;
-  hipLaunchKernelGGL(curves_fir_gain_kernel, dim3((unsigned)B), dim3(kT), (size_t)c->n * sizeof(double), s, a);
+  const unsigned tiles = normalize ? 1u : (unsigned)std::max(1, std::min(64, (g.ntaps + 2 * kT - 1) / (2 * kT)));
+  hipLaunchKernelGGL(curves_fir_gain_kernel, dim3((unsigned)B, tiles), dim3(kT), (size_t)c->n * sizeof(double), s, a);
   HIP_TRY(hipGetLastError());
   if (gain_out) HIP_TRY(hipMemcpyAsync(gain_out, c->d_gain, need * sizeof(double), hipMemcpyDeviceToHost, s));
   if (fir_out) return minphase_fir_from_device_gain(c->ctx, c->d_gain, B, g.ntaps, fs, fir_out);

@@ -119,6 +119,44 @@ static int ctx_scratch(imp_ctx* ctx, size_t bytes, void** out) {
   return IMP_OK;
 }
 
+// Small tables (row offsets, lengths, window parameters) on their way to a kernel: a ring in pinned host memory mirrored by a
+// ring in device memory.  ctx_stage hands out the same offset in both, the caller fills the host side and ctx_stage_push
+// sends it with ONE asynchronous copy in stream order - no pageable staging, no wait, nothing for the next call to
+// overwrite (the ring only wraps after the stream has drained).
+int ctx_stage(imp_ctx* ctx, size_t bytes, void** host, void** dev) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (ctx->stage_cap < bytes) {
+    if (ctx->stage_host) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      (void)hipHostFree(ctx->stage_host);
+      (void)hipFree(ctx->stage_dev);
+      ctx->stage_host = ctx->stage_dev = nullptr;
+      ctx->stage_cap = ctx->stage_pos = 0;
+    }
+    const size_t want = std::max(4 * bytes, (size_t)1 << 20);
+    HIP_TRY(hipHostMalloc((void**)&ctx->stage_host, want, hipHostMallocDefault));
+    if (hipMalloc((void**)&ctx->stage_dev, want) != hipSuccess) {
+      (void)hipHostFree(ctx->stage_host);
+      ctx->stage_host = nullptr;
+      return fail(IMP_ERR_ALLOC, "staging ring: device allocation of %zu bytes failed", want);
+    }
+    ctx->stage_cap = want;
+    ctx->stage_pos = 0;
+  }
+  if (ctx->stage_pos + bytes > ctx->stage_cap) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stage_pos = 0;
+  }
+  *host = ctx->stage_host + ctx->stage_pos;
+  *dev = ctx->stage_dev + ctx->stage_pos;
+  ctx->stage_pos += bytes;
+  return IMP_OK;
+}
+int ctx_stage_push(imp_ctx* ctx, const void* host, void* dev, size_t bytes) {
+  HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return IMP_OK;
+}
+
 extern "C" const char* imp_version(void) { return "impulse_hip 0.1.0 (gfx950)"; }
 extern "C" const char* imp_last_error(void) { return g_last_error.c_str(); }
 
@@ -228,6 +266,8 @@ extern "C" void imp_ctx_destroy(imp_ctx* ctx) {
   if (ctx->tw_t2) (void)hipFree(ctx->tw_t2);
   if (ctx->tw_t4) (void)hipFree(ctx->tw_t4);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
+  if (ctx->stage_dev) (void)hipFree(ctx->stage_dev);
   pool_release(ctx);
   for (auto& kv : ctx->live_blocks) (void)hipFree(kv.first);      // blocks the caller never handed back
   minphase_plans_destroy(ctx);
@@ -1591,15 +1631,17 @@ static int peak_index_impl(imp_ctx* ctx, const float* d_x, const int64_t* off, c
   const size_t meta = (size_t)B * sizeof(int64_t);
   const size_t res_bytes = (size_t)B * sizeof(imp::RowPeak);
   void* scr = nullptr;
-  int rc = ctx_scratch(ctx, 2 * meta + res_bytes + (size_t)(B * chunks) * sizeof(unsigned), &scr);
+  int rc = ctx_scratch(ctx, res_bytes + (size_t)(B * chunks) * sizeof(unsigned), &scr);
   if (rc) return rc;
-  int64_t* d_off = (int64_t*)scr;
-  int64_t* d_len = d_off + B;
-  imp::RowPeak* d_res = (imp::RowPeak*)(d_len + B);
+  imp::RowPeak* d_res = (imp::RowPeak*)scr;
   unsigned* d_chunk = (unsigned*)(d_res + B);
   hipStream_t s = ctx->stream;
-  HIP_TRY(hipMemcpyAsync(d_off, off, meta, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(d_len, len, meta, hipMemcpyHostToDevice, s));
+  int64_t *h_tab = nullptr, *d_off = nullptr;
+  if ((rc = ctx_stage(ctx, 2 * meta, (void**)&h_tab, (void**)&d_off))) return rc;
+  int64_t* d_len = d_off + B;
+  std::memcpy(h_tab, off, meta);
+  std::memcpy(h_tab + B, len, meta);
+  if ((rc = ctx_stage_push(ctx, h_tab, d_off, 2 * meta))) return rc;
   hipLaunchKernelGGL(imp::row_chunk_max_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, s, d_x, d_off, d_len,
                      (int64_t)0, d_chunk, chunks);
   HIP_TRY(hipGetLastError());
@@ -2090,14 +2132,17 @@ extern "C" int imp_decay_knees_device(imp_ctx* ctx, const float* d_x, const int6
   // scratch: off, len, seg_src, seg_dst, seg_len [B] | row maxima bits [B] | peak results [B] | search state [B] |
   // window means [B][mean_pitch] | chunk maxima [B][chunks]
   const size_t meta = (size_t)B * sizeof(int64_t);
-  size_t bytes = 5 * meta + (size_t)B * sizeof(unsigned long long) + (size_t)B * sizeof(imp::RowPeak) +
+  size_t bytes = 3 * meta + (size_t)B * sizeof(unsigned long long) + (size_t)B * sizeof(imp::RowPeak) +
                  (size_t)B * sizeof(imp::KneeRow) + (size_t)B * mean_pitch * sizeof(double) +
                  (size_t)(B * chunks) * sizeof(unsigned);
   void* scr = nullptr;
   if ((rc = ctx_scratch(ctx, bytes, &scr))) return rc;
-  int64_t* d_off = (int64_t*)scr;
+  int64_t *h_tab = nullptr, *d_off = nullptr;
+  if ((rc = ctx_stage(ctx, 2 * meta, (void**)&h_tab, (void**)&d_off))) return rc;
   int64_t* d_len = d_off + B;
-  int64_t* d_seg_src = d_len + B;
+  std::memcpy(h_tab, off, meta);
+  std::memcpy(h_tab + B, len, meta);
+  int64_t* d_seg_src = (int64_t*)scr;
   int64_t* d_seg_dst = d_seg_src + B;
   int64_t* d_seg_len = d_seg_dst + B;
   unsigned long long* d_max = (unsigned long long*)(d_seg_len + B);
@@ -2114,8 +2159,7 @@ extern "C" int imp_decay_knees_device(imp_ctx* ctx, const float* d_x, const int6
     return code;
   };
   std::vector<imp::KneeRow> h((size_t)B);
-  if (hipMemcpyAsync(d_off, off, meta, hipMemcpyHostToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(d_len, len, meta, hipMemcpyHostToDevice, s) != hipSuccess ||
+  if (ctx_stage_push(ctx, h_tab, d_off, 2 * meta) ||
       hipMemsetAsync(d_max, 0, (size_t)B * sizeof(unsigned long long), s) != hipSuccess)
     return bail(fail(IMP_ERR_HIP, "imp_decay_knees_device: upload failed"));
   hipLaunchKernelGGL(imp::row_chunk_max_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, s, d_x, d_off, d_len,
@@ -2361,22 +2405,22 @@ extern "C" int imp_apply_window_device(imp_ctx* ctx, const float* d_src, const i
   if (rc) return rc;
   hipStream_t s = ctx->stream;
   const size_t meta = (size_t)B * sizeof(int64_t);
-  void* scr = nullptr;
-  if ((rc = ctx_scratch(ctx, 3 * meta + (size_t)B * sizeof(imp_window_params), &scr))) return rc;
-  int64_t* d_so = (int64_t*)scr;
+  // the tables travel through the staging ring: one copy, and the call returns without waiting for the device
+  const size_t tab_bytes = 3 * meta + (size_t)B * sizeof(imp_window_params);
+  int64_t *h_tab = nullptr, *d_so = nullptr;
+  if ((rc = ctx_stage(ctx, tab_bytes, (void**)&h_tab, (void**)&d_so))) return rc;
   int64_t* d_do = d_so + B;
   int64_t* d_len = d_do + B;
   imp_window_params* d_par = (imp_window_params*)(d_len + B);
-  HIP_TRY(hipMemcpyAsync(d_so, src_off, meta, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(d_do, dst_off, meta, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(d_len, len, meta, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(d_par, params, (size_t)B * sizeof(imp_window_params), hipMemcpyHostToDevice, s));
+  std::memcpy(h_tab, src_off, meta);
+  std::memcpy(h_tab + B, dst_off, meta);
+  std::memcpy(h_tab + 2 * B, len, meta);
+  std::memcpy(h_tab + 3 * B, params, (size_t)B * sizeof(imp_window_params));
+  if ((rc = ctx_stage_push(ctx, h_tab, d_so, tab_bytes))) return rc;
   const int bpr = (int)std::max<int64_t>(1, std::min<int64_t>(256, (maxlen + 1023) / 1024));
   hipLaunchKernelGGL(imp::apply_window_copy_kernel, dim3((unsigned)bpr, (unsigned)B), dim3(256), 0, s, d_src, d_so, d_dst, d_do,
                      d_len, reinterpret_cast<const imp::WindowParams*>(d_par));
   HIP_TRY(hipGetLastError());
-  // the scratch block is reused by the next call on this context: the kernel must have read it by then
-  HIP_TRY(hipStreamSynchronize(s));
   return IMP_OK;
 }
 

@@ -46,6 +46,10 @@ struct imp_ctx {
   // scratch for the small ragged kernels
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // staging ring for small host tables: pinned host memory mirrored in device memory (impulse_hip.hip ctx_stage)
+  char* stage_host = nullptr;
+  char* stage_dev = nullptr;
+  size_t stage_cap = 0, stage_pos = 0;
   // extra streams for overlapped launch groups (imp_plan_set_overlap); lane 0 is `stream`
   std::vector<hipStream_t> side_streams;
   // K6 plans keyed by (taps n, fs)
@@ -71,6 +75,11 @@ struct imp_ctx {
 // nothing in flight uses any more (false: not a block of this context's pool)
 int ctx_block_get(imp_ctx* ctx, size_t bytes, void** dptr);
 bool ctx_block_put(imp_ctx* ctx, void* dptr);
+
+// staging ring (impulse_hip.hip): `bytes` at the same offset of a pinned host ring and its device mirror; fill the host
+// side, then ctx_stage_push sends it in stream order.  Valid until the ring wraps (which waits for the stream).
+int ctx_stage(imp_ctx* ctx, size_t bytes, void** host, void** dev);
+int ctx_stage_push(imp_ctx* ctx, const void* host, void* dev, size_t bytes);
 
 // opt a kernel into `bytes` of dynamic LDS on the context's device, once per context
 int ctx_kernel_lds(imp_ctx* ctx, const void* kernel, size_t bytes);

@@ -20,6 +20,7 @@
 // buffers, and a few elementwise kernels.  HBM-bound streaming passes; no LDS, no MFMA.
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <new>
 #include <utility>
 
@@ -141,7 +142,11 @@ __global__ __launch_bounds__(256) void magnitude_and_min(cdbl* __restrict__ h, u
 #pragma unroll
   for (int sft = 32; sft > 0; sft >>= 1) m = fmin(m, __shfl_xor(m, sft, 64));
   // positive doubles order like their bit patterns
-  if ((threadIdx.x & 63) == 0 && m != INFINITY) atomicMin(&minbits[blockIdx.y], (unsigned long long)__double_as_longlong(m));
+  // (4 800 waves on 16 addresses: the plain read first lets all but the few that lower the minimum skip the atomic; a
+  // stale read only means an atomic that changes nothing)
+  if ((threadIdx.x & 63) == 0 && m != INFINITY &&
+      (unsigned long long)__double_as_longlong(m) < __atomic_load_n(&minbits[blockIdx.y], __ATOMIC_RELAXED))
+    atomicMin(&minbits[blockIdx.y], (unsigned long long)__double_as_longlong(m));
 }
 
 // x = 0.5 * log(mag + 1e-7 * min)
@@ -568,20 +573,17 @@ static int magnitude_db_core(imp_ctx* ctx, const double* x, const float* d_rows,
   if (x) {
     HIP_TRY(hipMemcpyAsync(p->x, x, (size_t)B * n * sizeof(double), hipMemcpyHostToDevice, s));
   } else {
-    int64_t* d_meta = nullptr;
+    // row tables through the staging ring: one copy in stream order, no wait before the transform
     const size_t meta = (size_t)n_rows * sizeof(int64_t);
-    if (ctx_block_get(ctx, 3 * meta, (void**)&d_meta)) return IMP_ERR_ALLOC;
-    hipError_t e1 = hipMemcpyAsync(d_meta, off, meta, hipMemcpyHostToDevice, s);
-    hipError_t e2 = hipMemcpyAsync(d_meta + n_rows, len, meta, hipMemcpyHostToDevice, s);
-    hipError_t e3 = hipMemcpyAsync(d_meta + 2 * n_rows, group, meta, hipMemcpyHostToDevice, s);
-    if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess)
-      hipLaunchKernelGGL(rows_group_sum_kernel, dim3((unsigned)std::min<int64_t>(256, (n + 255) / 256), (unsigned)B),
-                         dim3(256), 0, s, d_rows, d_meta, d_meta + n_rows, d_meta + 2 * n_rows, (int)n_rows, p->x, n);
-    hipError_t e4 = hipGetLastError();
-    (void)hipStreamSynchronize(s);
-    (void)ctx_block_put(ctx, d_meta);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess)
-      return fail(IMP_ERR_HIP, "imp_magnitude_db_sum_device: row sum failed");
+    int64_t *h_meta = nullptr, *d_meta = nullptr;
+    if ((rc = ctx_stage(ctx, 3 * meta, (void**)&h_meta, (void**)&d_meta))) return rc;
+    std::memcpy(h_meta, off, meta);
+    std::memcpy(h_meta + n_rows, len, meta);
+    std::memcpy(h_meta + 2 * n_rows, group, meta);
+    if ((rc = ctx_stage_push(ctx, h_meta, d_meta, 3 * meta))) return rc;
+    hipLaunchKernelGGL(rows_group_sum_kernel, dim3((unsigned)std::min<int64_t>(256, (n + 255) / 256), (unsigned)B),
+                       dim3(256), 0, s, d_rows, d_meta, d_meta + n_rows, d_meta + 2 * n_rows, (int)n_rows, p->x, n);
+    if (hipGetLastError() != hipSuccess) return fail(IMP_ERR_HIP, "imp_magnitude_db_sum_device: row sum failed");
   }
   auto grid_for = [&](int count) { return dim3((unsigned)((count + 255) / 256), (unsigned)B); };
   cdbl *cur = p->a, *oth = p->b;

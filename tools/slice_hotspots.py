@@ -24,6 +24,19 @@ for i in range(8):
         tracks[ear, 2 * fs + i * L: 2 * fs + (i + 1) * L] = rec[2 * i + ear, :L]
 frames = np.ascontiguousarray(np.clip(np.rint(tracks.T * 2.0 ** 31), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int32))
 warnings.simplefilter("ignore")
+if stage == "all":                                            # the whole slice, as bench.py's `slice` times it
+    from impulse_hip.pipeline_slice import run_slice
+    for _ in range(3):
+        run_slice(est, [((fs, frames), speakers)])[0].to_host()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(20):
+        run_slice(est, [((fs, frames), speakers)])[0].to_host()
+    pr.disable()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(45)
+    st.sort_stats("cumulative").print_stats(40)
+    sys.exit(0)
 hs = []
 for _ in range(12):
     h = HRIR(est)
