@@ -218,6 +218,30 @@ __global__ __launch_bounds__(256) void bluestein_post_db(const cdbl* __restrict_
   out[(long long)blockIdx.y * half + k] = 20.0 * log10(hypot(v.x, v.y) / (double)mfft);
 }
 
+// np.max of each row of out[B][half] (NaN if the row holds one, as np.max): one workgroup per row
+__global__ __launch_bounds__(256) void rows_max_kernel(const double* __restrict__ out, int half, double* __restrict__ peak) {
+  const double* row = out + (long long)blockIdx.x * half;
+  double m = -INFINITY;
+  bool nan = false;
+  for (int k = threadIdx.x; k < half; k += 256) {
+    const double v = row[k];
+    nan = nan || v != v;
+    m = v > m ? v : m;
+  }
+  __shared__ double s_m[256];
+  __shared__ int s_nan;
+  if (threadIdx.x == 0) s_nan = 0;
+  __syncthreads();
+  s_m[threadIdx.x] = m;
+  if (nan) s_nan = 1;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) s_m[threadIdx.x] = s_m[threadIdx.x] > s_m[threadIdx.x + st] ? s_m[threadIdx.x] : s_m[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) peak[blockIdx.x] = s_nan ? __longlong_as_double(0x7ff8000000000000ll) : s_m[0];
+}
+
 std::vector<int> factorise(int n) {
   std::vector<int> f;
   // Every pass is one launch at the launch floor (~6 us at these sizes): radix 8 passes shorten the power-of-two part
@@ -481,10 +505,10 @@ __global__ __launch_bounds__(256) void rows_group_sum_kernel(const float* __rest
 }  // namespace
 
 static int magnitude_db_core(imp_ctx* ctx, const double* x, const float* d_rows, const int64_t* off, const int64_t* len,
-                             const int64_t* group, int64_t n_rows, int64_t B, int64_t n, double* db_out);
+                             const int64_t* group, int64_t n_rows, int64_t B, int64_t n, double* db_out, bool peak_only);
 
 extern "C" int imp_magnitude_db(imp_ctx* ctx, const double* x, int64_t B, int64_t n, double* db_out) {
-  return magnitude_db_core(ctx, x, nullptr, nullptr, nullptr, nullptr, 0, B, n, db_out);
+  return magnitude_db_core(ctx, x, nullptr, nullptr, nullptr, nullptr, 0, B, n, db_out, false);
 }
 
 // Device-resident rows (fp32 at d_rows + off[r], len[r] samples, r < n_rows) are summed per group (group[r] in
@@ -499,11 +523,24 @@ extern "C" int imp_magnitude_db_sum_device(imp_ctx* ctx, const float* d_rows, co
   for (int64_t r = 0; r < n_rows; ++r)
     if (off[r] < 0 || len[r] < 0 || len[r] > n || group[r] < 0 || group[r] >= n_groups)
       return fail(IMP_ERR_INVALID, "imp_magnitude_db_sum_device: row %lld out of range", (long long)r);
-  return magnitude_db_core(ctx, nullptr, d_rows, off, len, group, n_rows, n_groups, n, db_out);
+  return magnitude_db_core(ctx, nullptr, d_rows, off, len, group, n_rows, n_groups, n, db_out, false);
+}
+
+// the maximum of each of those spectra only (HRIR.normalize with peak_target, core/hrir.py:505: np.max of the stacked
+// spectra): peak_db_out[n_groups]; NaN if a spectrum holds one, -inf for an all-zero sum - what np.max returns
+extern "C" int imp_magnitude_db_sum_peak_device(imp_ctx* ctx, const float* d_rows, const int64_t* off, const int64_t* len,
+                                                const int64_t* group, int64_t n_rows, int64_t n_groups, int64_t n,
+                                                double* peak_db_out) {
+  if (!ctx || !d_rows || !off || !len || !group || n_rows < 1 || n_groups < 1)
+    return fail(IMP_ERR_INVALID, "imp_magnitude_db_sum_peak_device: bad argument");
+  for (int64_t r = 0; r < n_rows; ++r)
+    if (off[r] < 0 || len[r] < 0 || len[r] > n || group[r] < 0 || group[r] >= n_groups)
+      return fail(IMP_ERR_INVALID, "imp_magnitude_db_sum_peak_device: row %lld out of range", (long long)r);
+  return magnitude_db_core(ctx, nullptr, d_rows, off, len, group, n_rows, n_groups, n, peak_db_out, true);
 }
 
 static int magnitude_db_core(imp_ctx* ctx, const double* x, const float* d_rows, const int64_t* off, const int64_t* len,
-                             const int64_t* group, int64_t n_rows, int64_t B, int64_t n, double* db_out) {
+                             const int64_t* group, int64_t n_rows, int64_t B, int64_t n, double* db_out, bool peak_only) {
   if (!ctx || (B && n && ((!x && !d_rows) || !db_out))) return fail(IMP_ERR_INVALID, "imp_magnitude_db: null argument");
   IMP_CTX_LOCK(ctx);
   if (B < 0 || n < 0 || n > (1 << 22)) return fail(IMP_ERR_INVALID, "imp_magnitude_db: bad B or n");
@@ -595,7 +632,13 @@ static int magnitude_db_core(imp_ctx* ctx, const double* x, const float* d_rows,
   if ((rc = run_fft(ctx, p->fac, p->roots, p->mfft, B, +1, &cur, &oth))) return rc;
   hipLaunchKernelGGL(bluestein_post_db, grid_for(half), dim3(256), 0, s, cur, p->chirp, p->out, p->mfft, half);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(db_out, p->out, (size_t)B * half * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (peak_only) {                                       // db_out[B]: the maximum of each spectrum (p->x is free again)
+    hipLaunchKernelGGL(rows_max_kernel, dim3((unsigned)B), dim3(256), 0, s, p->out, half, p->x);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(db_out, p->x, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, s));
+  } else {
+    HIP_TRY(hipMemcpyAsync(db_out, p->out, (size_t)B * half * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
   HIP_TRY(hipStreamSynchronize(s));
   return IMP_OK;
 }

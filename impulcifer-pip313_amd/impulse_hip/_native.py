@@ -129,6 +129,7 @@ SIGNATURES = {
                                          C.POINTER(C.c_int32)]),
     "imp_rows_to_pcm_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, _pi64, _i64, _i64, C.c_int, _vp]),
     "imp_magnitude_db_sum_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _pi64, _i64, _i64, _i64, _pd]),
+    "imp_magnitude_db_sum_peak_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _pi64, _i64, _i64, _i64, _pd]),
 }
 
 _lib = None
@@ -360,6 +361,17 @@ class Context:
         _check(self._lib.imp_magnitude_db_sum_device(self._h, _vp(int(dptr)), _ptr_i64(offs), _ptr_i64(lens),
                                                      _ptr_i64(groups), len(offs), int(n_groups), int(n),
                                                      out.ctypes.data_as(_pd)))
+        return out
+
+    def magnitude_db_sum_peak_device(self, dptr, offs, lens, groups, n_groups, n):
+        """np.max of each of magnitude_db_sum_device's spectra, reduced on the device: [n_groups]."""
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int64)
+        groups = np.ascontiguousarray(groups, dtype=np.int64)
+        out = np.empty(int(n_groups), dtype=np.float64)
+        _check(self._lib.imp_magnitude_db_sum_peak_device(self._h, _vp(int(dptr)), _ptr_i64(offs), _ptr_i64(lens),
+                                                          _ptr_i64(groups), len(offs), int(n_groups), int(n),
+                                                          out.ctypes.data_as(_pd)))
         return out
 
     def decay_times(self, rows, peaks, knees, noise_floors, windows, fs):

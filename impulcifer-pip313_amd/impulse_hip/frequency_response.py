@@ -38,14 +38,24 @@ _CURVES = ("raw", "smoothed", "error", "error_smoothed", "equalization", "equali
            "target")
 
 
+_GRIDS = {}
+
+
 def generate_frequencies(f_min=DEFAULT_F_MIN, f_max=DEFAULT_F_MAX, f_step=DEFAULT_STEP):
-    """Geometric grid built by repeated multiplication (autoeq/frequency_response.py:850-857)."""
-    out = []
-    f = f_min
-    while f <= f_max:
-        out.append(f)
-        f *= f_step
-    return np.array(out)
+    """Geometric grid built by repeated multiplication (autoeq/frequency_response.py:850-857).  Every measurement asks
+    for the same grid: the loop runs once per (f_min, f_max, f_step) and callers get their own copy."""
+    key = (float(f_min), float(f_max), float(f_step))
+    grid = _GRIDS.get(key)
+    if grid is None:
+        out = []
+        f = f_min
+        while f <= f_max:
+            out.append(f)
+            f *= f_step
+        if len(_GRIDS) > 64:
+            _GRIDS.clear()
+        grid = _GRIDS[key] = np.array(out)
+    return grid.copy()
 
 
 def next_fast_len(n):

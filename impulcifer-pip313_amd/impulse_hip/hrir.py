@@ -302,8 +302,14 @@ class HRIR(_PlotBase):
             ctx = _native.default_context()
             base, offs, lens = span(dev)
             n = int(max(lens))
-            m_l, m_r = ctx.magnitude_db_sum_device(base, offs, lens, [0 if sd == "left" else 1 for sd, _ in sides], 2, n)
-            f_l = f_r = np.arange(int(np.ceil(n / 2))) * (self.fs / n)
+            groups = [0 if sd == "left" else 1 for sd, _ in sides]
+            if peak_target is not None and avg_target is None:
+                # np.max of the stacked spectra is all this mode reads: the two maxima are reduced where the spectra are
+                m_l, m_r = (np.array([v]) for v in ctx.magnitude_db_sum_peak_device(base, offs, lens, groups, 2, n))
+                f_l = f_r = None
+            else:
+                m_l, m_r = ctx.magnitude_db_sum_device(base, offs, lens, groups, 2, n)
+                f_l = f_r = np.arange(int(np.ceil(n / 2))) * (self.fs / n)
         else:
             f_l, m_l = magnitude_response(summed("left"), self.fs)
             f_r, m_r = magnitude_response(summed("right"), self.fs)

@@ -383,6 +383,11 @@ int imp_rows_to_pcm_device(imp_ctx* ctx, const float* d_rows, const int64_t* off
  * HRIR.normalize (core/hrir.py:496-503).  db_out: host [n_groups][ceil(n/2)]. */
 int imp_magnitude_db_sum_device(imp_ctx* ctx, const float* d_rows, const int64_t* off, const int64_t* len,
                                 const int64_t* group, int64_t n_rows, int64_t n_groups, int64_t n, double* db_out);
+/* the same sums, but only np.max of each spectrum comes back (HRIR.normalize with peak_target reads nothing else,
+ * core/hrir.py:505): peak_db_out[n_groups]; NaN if a spectrum holds a NaN, -inf for an all-zero sum, as np.max. */
+int imp_magnitude_db_sum_peak_device(imp_ctx* ctx, const float* d_rows, const int64_t* off, const int64_t* len,
+                                     const int64_t* group, int64_t n_rows, int64_t n_groups, int64_t n,
+                                     double* peak_db_out);
 
 /* ---- K1 -> K3 -> K4 -> K5 as one stream-ordered chain ("deconvolution + FIR") -------------------------------
  * recording (device) -> estimate() (core/impulse_response_estimator.py:149-151) -> first peak
