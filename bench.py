@@ -191,7 +191,7 @@ def synth_firs(B, K, seed=0xF1):
     return firs
 
 
-def slice_rate(est, rec, L, reps=3):
+def slice_rate(est, rec, L, reps=20):
     """SURVEY 8(d) secondary figure: the whole hot-path slice (ingest K1 -> crop_heads K3/K4 -> crop_tails K7/K4 ->
     EQ curves + FIR design K12/K6 -> equalize K5 -> normalize K2) on ONE 7.1 x 2-ear measurement laid out as a recording
     (2 s lead + one column per speaker): interleaved PCM frames in, float64 host arrays out; the responses stay on the
@@ -209,7 +209,8 @@ def slice_rate(est, rec, L, reps=3):
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        run_slice(est, job)                                   # plans, tables
+        for _ in range(2):
+            run_slice(est, job)[0].to_host()                  # plans, tables, the allocator's steady state
         t0 = time.perf_counter()
         for _ in range(reps):
             run_slice(est, job)[0].to_host()                  # float64 host arrays out

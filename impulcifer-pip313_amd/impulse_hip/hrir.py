@@ -203,6 +203,23 @@ def ingest_pcm_frames(estimator, expected_fs, fs, frames, speakers, side=None, s
     return ordered
 
 
+def _rows_matrix(rows):
+    """np.stack(rows) - or, when the rows already ARE the consecutive rows of one C-contiguous matrix (the FIR batch of
+    process_equalization_batch), that matrix without the copy."""
+    first = rows[0]
+    base = first.base
+    if (base is not None and isinstance(base, np.ndarray) and base.ndim == 2 and base.flags.c_contiguous
+            and base.dtype == first.dtype and base.shape[1] == first.shape[0] and len(rows) <= base.shape[0]
+            and all(r.base is base and r.flags.c_contiguous for r in rows)):
+        step = base.strides[0]
+        p0 = first.ctypes.data
+        i0, rem = divmod(p0 - base.ctypes.data, step)
+        if rem == 0 and 0 <= i0 and i0 + len(rows) <= base.shape[0] and \
+                all(r.ctypes.data == p0 + i * step for i, r in enumerate(rows)):
+            return base[i0:i0 + len(rows)]
+    return np.stack(rows)
+
+
 class HRIR(_PlotBase):
     def __init__(self, estimator):
         self.estimator = estimator
@@ -613,7 +630,7 @@ class HRIR(_PlotBase):
                 n, k = dev[0].n, len(taps[0])
                 out_pitch = (n + k - 1 + 63) // 64 * 64
                 block = DeviceBlock(_native.default_context(), len(dev) * out_pitch)
-                out_len = _k5_plans.run_device(dev[0].ptr, len(dev), pitch, n, np.stack(taps), block.ptr, out_pitch)
+                out_len = _k5_plans.run_device(dev[0].ptr, len(dev), pitch, n, _rows_matrix(taps), block.ptr, out_pitch)
                 for i, (sp, sd) in enumerate(keys):
                     self.irs[sp][sd]._row = Row(block, i * out_pitch, out_len)
                 return
