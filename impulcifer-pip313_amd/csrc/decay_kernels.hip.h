@@ -145,7 +145,7 @@ __device__ inline KneeFit knee_fit(const double* lev, int lo, int hi, double wd,
   const double kappa = a01 * rn / fabs(c01);            // conditioning of the cross term
   f.ok = c00 > 0.0 && fabs(f.slope) >= 1.0 && kappa < 1e3 && f.slope == f.slope;     // dB/s: flatter fits go to the host
   f.es = 64.0 * m * kKneeU * (1.0 + kappa) + ewd + 4.0 * kKneeEl * (ax * rn) / (c00 * fabs(f.slope));
-  f.e_icpt = fabs(xm * f.slope) * f.es + 2.0 * kKneeEl;
+  f.e_icpt = 2.0 * fabs(xm * f.slope) * f.es + 2.0 * kKneeEl;      // slope off by es, xm by ewd <= es, ym by el
   return f;
 }
 
