@@ -195,6 +195,7 @@ static int ctx_create_impl(int device_id, const uint32_t* cu_mask, int mask_word
                 prop.gcnArchName);
   imp_ctx* ctx = new (std::nothrow) imp_ctx();
   if (!ctx) return fail(IMP_ERR_ALLOC, "out of host memory");
+  ctx->k2_bluestein_only = std::getenv("IMPULSE_HIP_K2_BLUESTEIN") != nullptr;
   ctx->device = device_id;
   if (cu_mask && mask_words > 0) {
     ctx->cu_mask.assign(cu_mask, cu_mask + mask_words);

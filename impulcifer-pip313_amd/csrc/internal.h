@@ -54,8 +54,10 @@ struct imp_ctx {
   std::vector<hipStream_t> side_streams;
   // K6 plans keyed by (taps n, fs)
   std::map<std::pair<long long, long long>, MinPhasePlan*> minphase_plans;
-  // K2 plans keyed by row length n
+  // K2 plans keyed by row length n; k2_bluestein_only (IMPULSE_HIP_K2_BLUESTEIN when the context was made): every length
+  // through the chirp-z transform, the cross-check of the direct transform that smooth lengths take
   std::map<long long, struct MagPlan*> magnitude_plans;
+  bool k2_bluestein_only = false;
   // fp64 roots of unity on the device, keyed by transform length (filter-spectrum preparation)
   std::map<long long, void*> fft_roots;
   // kernels whose dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) has been made ON THIS DEVICE:

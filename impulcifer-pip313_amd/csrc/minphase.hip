@@ -187,6 +187,21 @@ __global__ __launch_bounds__(256) void take_real(const cdbl* __restrict__ c, dou
   out[(long long)blockIdx.y * ntaps + k] = c[(long long)blockIdx.y * N + k].x / (double)N;
 }
 
+// ---- K2 when n is a product of the radices above (crop_tails leaves next_fast_len lengths): the DFT itself ----
+__global__ __launch_bounds__(256) void real_to_complex(const double* __restrict__ x, cdbl* __restrict__ a, int n) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  a[(long long)blockIdx.y * n + m] = make_double2(x[(long long)blockIdx.y * n + m], 0.0);
+}
+
+// out = 20 log10 |X[k]| for k < half (no epsilon: -inf for exact zeros)
+__global__ __launch_bounds__(256) void direct_post_db(const cdbl* __restrict__ X, double* __restrict__ out, int n, int half) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= half) return;
+  const cdbl v = X[(long long)blockIdx.y * n + k];
+  out[(long long)blockIdx.y * half + k] = 20.0 * log10(hypot(v.x, v.y));
+}
+
 // ---- K2: arbitrary-length DFT by Bluestein's chirp-z identity --------------------------------
 // a[m] = x[m] c[m] (zero padded to Mfft), c[m] = exp(-i pi m^2 / n)
 __global__ __launch_bounds__(256) void bluestein_pre(const double* __restrict__ x, const cdbl* __restrict__ chirp,
@@ -465,6 +480,7 @@ static int minphase_run(imp_ctx* ctx, const double* gain, const double* d_gain, 
 // ------------------------------------------------------------------------------------------------
 struct MagPlan {
   int n = 0, mfft = 0;
+  bool direct = false;          // n factorises over the Stockham radices: one n-point transform, no chirp
   std::vector<int> fac;
   cdbl *roots = nullptr, *chirp = nullptr, *bhat = nullptr;
   int64_t cap = 0;
@@ -559,6 +575,18 @@ static int magnitude_db_core(imp_ctx* ctx, const double* x, const float* d_rows,
       p = new (std::nothrow) MagPlan();
       if (!p) return fail(IMP_ERR_ALLOC, "out of host memory");
       p->n = (int)n;
+      if (n >= 2 && !ctx->k2_bluestein_only && !factorise((int)n).empty()) {
+        p->direct = true;
+        p->mfft = (int)n;
+        p->fac = factorise((int)n);
+        if (upload_roots(&p->roots, (int)n, ctx->stream) != IMP_OK || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+          mag_plan_free(p);
+          return fail(IMP_ERR_HIP, "imp_magnitude_db: plan set-up for n = %lld failed", (long long)n);
+        }
+        plans[(long long)n] = p;
+      }
+    }
+    if (!p->direct && !p->chirp) {
       int mf = 1;
       while (mf < 2 * (int)n - 1) mf <<= 1;
       if (mf < 4) mf = 4;
@@ -624,14 +652,22 @@ static int magnitude_db_core(imp_ctx* ctx, const double* x, const float* d_rows,
   }
   auto grid_for = [&](int count) { return dim3((unsigned)((count + 255) / 256), (unsigned)B); };
   cdbl *cur = p->a, *oth = p->b;
-  hipLaunchKernelGGL(bluestein_pre, grid_for(p->mfft), dim3(256), 0, s, p->x, p->chirp, cur, p->n, p->mfft);
-  HIP_TRY(hipGetLastError());
-  if ((rc = run_fft(ctx, p->fac, p->roots, p->mfft, B, -1, &cur, &oth))) return rc;
-  hipLaunchKernelGGL(pointwise_mul, grid_for(p->mfft), dim3(256), 0, s, cur, p->bhat, p->mfft);
-  HIP_TRY(hipGetLastError());
-  if ((rc = run_fft(ctx, p->fac, p->roots, p->mfft, B, +1, &cur, &oth))) return rc;
-  hipLaunchKernelGGL(bluestein_post_db, grid_for(half), dim3(256), 0, s, cur, p->chirp, p->out, p->mfft, half);
-  HIP_TRY(hipGetLastError());
+  if (p->direct) {                                       // n = 2^a 3^b 5^c 11^d: the n-point transform itself
+    hipLaunchKernelGGL(real_to_complex, grid_for(p->n), dim3(256), 0, s, p->x, cur, p->n);
+    HIP_TRY(hipGetLastError());
+    if ((rc = run_fft(ctx, p->fac, p->roots, p->n, B, -1, &cur, &oth))) return rc;
+    hipLaunchKernelGGL(direct_post_db, grid_for(half), dim3(256), 0, s, cur, p->out, p->n, half);
+    HIP_TRY(hipGetLastError());
+  } else {
+    hipLaunchKernelGGL(bluestein_pre, grid_for(p->mfft), dim3(256), 0, s, p->x, p->chirp, cur, p->n, p->mfft);
+    HIP_TRY(hipGetLastError());
+    if ((rc = run_fft(ctx, p->fac, p->roots, p->mfft, B, -1, &cur, &oth))) return rc;
+    hipLaunchKernelGGL(pointwise_mul, grid_for(p->mfft), dim3(256), 0, s, cur, p->bhat, p->mfft);
+    HIP_TRY(hipGetLastError());
+    if ((rc = run_fft(ctx, p->fac, p->roots, p->mfft, B, +1, &cur, &oth))) return rc;
+    hipLaunchKernelGGL(bluestein_post_db, grid_for(half), dim3(256), 0, s, cur, p->chirp, p->out, p->mfft, half);
+    HIP_TRY(hipGetLastError());
+  }
   if (peak_only) {                                       // db_out[B]: the maximum of each spectrum (p->x is free again)
     hipLaunchKernelGGL(rows_max_kernel, dim3((unsigned)B), dim3(256), 0, s, p->out, half, p->x);
     HIP_TRY(hipGetLastError());

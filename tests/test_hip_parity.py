@@ -780,6 +780,29 @@ def test_magnitude_response_golden(gpu_ctx, golden):
     assert np.array_equal(magnitude_response(np.zeros(0), 48000)[1], np.zeros(0))
 
 
+def test_magnitude_direct_transform_equals_bluestein(gpu_ctx, monkeypatch):
+    """K2 takes the n-point transform itself when n is a product of the Stockham radices (every length crop_tails leaves:
+    next_fast_len) and Bluestein's chirp-z otherwise: both against np.fft.rfft at 1e-9 dB and against each other, on a
+    context of each kind (the switch is read when a context is made)."""
+    from impulse_hip import Context
+    rng = np.random.default_rng(77)
+    monkeypatch.setenv("IMPULSE_HIP_K2_BLUESTEIN", "1")
+    chirp = Context(0)
+    monkeypatch.delenv("IMPULSE_HIP_K2_BLUESTEIN")
+    try:
+        for n in (2, 6, 2048, 27000, 55296, 2 * 3 * 5 * 11, 65536):
+            rows = rng.standard_normal((3, n)) * np.exp(-np.arange(n) / (n / 6.0))
+            with np.errstate(divide="ignore"):
+                ref = 20 * np.log10(np.abs(np.fft.rfft(rows, axis=1)[:, : (n + 1) // 2]))
+            direct = gpu_ctx.magnitude_db(rows)
+            via_chirp = chirp.magnitude_db(rows)
+            assert direct.shape == ref.shape == via_chirp.shape
+            assert np.max(np.abs(direct - ref)) <= 1e-9, n
+            assert np.max(np.abs(via_chirp - ref)) <= 1e-9, n
+    finally:
+        chirp.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # alignment / shift (next-tier row f1; host-side correlations): the reference's own assertions
 # (tests/test_dsp_stages.py:105-166)
