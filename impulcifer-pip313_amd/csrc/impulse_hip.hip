@@ -172,10 +172,40 @@ extern "C" int imp_device_count(int* n) {
   return IMP_OK;
 }
 
+// CU-masked streams are never destroyed, they go back to this process-wide store: the runtime does not seem to recycle
+// the hardware queue behind hipExtStreamCreateWithCUMask - after ~470 create / destroy cycles in one process the call
+// does not return (tools/soak.py caught it) - so a (device, mask) pair costs at most as many queues as were ever live
+// at the same time.
+static std::mutex g_masked_mu;
+static std::map<std::pair<int, std::vector<uint32_t>>, std::vector<hipStream_t>> g_masked_streams;
+
 int ctx_new_stream(imp_ctx* ctx, hipStream_t* out) {
-  if (ctx->cu_mask.empty()) HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
-  else HIP_TRY(hipExtStreamCreateWithCUMask(out, (uint32_t)ctx->cu_mask.size(), ctx->cu_mask.data()));
+  if (ctx->cu_mask.empty()) {
+    HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return IMP_OK;
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_masked_mu);
+    auto& kept = g_masked_streams[{ctx->device, ctx->cu_mask}];
+    if (!kept.empty()) {
+      *out = kept.back();
+      kept.pop_back();
+      return IMP_OK;
+    }
+  }
+  HIP_TRY(hipExtStreamCreateWithCUMask(out, (uint32_t)ctx->cu_mask.size(), ctx->cu_mask.data()));
   return IMP_OK;
+}
+
+// a stream ctx_new_stream made and nothing uses any more
+static void ctx_release_stream(imp_ctx* ctx, hipStream_t st) {
+  (void)hipStreamSynchronize(st);
+  if (ctx->cu_mask.empty()) {
+    (void)hipStreamDestroy(st);
+    return;
+  }
+  std::lock_guard<std::mutex> lk(g_masked_mu);
+  g_masked_streams[{ctx->device, ctx->cu_mask}].push_back(st);
 }
 
 static int ctx_create_impl(int device_id, const uint32_t* cu_mask, int mask_words, imp_ctx** out) {
@@ -213,7 +243,7 @@ static int ctx_create_impl(int device_id, const uint32_t* cu_mask, int mask_word
   if (const char* mb = std::getenv("IMPULSE_HIP_POOL_MB")) ctx->free_cap = (size_t)std::max(0ll, std::atoll(mb)) << 20;
   int rc = ctx_row_tables(ctx);
   if (rc) {
-    hipStreamDestroy(ctx->stream);
+    ctx_release_stream(ctx, ctx->stream);
     delete ctx;
     return rc;
   }
@@ -231,10 +261,7 @@ extern "C" int imp_ctx_create_masked(int device_id, const uint32_t* cu_mask, int
 extern "C" int imp_ctx_set_stream(imp_ctx* ctx, void* hip_stream) {
   if (!ctx) return fail(IMP_ERR_INVALID, "null ctx");
   IMP_CTX_LOCK(ctx);
-  if (ctx->own_stream && ctx->stream) {
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipStreamDestroy(ctx->stream));
-  }
+  if (ctx->own_stream && ctx->stream) ctx_release_stream(ctx, ctx->stream);
   ctx->stream = (hipStream_t)hip_stream;
   ctx->own_stream = false;
   return IMP_OK;
@@ -274,11 +301,8 @@ extern "C" void imp_ctx_destroy(imp_ctx* ctx) {
   minphase_plans_destroy(ctx);
   fft_roots_destroy(ctx);
   magnitude_plans_destroy(ctx);
-  for (auto st : ctx->side_streams) {
-    (void)hipStreamSynchronize(st);
-    (void)hipStreamDestroy(st);
-  }
-  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  for (auto st : ctx->side_streams) ctx_release_stream(ctx, st);
+  if (ctx->own_stream && ctx->stream) ctx_release_stream(ctx, ctx->stream);
   delete ctx;
 }
 

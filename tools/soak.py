@@ -66,13 +66,34 @@ def main():
         ctx.free(d_x)
         ctx.free(d_o)
         tail.close()
+        # the device knee search (its segment block comes from the pool), the staged window tables, the peak-only spectra
+        from impulse_hip.device_rows import DeviceBlock, Row, span
+        blk = DeviceBlock(ctx, 4 * 30016)
+        flat = np.zeros((4, 30016), dtype=np.float32)
+        for i, r in enumerate(rows):
+            flat[i, :30000] = r
+        ctx.h2d(blk.ptr, flat)
+        drows = [Row(blk, i * 30016, 30000) for i in range(4)]
+        base, offs, lens = span(drows)
+        ctx.decay_knees_device(base, offs, lens, 48000)
+        ctx.apply_window_device(base, offs, base, offs, lens, [dict(fade_out=100)] * 4)
+        ctx.magnitude_db_sum_peak_device(base, offs, lens, [0, 1, 0, 1], 2, 30000)
+        blk.close()
         return float(y[0, 0])
 
     for _ in range(10):
         once()
     before = free_bytes()
-    for _ in range(iters):
+    import time
+    t0 = time.perf_counter()
+    import faulthandler
+    for it in range(iters):
+        # a call that does not come back within a minute: print where the host is waiting and leave
+        faulthandler.dump_traceback_later(60, exit=True)
         once()
+        faulthandler.cancel_dump_traceback_later()
+        if it % 50 == 49:
+            print(f"  {it + 1} iterations, {time.perf_counter() - t0:.0f} s", flush=True)
     after = free_bytes()
     print(f"{iters} iterations: free device memory {before / 2**20:.1f} MiB -> {after / 2**20:.1f} MiB (delta {(before - after) / 2**20:.2f} MiB)")
     assert before - after < 8 * 2 ** 20, "device memory leak"
