@@ -626,7 +626,12 @@ __global__ __launch_bounds__(256) void seg_maxabs_kernel(const double* __restric
     m = fmax(m, fabs(row[i]));
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) m = fmax(m, __shfl_xor(m, s, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(&maxbits[b], (unsigned long long)__double_as_longlong(m));
+  // one atomic per workgroup: the maxima of all rows share a cache line, and one L2 channel serves every operation on it
+  __shared__ double s_m[4];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(&maxbits[b], (unsigned long long)__double_as_longlong(fmax(fmax(s_m[0], s_m[1]), fmax(s_m[2], s_m[3]))));
 }
 
 // e = (x / top)^2 when top >= 1e-20 (core/decay.py:96-100), else x^2; in place

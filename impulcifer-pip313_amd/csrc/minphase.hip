@@ -128,25 +128,36 @@ __global__ __launch_bounds__(256) void firwin2_window(const cdbl* __restrict__ t
   ir[(long long)blockIdx.y * numtaps + k] = make_double2(v * w, 0.0);
 }
 
-// mag = |H| in place (.x), per-transform minimum of the strictly positive magnitudes
+// mag = |H| in place (.x), per-transform minimum of the strictly positive magnitudes.  The minima of all transforms sit
+// in ONE cache line, and every operation on it - atomic or plain load - is served by one L2 channel at ~10 ns apiece:
+// one per wave (4 800 at 16 x 19 200 points) took 43 - 60 us.  A workgroup now covers kMagPerThread x 256 points, folds
+// its four waves in LDS and sends one atomic, after a plain read that lets all but a few skip even that.
+constexpr int kMagPerThread = 8;
 __global__ __launch_bounds__(256) void magnitude_and_min(cdbl* __restrict__ h, unsigned long long* __restrict__ minbits,
                                                          int N) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
   double m = INFINITY;
-  if (k < N) {
-    cdbl* p = h + (long long)blockIdx.y * N + k;
-    const double mag = hypot(p->x, p->y);
-    *p = make_double2(mag, 0.0);
-    if (mag > 0.0) m = mag;
+#pragma unroll
+  for (int u = 0; u < kMagPerThread; ++u) {
+    const int k = (blockIdx.x * kMagPerThread + u) * 256 + threadIdx.x;
+    if (k < N) {
+      cdbl* p = h + (long long)blockIdx.y * N + k;
+      const double mag = hypot(p->x, p->y);
+      *p = make_double2(mag, 0.0);
+      if (mag > 0.0) m = fmin(m, mag);
+    }
   }
 #pragma unroll
   for (int sft = 32; sft > 0; sft >>= 1) m = fmin(m, __shfl_xor(m, sft, 64));
-  // positive doubles order like their bit patterns
-  // (4 800 waves on 16 addresses: the plain read first lets all but the few that lower the minimum skip the atomic; a
-  // stale read only means an atomic that changes nothing)
-  if ((threadIdx.x & 63) == 0 && m != INFINITY &&
-      (unsigned long long)__double_as_longlong(m) < __atomic_load_n(&minbits[blockIdx.y], __ATOMIC_RELAXED))
-    atomicMin(&minbits[blockIdx.y], (unsigned long long)__double_as_longlong(m));
+  __shared__ double s_m[4];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmin(fmin(s_m[0], s_m[1]), fmin(s_m[2], s_m[3]));
+    // positive doubles order like their bit patterns; a stale plain read only means an atomic that changes nothing
+    if (m != INFINITY &&
+        (unsigned long long)__double_as_longlong(m) < __atomic_load_n(&minbits[blockIdx.y], __ATOMIC_RELAXED))
+      atomicMin(&minbits[blockIdx.y], (unsigned long long)__double_as_longlong(m));
+  }
 }
 
 // x = 0.5 * log(mag + 1e-7 * min)
@@ -233,24 +244,33 @@ __global__ __launch_bounds__(256) void bluestein_post_db(const cdbl* __restrict_
   out[(long long)blockIdx.y * half + k] = 20.0 * log10(hypot(v.x, v.y) / (double)mfft);
 }
 
-// np.max of each row of out[B][half] (NaN if the row holds one, as np.max): one workgroup per row
-__global__ __launch_bounds__(256) void rows_max_kernel(const double* __restrict__ out, int half, double* __restrict__ peak) {
+// np.max of each row of out[B][half] (NaN if the row holds one, as np.max): one workgroup of 1024 per row, eight loads
+// in flight per thread (256 threads walking the row one load at a time took 37 us for two rows of 32 448)
+__global__ __launch_bounds__(1024) void rows_max_kernel(const double* __restrict__ out, int half, double* __restrict__ peak) {
   const double* row = out + (long long)blockIdx.x * half;
   double m = -INFINITY;
   bool nan = false;
-  for (int k = threadIdx.x; k < half; k += 256) {
-    const double v = row[k];
-    nan = nan || v != v;
-    m = v > m ? v : m;
+  for (int k0 = 0; k0 < half; k0 += 8 * 1024) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u * 1024 + (int)threadIdx.x;
+      v[u] = k < half ? row[k] : -INFINITY;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      nan = nan || v[u] != v[u];
+      m = v[u] > m ? v[u] : m;
+    }
   }
-  __shared__ double s_m[256];
+  __shared__ double s_m[1024];
   __shared__ int s_nan;
   if (threadIdx.x == 0) s_nan = 0;
   __syncthreads();
   s_m[threadIdx.x] = m;
   if (nan) s_nan = 1;
   __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
+  for (int st = 512; st > 0; st >>= 1) {
     if ((int)threadIdx.x < st) s_m[threadIdx.x] = s_m[threadIdx.x] > s_m[threadIdx.x + st] ? s_m[threadIdx.x] : s_m[threadIdx.x + st];
     __syncthreads();
   }
@@ -261,7 +281,9 @@ std::vector<int> factorise(int n) {
   std::vector<int> f;
   // Every pass is one launch at the launch floor (~6 us at these sizes): radix 8 passes shorten the power-of-two part
   // (78 VGPRs; the O(R^2) butterfly of radix 16 needs 256 and gains nothing more).  Whole slice, radix 4 / 8 / 16:
-  // 3.47 / 3.38 / 3.45 ms.  IMPULSE_HIP_FFT_MAX_RADIX overrides.
+  // 3.47 / 3.38 / 3.45 ms.  Two-level butterflies (16 = 4 x 4, 25 = 5 x 5 inside the thread, 126 / 155 VGPRs) were
+  // tried in round 3: 34 passes per slice instead of 47, and the same 300 us - 9.4 us per radix-16 pass against 6 - 7 us
+  // per radix-8 pass.  IMPULSE_HIP_FFT_MAX_RADIX overrides.
   static const int max_radix = [] {
     const char* e = std::getenv("IMPULSE_HIP_FFT_MAX_RADIX");
     return e ? std::atoi(e) : 8;
@@ -455,7 +477,8 @@ static int minphase_run(imp_ctx* ctx, const double* gain, const double* d_gain, 
   };
   if (stage == 0) return dump_real(cur);
   if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, -1, &cur, &oth))) return rc;
-  hipLaunchKernelGGL(magnitude_and_min, grid_for(N), dim3(256), 0, s, cur, p->minbits, N);
+  hipLaunchKernelGGL(magnitude_and_min, dim3((unsigned)((N + 256 * kMagPerThread - 1) / (256 * kMagPerThread)), (unsigned)B),
+                     dim3(256), 0, s, cur, p->minbits, N);
   HIP_TRY(hipGetLastError());
   if (stage == 1) return dump_real(cur);
   hipLaunchKernelGGL(half_log, grid_for(N), dim3(256), 0, s, cur, p->minbits, N);
@@ -669,7 +692,7 @@ static int magnitude_db_core(imp_ctx* ctx, const double* x, const float* d_rows,
     HIP_TRY(hipGetLastError());
   }
   if (peak_only) {                                       // db_out[B]: the maximum of each spectrum (p->x is free again)
-    hipLaunchKernelGGL(rows_max_kernel, dim3((unsigned)B), dim3(256), 0, s, p->out, half, p->x);
+    hipLaunchKernelGGL(rows_max_kernel, dim3((unsigned)B), dim3(1024), 0, s, p->out, half, p->x);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(db_out, p->x, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, s));
   } else {
