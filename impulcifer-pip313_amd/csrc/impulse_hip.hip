@@ -373,9 +373,18 @@ extern "C" int imp_free(imp_ctx* ctx, void* dptr) {
   IMP_CTX_LOCK(ctx);
   int rc = ctx_bind(ctx);
   if (rc) return rc;
-  // nothing in flight may still use the block, whoever gets it next (hipFree would have drained the device too)
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
-  for (auto st : ctx->side_streams) HIP_TRY(hipStreamSynchronize(st));
+  // Whoever gets the block next uses it in the order of the context's stream - every entry point of this library
+  // queues its work (copies included) there - so a context with that one stream hands the block back without waiting:
+  // what is still in flight on it finishes before anything queued later starts.  Contexts with overlap lanes (work on
+  // side streams) drain first, as hipFree would.  IMPULSE_HIP_FREE_SYNC=1: always drain.
+  static const bool always_sync = [] {
+    const char* e = std::getenv("IMPULSE_HIP_FREE_SYNC");
+    return e && e[0] == '1';
+  }();
+  if (always_sync || !ctx->side_streams.empty()) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto st : ctx->side_streams) HIP_TRY(hipStreamSynchronize(st));
+  }
   if (!ctx_block_put(ctx, dptr)) return fail(IMP_ERR_INVALID, "imp_free: %p did not come from imp_malloc on this context", dptr);
   return IMP_OK;
 }

@@ -860,7 +860,7 @@ class ConvPlan:
             ctx.h2d(d_in, frames)
             self._launch_pcm_columns(d_in, frames, column_starts, d_out, pitch)
         finally:
-            ctx.free(d_in)                                  # synchronises the stream first
+            ctx.free(d_in)                                  # ordered on the context's stream: no wait
 
     def _launch_pcm_columns(self, d_in, frames, column_starts, d_out, pitch):
         """Launch groups for the columns of an uploaded PCM block: column j, track t -> row j * tracks + t of d_out.

@@ -60,9 +60,14 @@ int imp_ctx_synchronize(imp_ctx* ctx);
 void imp_ctx_destroy(imp_ctx* ctx);
 
 /* device memory helpers (so a NumPy-only host needs no other HIP binding).  imp_free takes only pointers imp_malloc of
- * the same context returned; it waits for the context's streams and then KEEPS the block for the next request of about
- * that size (hipFree costs ~0.4 ms and drains the device), up to IMPULSE_HIP_POOL_MB (default 2048; 0 = give every
- * block back at once).  imp_ctx_destroy releases what is kept and what was never handed back. */
+ * the same context returned and KEEPS the block for the next request of about that size (hipFree costs ~0.4 ms and
+ * drains the device), up to IMPULSE_HIP_POOL_MB (default 2048; 0 = give every block back at once).  The free is ordered
+ * on the context's stream: it does not wait for work already queued there, and whoever gets the block next reaches it
+ * through that same stream (every entry point of this library queues its kernels and copies there), so that work is
+ * finished by then.  A context with overlap lanes (imp_plan_set_overlap: work on side streams) drains all its streams
+ * first; so does every context under IMPULSE_HIP_FREE_SYNC=1.  A block that OTHER contexts or streams still use must be
+ * synchronised by the caller before it is freed, as with hipFreeAsync.  imp_ctx_destroy releases what is kept and what
+ * was never handed back. */
 int imp_malloc(imp_ctx* ctx, size_t bytes, void** dptr);
 int imp_free(imp_ctx* ctx, void* dptr);
 int imp_memcpy_h2d(imp_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);

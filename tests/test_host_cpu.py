@@ -442,3 +442,35 @@ def test_line_fit_has_the_bits_of_numpy_cov():
         want = (slope, np.mean(ys) - slope * np.mean(xs))
         got = _fit_line(xs, ys)
         assert got[0] == want[0] and got[1] == want[1]
+
+
+def test_fir_batch_reaches_k5_without_a_copy_only_when_it_is_the_same_matrix():
+    """HRIR.equalize_channels hands K5 the FIR matrix of process_equalization_batch itself when the per-channel taps are
+    its consecutive rows; anything else (copies, another order, a subset with gaps, Fortran order) is stacked as before."""
+    from impulse_hip.hrir import _rows_matrix
+    m = np.empty((4, 6))
+    m[:] = np.arange(24.0).reshape(4, 6)
+    same = _rows_matrix([m[i] for i in range(4)])
+    assert np.shares_memory(same, m) and np.array_equal(same, m)
+    part = _rows_matrix([m[1], m[2]])
+    assert np.shares_memory(part, m) and np.array_equal(part, m[1:3])
+    for rows in ([m[2], m[1]], [m[0], m[2]], [m[0].copy(), m[1].copy()], [m[0], m[1][::-1]], [np.asfortranarray(m)[0], np.asfortranarray(m)[1]],
+                 [m[0, :3], m[1, :3]]):
+        got = _rows_matrix(rows)
+        assert not np.shares_memory(got, m)
+        assert np.array_equal(got, np.stack(rows))
+
+
+def test_frequency_grid_is_cached_but_never_shared():
+    """generate_frequencies runs its multiplication loop once per (f_min, f_max, f_step); every caller gets its own array
+    (the reference's callers write into theirs)."""
+    from impulse_hip.frequency_response import FrequencyResponse, generate_frequencies
+    a = generate_frequencies(10, 24000, 1.01)
+    b = FrequencyResponse.generate_frequencies(f_min=10, f_max=24000, f_step=1.01)
+    ref, f = [], 10
+    while f <= 24000:
+        ref.append(f)
+        f *= 1.01
+    assert np.array_equal(a, np.array(ref)) and np.array_equal(a, b) and not np.shares_memory(a, b)
+    a[0] = -1.0
+    assert generate_frequencies(10, 24000, 1.01)[0] == 10.0
