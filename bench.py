@@ -216,7 +216,9 @@ def slice_rate(est, rec, L, reps=20):
             run_slice(est, job)[0].to_host()                  # float64 host arrays out
         dt = (time.perf_counter() - t0) / reps
     return dict(value=16 / dt, unit="IR/s", ms_per_measurement=dt * 1e3,
-                note="end to end: PCM frames in host memory -> float64 responses in host memory, incl. PCIe; 16 IRs per measurement; not the headline metric")
+                note="end to end: PCM frames in host memory -> float64 responses in host memory, incl. PCIe; 16 IRs per "
+                     "measurement, one measurement after the other (the FIR design of a measurement runs on a second stream "
+                     "while its recording uploads); not the headline metric")
 
 
 # ------------------------------------------------------------------------------------------------------

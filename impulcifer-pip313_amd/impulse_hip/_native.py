@@ -995,13 +995,45 @@ def host_spectrum(filt, n1_rows):
 
 
 _default_ctx = None
+_aux_ctx = None
 _default_lock = threading.Lock()
+_thread_ctx = threading.local()
 
 
 def default_context():
-    """Process-wide context on IMPULSE_HIP_DEVICE (default 0)."""
+    """Process-wide context on IMPULSE_HIP_DEVICE (default 0) - or the one `using_context` installed for this thread."""
     global _default_ctx
+    override = getattr(_thread_ctx, "ctx", None)
+    if override is not None:
+        return override
     with _default_lock:
         if _default_ctx is None:
             _default_ctx = Context(int(os.environ.get("IMPULSE_HIP_DEVICE", "0")))
         return _default_ctx
+
+
+def aux_context():
+    """A second context (its own stream) on the default context's device, for work that does not depend on what the
+    default context is doing: pipeline_slice designs the equalisation FIRs there while the recording uploads."""
+    global _aux_ctx
+    with _default_lock:
+        if _aux_ctx is None or not _aux_ctx._h:
+            _aux_ctx = Context(int(os.environ.get("IMPULSE_HIP_DEVICE", "0")))
+        return _aux_ctx
+
+
+class using_context:
+    """with using_context(ctx): ... - the classes of this package, called from THIS thread inside the block, take `ctx`
+    wherever they would take default_context()."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.prev = getattr(_thread_ctx, "ctx", None)
+        _thread_ctx.ctx = self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _thread_ctx.ctx = self.prev
+        return False

@@ -8,9 +8,45 @@ parity-checked end to end and benchmarked.
 """
 import numpy as np
 
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+from . import _native
 from .frequency_response import FrequencyResponse
 from .hrir import HRIR
 from .parallel_workers import process_decay_worker, process_equalization_batch
+
+_designer = None
+_designer_lock = threading.Lock()
+
+
+def _design_early(tasks, *args):
+    """process_equalization_batch(tasks, ...) on a worker thread and a context of its own (a second stream).  The FIRs
+    depend on the room / headphone / user curves and the target only - not on the recording - so their design (K12 + K6,
+    0.46 ms for a 7.1 layout) runs while the recording crosses PCIe and is deconvolved.  Returns a Future."""
+    global _designer
+    with _designer_lock:
+        if _designer is None:
+            _designer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="impulse-eq")
+
+    def work():
+        with _native.using_context(_native.aux_context()):
+            return process_equalization_batch(tasks, *args)
+
+    return _designer.submit(work)
+
+
+def _expected_tasks(recordings):
+    """(speaker, side) of every response the recordings will bring, in the order HRIR.irs lists them"""
+    seen, out = set(), []
+    for rec in recordings:
+        side = rec[2] if len(rec) > 2 else None
+        for sp in rec[1]:
+            for sd in (("left", "right") if side is None else (side,)):
+                if (sp, sd) not in seen:
+                    seen.add((sp, sd))
+                    out.append((sp, sd))
+    return out
 
 
 def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, decay=None, peak_target=-0.1,
@@ -18,8 +54,18 @@ def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, deca
     """recordings: list of (path_or_(fs, array), speakers[, side]) measurement files.
     Returns the HRIR after: ingest (batched GPU deconvolution) -> crop_heads -> crop_tails ->
     per-channel minimum-phase FIR (batched GPU design) + equalize -> optional decay adjustment ->
-    normalize.  ``stages`` (dict) receives copies of the intermediate channel data when given."""
+    normalize.  ``stages`` (dict) receives copies of the intermediate channel data when given.
+    The FIR design is a function of the curves and the target alone, so it is started first, on a worker thread with a
+    context (stream) of its own, and collected where the reference's stage order needs it: same FIRs, same stage
+    results, the design's 0.46 ms hidden behind the upload of the recording."""
     hrir = HRIR(estimator)
+    fs = estimator.fs
+    common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
+    if target is None:
+        target = FrequencyResponse(name="target", frequency=common.copy(), raw=0)
+    eq_args = (room_frs, hp_left, hp_right, eq_left, eq_right, target, common, fs)
+    planned = _expected_tasks(recordings)
+    design = _design_early(planned, *eq_args) if planned else None
     for rec in recordings:
         src, speakers = rec[0], rec[1]
         side = rec[2] if len(rec) > 2 else None
@@ -41,14 +87,11 @@ def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, deca
     hrir.crop_tails()
     snap("crop_tails")
 
-    fs = estimator.fs
-    common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
-    if target is None:
-        target = FrequencyResponse(name="target", frequency=common.copy(), raw=0)
     tasks = [(sp, sd) for sp, pair in hrir.irs.items() for sd in pair]
-    hrir.equalize_channels({(sp, sd): fir for sp, sd, fir in
-                            process_equalization_batch(tasks, room_frs, hp_left, hp_right, eq_left, eq_right, target,
-                                                       common, fs)})
+    firs = {(sp, sd): fir for sp, sd, fir in design.result()} if design is not None else {}
+    if set(firs) != set(tasks):                              # (a recording that brought other channels than announced)
+        firs = {(sp, sd): fir for sp, sd, fir in process_equalization_batch(tasks, *eq_args)}
+    hrir.equalize_channels({t: firs[t] for t in tasks})
     snap("equalize")
 
     if decay is not None:
