@@ -2027,6 +2027,49 @@ def test_device_resident_stages_equal_the_host_array_stages(gpu_ctx, golden):
     assert np.array_equal(copy.deepcopy(h_dev).irs["FR"]["left"].data, h_dev.irs["FR"]["left"].peek())
 
 
+def test_slice_fir_design_on_the_second_stream_changes_nothing(gpu_ctx, golden, monkeypatch):
+    """run_slice designs the equalisation FIRs on a worker thread and a context of its own while the recording uploads.
+    The same slice with the early design's channel list made wrong on purpose (so that the FIRs are designed where the
+    reference's stage order has them, on the default context) must agree bit for bit, stage by stage; the thread-local
+    context override ends with its block; the early design ran on the auxiliary context."""
+    import slice_input
+    from impulse_hip import _native, pipeline_slice
+    from impulse_hip.frequency_response import FrequencyResponse
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    g = golden("pipeline_slice")
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=48000)
+    fs = 48000
+    frames = np.ascontiguousarray(slice_input.to_pcm32(slice_input.make_tracks(e.test_signal, fs)).T)
+    order = [("FL", "left"), ("FL", "right"), ("FR", "left"), ("FR", "right")]
+    common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
+    room = {sp: {} for sp in ("FL", "FR")}
+    for sp, sd in order:
+        room[sp][sd] = FrequencyResponse("r", frequency=common.copy(), raw=0, error=g[f"room_error_{sp}_{sd}"])
+    assert pipeline_slice._expected_tasks([((fs, frames), ["FL", "FR"])]) == order
+    assert pipeline_slice._expected_tasks([("l.wav", ["FL", "FR"], "left"), ("r.wav", ["FL", "FR"], "right")]) == \
+        [("FL", "left"), ("FR", "left"), ("FL", "right"), ("FR", "right")]
+    seen = []
+    real = pipeline_slice.process_equalization_batch
+    monkeypatch.setattr(pipeline_slice, "process_equalization_batch",
+                        lambda *a: (seen.append(_native.default_context()), real(*a))[1])
+    st_early, st_late = {}, {}
+    h_early, gain_early = pipeline_slice.run_slice(e, [((fs, frames), ["FL", "FR"])], room_frs=room, stages=st_early)
+    assert seen == [_native.aux_context()] and _native.default_context() is not _native.aux_context()
+    monkeypatch.setattr(pipeline_slice, "_expected_tasks", lambda recordings: [("FC", "left")])
+    h_late, gain_late = pipeline_slice.run_slice(e, [((fs, frames), ["FL", "FR"])], room_frs=room, stages=st_late)
+    assert seen[1] is _native.aux_context() and seen[2] is _native.default_context() and len(seen) == 3
+    assert gain_early == gain_late
+    for stage in ("ingest", "crop_heads", "crop_tails", "equalize", "normalize"):
+        for k in order:
+            assert np.array_equal(st_early[stage][k], st_late[stage][k]), (stage, k)
+    with _native.using_context(gpu_ctx):
+        assert _native.default_context() is gpu_ctx
+        with _native.using_context(_native.aux_context()):
+            assert _native.default_context() is _native.aux_context()
+        assert _native.default_context() is gpu_ctx
+    assert _native.default_context() is not gpu_ctx
+
+
 def test_library_rccl_broadcast_single_rank(gpu_ctx, tmp_path):
     """imp_comm_*: the spectrum broadcast by the library itself over RCCL (one rank on this one-GPU box: communicator
     creation from a unique id shared through a file, in-place broadcast of the plan's spectrum, teardown)."""
