@@ -3,10 +3,11 @@
 //
 // The host search (impulse_hip/decay.py) keeps its control flow in NumPy because two of its primitives are not
 // reproducible bit for bit anywhere else: np.log10 (SVML / libm, differs from every other log10 in the last place) and
-// the BLAS dot product inside scipy.stats.linregress.  Everything else - the window means (K7, NumPy's summation
-// order), the time grids, the integer truncations - is plain IEEE arithmetic that the device repeats exactly (this
-// header is compiled with fp contraction off).  So the device search differs from the host search only through
-// quantities that are a few ulp apart, and the knee it returns is an INTEGER: it can only come out different if one of
+// the BLAS dot product inside scipy.stats.linregress.  The time grids and the integer truncations are plain IEEE
+// arithmetic that the device repeats exactly (this header is compiled with fp contraction off); the window means are
+// tree sums within ~1e-14 dB of NumPy's pairwise ones (block_fast_mean below).  So the device search differs from the
+// host search only through quantities that are a few ulp apart, and the knee it returns is an INTEGER: it can only come
+// out different if one of
 // the search's decisions (a comparison against a threshold, an int() truncation, an argmin on the time grid) falls within
 // the width of those few ulp.  Every decision is therefore taken with a guard band derived from explicit error bounds
 // (el for levels, es / ewd for slopes and window durations, propagated to times); a row with any decision inside its
@@ -39,9 +40,40 @@ struct KneeRow {
 };
 
 constexpr double kKneeU = 1.1102230246251565e-16;     // 2^-53
-constexpr double kKneeEl = 1e-12;                     // dB: |device level - NumPy level| (<= 4 ulp of 10 log10, |level| <= 200)
+constexpr double kKneeEl = 1e-12;                     // dB: |device level - NumPy level| (log10 a few ulp apart, |level| <= 200: 3e-13; the mean's summation order: 1e-14)
 
 __device__ inline double knee_db(double mean) { return 10 * log10(fmax(mean, 1e-20)); }
+
+// mean(e[0:n]), e[i] = (x[i] / top)^2 (x[i]^2 when top < 1e-20: core/decay.py:96-100), straight from the fp32 row, by
+// the 256 threads of a workgroup, on every thread.  NOT NumPy's summation order (block_np_mean is, at several barriers
+// and a serial tree lay-out per 8 192 samples): a tree sum of non-negative fp64 terms is within ~log2(n) ulp of any
+// other order - 1e-14 dB on a level, a hundredth of kKneeEl, which bounds |device level - host level| for every
+// decision below.  The levels of the device search need that bound, not the host's bits.
+__device__ inline double block_fast_mean_sq(const float* __restrict__ x, double top, long long n) {
+  __shared__ double s_part[4];
+  if (n <= 0) return __longlong_as_double(0x7ff8000000000000ll);
+  const bool norm = top >= 1e-20;
+  auto e = [&](long long i) {
+    const double v = norm ? (double)x[i] / top : (double)x[i];
+    return v * v;
+  };
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  long long i = threadIdx.x;
+  for (; i + 3 * 256 < n; i += 4 * 256) {                 // four loads in flight
+    acc[0] += e(i);
+    acc[1] += e(i + 256);
+    acc[2] += e(i + 512);
+    acc[3] += e(i + 768);
+  }
+  for (; i < n; i += 256) acc[0] += e(i);
+  double v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft, 64);
+  __syncthreads();                                        // the previous call's s_part is no longer read
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])) / (double)n;
+}
 
 // NumPy's pairwise sum of n <= 128 values f(0) .. f(n - 1) (numpy/_core/src/umath/loops_utils.h.src)
 template <typename F>
@@ -154,11 +186,10 @@ __device__ inline KneeFit knee_fit(const double* lev, int lo, int hi, double wd,
 // 1. analysis spans from the peak search's results (impulse_hip/decay.py _knee_searches) and the first round's windows
 __global__ __launch_bounds__(64) void knee_span_kernel(const RowPeak* __restrict__ res, const int64_t* __restrict__ off,
                                                        const int64_t* __restrict__ len, long long two_fs, double fs,
-                                                       long long seg_pitch, KneeRow* __restrict__ rows,
-                                                       int64_t* __restrict__ seg_src, int64_t* __restrict__ seg_dst,
-                                                       int64_t* __restrict__ seg_len) {
+                                                       KneeRow* __restrict__ rows, unsigned long long* __restrict__ maxbits) {
   if (threadIdx.x) return;
   const int b = blockIdx.x;
+  maxbits[b] = 0ull;
   KneeRow r = {};
   r.src_off = off[b];
   r.n = len[b];
@@ -167,15 +198,12 @@ __global__ __launch_bounds__(64) void knee_span_kernel(const RowPeak* __restrict
   if (r.n == 0 || !(top >= 1e-20f)) pk = 0;
   else if (res[b].first_peak != ~0ull) pk = (long long)res[b].first_peak;
   else pk = (long long)res[b].first_max;
-  seg_dst[b] = (long long)b * seg_pitch;
   if (r.n < 10) {
     r.peak = 0;
     r.knee = r.n;
     r.floor = -200.0;
     r.window = r.n > 0 ? r.n : 1;
     r.done = 1;
-    seg_src[b] = r.src_off;
-    seg_len[b] = 0;
     rows[b] = r;
     return;
   }
@@ -188,8 +216,6 @@ __global__ __launch_bounds__(64) void knee_span_kernel(const RowPeak* __restrict
   }
   r.peak = pk;
   r.n_sq = (int)seg;
-  seg_src[b] = r.src_off + pk;
-  seg_len[b] = seg;
   const double wd = 0.03;
   const int n = fs > 0 ? (int)(r.n_sq / fs / wd) : 0;
   if (n == 0) {                                          // one mean over the whole span decides
@@ -209,19 +235,39 @@ __global__ __launch_bounds__(64) void knee_span_kernel(const RowPeak* __restrict
   rows[b] = r;
 }
 
+__global__ __launch_bounds__(256) void knee_maxabs_kernel(const float* __restrict__ x, const KneeRow* __restrict__ rows,
+                                                          unsigned long long* __restrict__ maxbits) {
+  const int b = blockIdx.y;
+  const KneeRow& r = rows[b];
+  if (r.done) return;
+  const float* seg = x + r.src_off + r.peak;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < r.n_sq; i += (long long)gridDim.x * 256)
+    m = fmaxf(m, fabsf(seg[i]));
+#pragma unroll
+  for (int sft = 32; sft > 0; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
+  __shared__ float s_m[4];
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // one atomic per workgroup (the maxima of all rows share a cache line); bits of a non-negative double order like integers
+  if (threadIdx.x == 0)
+    atomicMax(&maxbits[b], (unsigned long long)__double_as_longlong((double)fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]))));
+}
+
 // 2 / 4. window means of the current round: means[b][i], i < n_win, and the tail's mean at [n_win] in round 1
-__global__ __launch_bounds__(256) void knee_windows_kernel(const KneeRow* __restrict__ rows, const double* __restrict__ e,
-                                                           long long seg_pitch, double* __restrict__ means, int mean_pitch,
-                                                           int with_tail) {
+__global__ __launch_bounds__(256) void knee_windows_kernel(const KneeRow* __restrict__ rows, const float* __restrict__ x,
+                                                           const unsigned long long* __restrict__ maxbits,
+                                                           double* __restrict__ means, int mean_pitch, int with_tail) {
   const int b = blockIdx.y;
   const KneeRow& r = rows[b];
   if (r.done || r.flags) return;
   const int count = r.n_win + (with_tail ? 1 : 0);
-  const double* seg = e + (long long)b * seg_pitch;
+  const float* seg = x + r.src_off + r.peak;
+  const double top = __longlong_as_double((long long)maxbits[b]);
   for (int q = blockIdx.x; q < count; q += gridDim.x) {
     const long long a = q < r.n_win ? (long long)q * r.w : r.tail_a;
     const long long z = q < r.n_win ? a + r.w : r.tail_b;
-    const double m = block_np_mean(seg + a, z - a);
+    const double m = block_fast_mean_sq(seg + a, top, z - a);
     if (threadIdx.x == 0) means[(long long)b * mean_pitch + q] = m;
   }
 }
@@ -301,14 +347,15 @@ __global__ __launch_bounds__(64) void knee_stage1_kernel(KneeRow* __restrict__ r
 // (core/decay.py:163-253).  One workgroup of 256 per response: the refinement's range means are block_np_mean calls
 // that all threads reach together - every thread runs the same scalar flow on the same LDS levels.
 __global__ __launch_bounds__(256) void knee_stage2_kernel(KneeRow* __restrict__ rows, const double* __restrict__ means,
-                                                          int mean_pitch, const double* __restrict__ e,
-                                                          long long seg_pitch, double fs) {
+                                                          int mean_pitch, const float* __restrict__ x,
+                                                          const unsigned long long* __restrict__ maxbits, double fs) {
   const int b = blockIdx.x, tid = threadIdx.x;
   KneeRow r = rows[b];
   if (r.done || r.flags) return;
   __shared__ double lev[kKneeMaxWindows];
   const double* mu = means + (long long)b * mean_pitch;
-  const double* seg = e + (long long)b * seg_pitch;
+  const float* seg = x + r.src_off + r.peak;
+  const double top = __longlong_as_double((long long)maxbits[b]);
   const int n = r.n_win;
   const double wd = r.wd, ewd = r.ewd;
   for (int i = tid; i < n; i += 256) lev[i] = knee_db(mu[i]);
@@ -338,7 +385,7 @@ __global__ __launch_bounds__(256) void knee_stage2_kernel(KneeRow* __restrict__ 
     const int z = grid.nearest_guarded(fmin(t0 + knee_time, total), gt + ekt, unsure);
     if (a >= z) break;
     if (unsure) break;                                    // (uniform: every thread holds the same flags)
-    floor = knee_db(block_np_mean(seg + a, (long long)(z - a)));
+    floor = knee_db(block_fast_mean_sq(seg + a, top, (long long)(z - a)));
     int hi = knee_first_le(lev, n, floor + 8, 4 * kKneeEl, unsure);
     int lo = knee_first_le(lev, n, floor + 28, 4 * kKneeEl, unsure);
     if (hi < 0 || lo < 0) break;

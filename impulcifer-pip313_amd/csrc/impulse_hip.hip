@@ -2160,15 +2160,14 @@ extern "C" int imp_decay_knees_device(imp_ctx* ctx, const float* d_x, const int6
   int rc = ctx_bind(ctx);
   if (rc) return rc;
   const int64_t two_fs = (int64_t)(2 * fs);               // int(2 * fs), core/decay.py:84
-  const int64_t seg_pitch = std::max<int64_t>(1, std::min(two_fs, maxlen));
+  const int64_t span_max = std::max<int64_t>(1, std::min(two_fs, maxlen));
   const int64_t chunks = std::max<int64_t>(1, (maxlen + imp::kPeakChunk - 1) / imp::kPeakChunk);
   const int mean_pitch = imp::kKneeMaxWindows + 1;
-  // scratch: off, len, seg_src, seg_dst, seg_len [B] | row maxima bits [B] | peak results [B] | search state [B] |
-  // window means [B][mean_pitch] | chunk maxima [B][chunks]
+  // scratch: span maxima bits [B] | peak results [B] | search state [B] | window means [B][mean_pitch] | chunk maxima
+  // [B][chunks].  The spans are read where they are (fp32 rows): no fp64 copy of them is made.
   const size_t meta = (size_t)B * sizeof(int64_t);
-  size_t bytes = 3 * meta + (size_t)B * sizeof(unsigned long long) + (size_t)B * sizeof(imp::RowPeak) +
-                 (size_t)B * sizeof(imp::KneeRow) + (size_t)B * mean_pitch * sizeof(double) +
-                 (size_t)(B * chunks) * sizeof(unsigned);
+  size_t bytes = (size_t)B * sizeof(unsigned long long) + (size_t)B * sizeof(imp::RowPeak) + (size_t)B * sizeof(imp::KneeRow) +
+                 (size_t)B * mean_pitch * sizeof(double) + (size_t)(B * chunks) * sizeof(unsigned);
   void* scr = nullptr;
   if ((rc = ctx_scratch(ctx, bytes, &scr))) return rc;
   int64_t *h_tab = nullptr, *d_off = nullptr;
@@ -2176,50 +2175,34 @@ extern "C" int imp_decay_knees_device(imp_ctx* ctx, const float* d_x, const int6
   int64_t* d_len = d_off + B;
   std::memcpy(h_tab, off, meta);
   std::memcpy(h_tab + B, len, meta);
-  int64_t* d_seg_src = (int64_t*)scr;
-  int64_t* d_seg_dst = d_seg_src + B;
-  int64_t* d_seg_len = d_seg_dst + B;
-  unsigned long long* d_max = (unsigned long long*)(d_seg_len + B);
+  unsigned long long* d_max = (unsigned long long*)scr;
   imp::RowPeak* d_res = (imp::RowPeak*)(d_max + B);
   imp::KneeRow* d_rows = (imp::KneeRow*)(d_res + B);
   double* d_means = (double*)(d_rows + B);
   unsigned* d_chunk = (unsigned*)(d_means + (size_t)B * mean_pitch);
-  double* d_e = nullptr;
-  if ((rc = ctx_block_get(ctx, (size_t)(B * seg_pitch) * sizeof(double), (void**)&d_e))) return rc;
   hipStream_t s = ctx->stream;
-  auto bail = [&](int code) {
-    (void)hipStreamSynchronize(s);
-    (void)ctx_block_put(ctx, d_e);
-    return code;
-  };
   std::vector<imp::KneeRow> h((size_t)B);
-  if (ctx_stage_push(ctx, h_tab, d_off, 2 * meta) ||
-      hipMemsetAsync(d_max, 0, (size_t)B * sizeof(unsigned long long), s) != hipSuccess)
-    return bail(fail(IMP_ERR_HIP, "imp_decay_knees_device: upload failed"));
+  if ((rc = ctx_stage_push(ctx, h_tab, d_off, 2 * meta))) return rc;
   hipLaunchKernelGGL(imp::row_chunk_max_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, s, d_x, d_off, d_len,
                      (int64_t)0, d_chunk, chunks);
   hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)B), dim3(imp::kPeakThreads), 0, s, d_x, d_off, d_len,
                      (int64_t)0, (const unsigned*)nullptr, 0, (const unsigned*)d_chunk, chunks, d_res, peak_height,
                      (long long*)nullptr);
   hipLaunchKernelGGL(imp::knee_span_kernel, dim3((unsigned)B), dim3(64), 0, s, (const imp::RowPeak*)d_res, d_off, d_len,
-                     (long long)two_fs, fs, (long long)seg_pitch, d_rows, d_seg_src, d_seg_dst, d_seg_len);
-  const int bpr = (int)std::max<int64_t>(1, std::min<int64_t>(256, (seg_pitch + 4095) / 4096));
-  dim3 grid((unsigned)bpr, (unsigned)B), block(256);
-  hipLaunchKernelGGL(imp::seg_from_float_kernel, grid, block, 0, s, d_x, d_seg_src, d_e, d_seg_dst, d_seg_len);
-  hipLaunchKernelGGL(imp::seg_maxabs_kernel, grid, block, 0, s, d_e, d_seg_dst, d_seg_len, d_max);
-  hipLaunchKernelGGL(imp::seg_square_kernel, grid, block, 0, s, d_e, d_seg_dst, d_seg_len, d_max);
+                     (long long)two_fs, fs, d_rows, d_max);
+  const int bpr = (int)std::max<int64_t>(1, std::min<int64_t>(64, (span_max + 8191) / 8192));
+  dim3 block(256);
+  hipLaunchKernelGGL(imp::knee_maxabs_kernel, dim3((unsigned)bpr, (unsigned)B), block, 0, s, d_x, (const imp::KneeRow*)d_rows, d_max);
   hipLaunchKernelGGL(imp::knee_windows_kernel, dim3(imp::kKneeRound1, (unsigned)B), block, 0, s, (const imp::KneeRow*)d_rows,
-                     (const double*)d_e, (long long)seg_pitch, d_means, mean_pitch, 1);
+                     d_x, (const unsigned long long*)d_max, d_means, mean_pitch, 1);
   hipLaunchKernelGGL(imp::knee_stage1_kernel, dim3((unsigned)B), dim3(64), 0, s, d_rows, (const double*)d_means, mean_pitch, fs);
-  hipLaunchKernelGGL(imp::knee_windows_kernel, dim3(64, (unsigned)B), block, 0, s, (const imp::KneeRow*)d_rows,
-                     (const double*)d_e, (long long)seg_pitch, d_means, mean_pitch, 0);
-  hipLaunchKernelGGL(imp::knee_stage2_kernel, dim3((unsigned)B), block, 0, s, d_rows, (const double*)d_means, mean_pitch,
-                     (const double*)d_e, (long long)seg_pitch, fs);
-  if (hipGetLastError() != hipSuccess) return bail(fail(IMP_ERR_HIP, "imp_decay_knees_device: launch failed"));
-  if (hipMemcpyAsync(h.data(), d_rows, (size_t)B * sizeof(imp::KneeRow), hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipStreamSynchronize(s) != hipSuccess)
-    return bail(fail(IMP_ERR_HIP, "imp_decay_knees_device: readback failed"));
-  (void)ctx_block_put(ctx, d_e);
+  hipLaunchKernelGGL(imp::knee_windows_kernel, dim3(64, (unsigned)B), block, 0, s, (const imp::KneeRow*)d_rows, d_x,
+                     (const unsigned long long*)d_max, d_means, mean_pitch, 0);
+  hipLaunchKernelGGL(imp::knee_stage2_kernel, dim3((unsigned)B), block, 0, s, d_rows, (const double*)d_means, mean_pitch, d_x,
+                     (const unsigned long long*)d_max, fs);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h.data(), d_rows, (size_t)B * sizeof(imp::KneeRow), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   for (int64_t b = 0; b < B; ++b) {
     const imp::KneeRow& r = h[(size_t)b];
     peak_out[b] = r.peak;

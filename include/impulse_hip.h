@@ -369,9 +369,9 @@ int imp_segset_create_device(imp_ctx* ctx, const float* d_x, const int64_t* off,
 /* HRIR.crop_tails (core/hrir.py:585-611) asks every response for decay_params()[1], the Lundeby knee INDEX
  * (core/decay.py:44-260).  For B fp32 device rows this runs the peak search (K3) and the whole knee search on the
  * device, one stream-ordered sequence of launches and one readback: spans [peak, peak + int(2 fs)), e = (x / max)^2,
- * 30 ms window levels, line fit, knee estimate, three windows per 10 dB, up to five refinements.  The window means are
- * imp_segset_range_means' (NumPy's summation order); np.log10 and linregress's BLAS dot product cannot be reproduced
- * to the last bit, so every decision of the search carries a guard band from explicit error bounds and
+ * 30 ms window levels, line fit, knee estimate, three windows per 10 dB, up to five refinements.  np.log10 and
+ * linregress's BLAS dot product cannot be reproduced to the last bit (and the window means here are plain tree sums,
+ * ~1e-14 dB from NumPy's), so every decision of the search carries a guard band from explicit error bounds and
  * flags_out[b] != 0 says "row b has a decision inside its band (1) or a shape outside the device path's limits (2):
  * ask the host search" - for rows with flags_out[b] == 0 knee_out[b] IS the host search's integer.  peak_out[b] is
  * exact for every row; floor_out[b] (dB) is within a few ulp of the host's, window_out[b] its window size. */
