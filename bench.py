@@ -62,8 +62,10 @@ GROUP_CHANNELS = {"c2": 32, "c3": 13, "c4": 8, "c5": 8}
 MEASUREMENTS_PER_BLOCK = {"c2": 2, "c3": 1}
 DEFAULT_BLOCKS = {"c2": 320, "c3": 96, "c4": 12, "c5": 12}
 # calls (chains / K1 launch groups) in flight = streams, measured per workload (IMPULSE_BENCH_GROUP / --lanes; C3: 2 streams
-# x 13-channel groups 194 k IR/s K1 and 154 k chain, 3 x 13: 197 k / 135 k, 3 x 26: 160 k / 135 k)
-CHAINS = {"c2": 3, "c3": 2, "c4": 3, "c5": 3}
+# x 13-channel groups 194 k IR/s K1 and 154 k chain, 3 x 13: 197 k / 135 k, 3 x 26: 160 k / 135 k; C5, tools/c5_group_sweep.sh:
+# 8-channel groups x 2 streams 138 k IR/s, x 3: 130 k, x 1: 111 k, x 4: 119 k; groups of 4 / 6 / 12 / 16 / 32 at their best
+# 131 / 132 / 129 / 126 / 123 k - three 6.3 MB workspaces per channel in flight no longer fit beside inputs and outputs)
+CHAINS = {"c2": 3, "c3": 2, "c4": 2, "c5": 2}
 
 
 def parse_args(argv=None):
@@ -74,7 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lanes", type=int, default=0,
-                    help="chains / K1 launch groups in flight (0: 3, 2 at C3); 1 = strictly serial kernels")
+                    help="chains / K1 launch groups in flight (0: 3 at C2, 2 at C3 - C5); 1 = strictly serial kernels")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not collect FETCH_SIZE / WRITE_SIZE with rocprofv3 child runs (roofline.traffic then comes from "
