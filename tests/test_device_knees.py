@@ -143,3 +143,33 @@ def test_device_knees_fuzz_many_rows_one_call(gpu_ctx):
         datas.append(x)
     clear, flags = _compare(datas, fs)
     assert clear >= 0.8 * len(datas), (clear, np.bincount(flags))
+
+
+def test_staging_ring_grows_and_wraps_with_many_rows(gpu_ctx):
+    """The small host tables of the device-row entry points travel through a 1 MiB pinned ring mirrored on the device.
+    40 000 rows make one call's tables (offsets, lengths, window parameters: 3.2 MB) larger than the ring - it is
+    rebuilt - and 300 more calls make it wrap; every result must still be what NumPy gives."""
+    rng = np.random.default_rng(12)
+    B, n = 40000, 48
+    x = rng.standard_normal((B, n)).astype(np.float32)
+    d = gpu_ctx.malloc(x.nbytes)
+    gpu_ctx.h2d(d, x)
+    offs = np.arange(B, dtype=np.int64) * n
+    lens = np.full(B, n, dtype=np.int64)
+    gpu_ctx.apply_window_device(d, offs, d, offs, lens, [dict(gain=0.5)] * B)
+    idx, mx = gpu_ctx.peak_index_device(d, offs, lens)
+    back = np.empty_like(x)
+    gpu_ctx.synchronize()
+    gpu_ctx.d2h(back, d)
+    assert np.array_equal(back, x * np.float32(0.5))
+    assert np.array_equal(mx, np.max(np.abs(back), axis=1))
+    small = 64
+    for it in range(300):                                   # ~3.4 KiB of tables a call: the 1 MiB ring comes round again
+        g = np.float32(2.0 if it % 2 == 0 else 0.5)           # exact in fp32, the product stays bounded
+        gpu_ctx.apply_window_device(d, offs[:small], d, offs[:small], lens[:small], [dict(gain=float(g))] * small)
+        back[:small] *= g
+    out = np.empty((small, n), dtype=np.float32)
+    gpu_ctx.synchronize()
+    gpu_ctx.d2h(out, d)
+    assert np.array_equal(out, back[:small])
+    gpu_ctx.free(d)
