@@ -857,7 +857,7 @@ def main(argv=None):
         mpb = 1
         n_blocks = args.blocks or max(1, (hi - lo) // B)      # one step = one pass over this rank's shard
     else:
-        mpb = MEASUREMENTS_PER_BLOCK[args.workload]
+        mpb = int(os.environ.get("IMPULSE_BENCH_MEASUREMENTS", "0")) or MEASUREMENTS_PER_BLOCK[args.workload]
         B = B_meas * mpb                                      # a resident block = mpb measurements, rows contiguous
         rec, L, pitch, delays = synth_recordings(est, B, seed0=0xC2 + 1000 * rank)
         # C2: 320 blocks x 2 measurements x 16 channels = 10 240 IRs per step: 20 steps time 0.55 s at 370 k IR/s
