@@ -172,43 +172,19 @@ extern "C" int imp_device_count(int* n) {
   return IMP_OK;
 }
 
-// CU-masked streams are never destroyed, they go back to this process-wide store: the runtime does not seem to recycle
-// the hardware queue behind hipExtStreamCreateWithCUMask - after ~470 create / destroy cycles in one process the call
-// does not return (tools/soak.py caught it) - so a (device, mask) pair costs at most as many queues as were ever live
-// at the same time.
-static std::mutex g_masked_mu;
-static std::map<std::pair<int, std::vector<uint32_t>>, std::vector<hipStream_t>> g_masked_streams;
-
 int ctx_new_stream(imp_ctx* ctx, hipStream_t* out) {
-  if (ctx->cu_mask.empty()) {
-    HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
-    return IMP_OK;
-  }
-  {
-    std::lock_guard<std::mutex> lk(g_masked_mu);
-    auto& kept = g_masked_streams[{ctx->device, ctx->cu_mask}];
-    if (!kept.empty()) {
-      *out = kept.back();
-      kept.pop_back();
-      return IMP_OK;
-    }
-  }
-  HIP_TRY(hipExtStreamCreateWithCUMask(out, (uint32_t)ctx->cu_mask.size(), ctx->cu_mask.data()));
+  (void)ctx;
+  HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
   return IMP_OK;
 }
 
 // a stream ctx_new_stream made and nothing uses any more
-static void ctx_release_stream(imp_ctx* ctx, hipStream_t st) {
+static void ctx_release_stream(imp_ctx*, hipStream_t st) {
   (void)hipStreamSynchronize(st);
-  if (ctx->cu_mask.empty()) {
-    (void)hipStreamDestroy(st);
-    return;
-  }
-  std::lock_guard<std::mutex> lk(g_masked_mu);
-  g_masked_streams[{ctx->device, ctx->cu_mask}].push_back(st);
+  (void)hipStreamDestroy(st);
 }
 
-static int ctx_create_impl(int device_id, const uint32_t* cu_mask, int mask_words, imp_ctx** out) {
+extern "C" int imp_ctx_create(int device_id, imp_ctx** out) {
   if (!out) return fail(IMP_ERR_INVALID, "imp_ctx_create: null output");
   *out = nullptr;
   int n = 0;
@@ -227,15 +203,6 @@ static int ctx_create_impl(int device_id, const uint32_t* cu_mask, int mask_word
   if (!ctx) return fail(IMP_ERR_ALLOC, "out of host memory");
   ctx->k2_bluestein_only = std::getenv("IMPULSE_HIP_K2_BLUESTEIN") != nullptr;
   ctx->device = device_id;
-  if (cu_mask && mask_words > 0) {
-    ctx->cu_mask.assign(cu_mask, cu_mask + mask_words);
-    bool any = false;
-    for (uint32_t w : ctx->cu_mask) any |= w != 0;
-    if (!any) {
-      delete ctx;
-      return fail(IMP_ERR_INVALID, "imp_ctx_create_masked: the CU mask is empty");
-    }
-  }
   if (ctx_new_stream(ctx, &ctx->stream)) {
     delete ctx;
     return IMP_ERR_HIP;
@@ -251,19 +218,20 @@ static int ctx_create_impl(int device_id, const uint32_t* cu_mask, int mask_word
   return IMP_OK;
 }
 
-extern "C" int imp_ctx_create(int device_id, imp_ctx** out) { return ctx_create_impl(device_id, nullptr, 0, out); }
-
-extern "C" int imp_ctx_create_masked(int device_id, const uint32_t* cu_mask, int mask_words, imp_ctx** out) {
-  if (!cu_mask || mask_words < 1 || mask_words > 64) return fail(IMP_ERR_INVALID, "imp_ctx_create_masked: bad CU mask");
-  return ctx_create_impl(device_id, cu_mask, mask_words, out);
-}
-
+// The staging ring and the stream-ordered imp_free are correct only while all of a context's work is on ONE stream: the
+// outgoing stream is drained before the swap, whoever owns it, so nothing queued there can still read the ring or a block
+// that imp_free has handed back; the ring starts over on the new stream.
 extern "C" int imp_ctx_set_stream(imp_ctx* ctx, void* hip_stream) {
   if (!ctx) return fail(IMP_ERR_INVALID, "null ctx");
   IMP_CTX_LOCK(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  if (ctx->stream) HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (auto st : ctx->side_streams) HIP_TRY(hipStreamSynchronize(st));
   if (ctx->own_stream && ctx->stream) ctx_release_stream(ctx, ctx->stream);
   ctx->stream = (hipStream_t)hip_stream;
   ctx->own_stream = false;
+  ctx->stage_pos = 0;
   return IMP_OK;
 }
 

@@ -37,7 +37,6 @@ struct imp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = true;
-  std::vector<uint32_t> cu_mask;        // non-empty: the context's streams run on these CUs only (imp_ctx_create_masked)
   cf* tw_t1 = nullptr;                  // row-pass stage tables, see conv_kernels.hip.h
   cf* tw_t2 = nullptr;
   cf* tw_t4 = nullptr;
@@ -93,7 +92,7 @@ int ctx_kernel_lds(imp_ctx* ctx, const void* kernel, size_t bytes);
 #define IMP_CTX_LOCK(ctx) std::lock_guard<std::recursive_mutex> imp_ctx_lock_((ctx)->mu)
 
 int ctx_bind(imp_ctx* ctx);
-// a new stream of the context: non-blocking, restricted to the context's CU mask if it has one
+// a new non-blocking stream of the context's device
 int ctx_new_stream(imp_ctx* ctx, hipStream_t* out);
 void minphase_plans_destroy(imp_ctx* ctx);
 void magnitude_plans_destroy(imp_ctx* ctx);

@@ -58,7 +58,6 @@ SIGNATURES = {
     "imp_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "imp_ctx_synchronize": (C.c_int, [_vp]),
     "imp_ctx_destroy": (None, [_vp]),
-    "imp_ctx_create_masked": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(_vp)]),
     "imp_malloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "imp_free": (C.c_int, [_vp, _vp]),
     "imp_memcpy_h2d": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -198,22 +197,14 @@ def _ptr_i64(a):
 class Context:
     """One GPU + one stream (imp_ctx)."""
 
-    def __init__(self, device=0, cus=None):
-        """cus: optional iterable of CU indices this context's streams are restricted to (imp_ctx_create_masked)"""
+    def __init__(self, device=0):
         lib = load_library()
         n = C.c_int(0)
         rc = lib.imp_device_count(C.byref(n))
         if rc != 0 or n.value <= 0:
             raise NativeUnavailable("no HIP device visible: the impulse_hip product path needs an MI355X (gfx950)")
         h = _vp()
-        if cus is None:
-            rc = lib.imp_ctx_create(int(device), C.byref(h))
-        else:
-            cus = sorted(set(int(c) for c in cus))
-            words = (C.c_uint32 * (max(cus) // 32 + 1))()
-            for c in cus:
-                words[c // 32] |= 1 << (c % 32)
-            rc = lib.imp_ctx_create_masked(int(device), words, len(words), C.byref(h))
+        rc = lib.imp_ctx_create(int(device), C.byref(h))
         if rc != 0:
             msg = lib.imp_last_error().decode("utf-8", "replace")
             raise NativeUnavailable(f"imp_ctx_create({device}) failed: {msg}")
@@ -257,7 +248,9 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            for plan in list(getattr(self, "_plans", ())):
+            # chains (and other composites) hold raw pointers to plans: they go before the plans they are made of
+            members = list(getattr(self, "_plans", ()))
+            for plan in sorted(members, key=lambda m: 0 if getattr(m, "_composite", False) else 1):
                 plan.close()
             self._lib.imp_ctx_destroy(self._h)
             self._h = None
@@ -555,6 +548,7 @@ class SegSet:
 class FirChain:
     """K1 -> K3 -> K4 -> K5 in stream order, no host round trip (imp_chain): recordings on the device in, equalised
     cropped responses on the device out."""
+    _composite = True
 
     def __init__(self, deconv_plan, fir_plan, B, head, fade_in, fade_out, peak_height=0.12589):
         self.ctx = deconv_plan.ctx
@@ -564,15 +558,20 @@ class FirChain:
         _check(self._lib.imp_chain_create(deconv_plan.handle, fir_plan.handle, int(B), int(head), int(fade_in),
                                           int(fade_out), float(peak_height), C.byref(h)))
         self._h = h
+        # the chain holds raw pointers into BOTH contexts: whichever closes first must close the chain before its plans
         self.ctx._plans.add(self)
+        fir_plan.ctx._plans.add(self)
 
     def execute_device(self, d_x, chan_stride_in, d_out, chan_stride_out, d_peaks=0, elem_stride_in=1):
+        if not getattr(self, "_h", None):
+            raise NativeError(-1, "the chain is closed (one of its contexts was closed)")
         _check(self._lib.imp_chain_execute_device(self._h, _vp(int(d_x)), int(chan_stride_in), int(elem_stride_in),
                                                   _vp(int(d_out)), int(chan_stride_out), _vp(int(d_peaks)) if d_peaks else None))
 
     def close(self):
         if getattr(self, "_h", None):
-            if getattr(self.ctx, "_h", None):
+            # imp_chain_destroy locks both contexts and drains both streams: both must still be alive
+            if all(getattr(p.ctx, "_h", None) for p in self._plans):
                 self._lib.imp_chain_destroy(self._h)
             self._h = None
 

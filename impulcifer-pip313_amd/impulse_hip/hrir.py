@@ -15,13 +15,6 @@ from .constants import (HEXADECAGONAL_TRACK_ORDER, IPSILATERAL_PAIRS, SPEAKER_DE
                         speaker_side, track_name)
 from .impulse_response import ImpulseResponse
 
-try:
-    from .plotting import HRIRPlotter as _PlotBase          # pragma: no cover
-except Exception:                                           # noqa: BLE001
-    class _PlotBase(object):
-        pass
-
-
 def _unit_impulse(n):
     x = np.zeros(int(n))
     x[0] = 1.0
@@ -220,7 +213,7 @@ def _rows_matrix(rows):
     return np.stack(rows)
 
 
-class HRIR(_PlotBase):
+class HRIR(object):
     def __init__(self, estimator):
         self.estimator = estimator
         self.fs = self.estimator.fs
@@ -640,6 +633,13 @@ class HRIR(_PlotBase):
 
     def resample(self, fs):
         raise NotImplementedError("resample depends on nnresample (no oracle here, parity unpinned)")
+
+    def correct_microphone_deviation(self, correction_strength=0.7, anchor="auto", plot_analysis=False, plot_dir=None):
+        """core/hrir.py:801-857 hands the HRIR to core.microphone_deviation_correction, which is outside the hot-path
+        scope: a caller that sets the flag (core/pipeline.py:631) gets a clear refusal."""
+        raise NotImplementedError(
+            "correct_microphone_deviation is outside the device path's scope (core.microphone_deviation_correction is "
+            "not part of the accelerated hot path); run the pipeline without microphone-deviation correction")
 
     # ---- alignment (small host-side correlations; 'next' tier of the scope table) ----------
     def align_ipsilateral_all(self, speaker_pairs=None, segment_ms=30):

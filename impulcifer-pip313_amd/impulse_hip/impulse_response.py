@@ -10,12 +10,6 @@ import numpy as np
 from . import _native, decay
 from .audio_io import magnitude_response
 
-try:                                            # plot mixin is optional (matplotlib-free workers)
-    from .plotting import ImpulseResponsePlotter as _PlotBase   # pragma: no cover
-except Exception:                               # noqa: BLE001
-    class _PlotBase(object):
-        pass
-
 EPSILON = 1e-20
 
 
@@ -99,7 +93,7 @@ def fir_convolve_full_batch(signals, taps):
     return out
 
 
-class ImpulseResponse(_PlotBase):
+class ImpulseResponse(object):
     def __init__(self, data, fs, recording=None):
         self.fs = fs
         self._row = None              # device_rows.Row while the samples live on the GPU (then _data is None)

@@ -158,8 +158,8 @@ class ImpulseResponseEstimator(object):
     def sweep_sequence(self, speakers, tracks):
         """Multi-track playback sequence: 2 s silence, then per speaker a sweep + 2 s silence on
         that speaker's track (reference :153-232)."""
-        if len(set(speakers)) != len(speakers):
-            raise ValueError('All speaker names in speakers must be unique.')
+        # (the reference's uniqueness loop, core/impulse_response_estimator.py:186-189, never appends to its list and so
+        # never raises: duplicate speakers pass, and so they do here)
         if tracks in SEQUENCE_TRACK_ORDERS:
             order = SEQUENCE_TRACK_ORDERS[tracks]
             n_tracks = len(order)

@@ -55,48 +55,66 @@ def broadcast_plan_spectrum(plan, ctx, dist, torch, device, src=0, via_host=Fals
     return nbytes
 
 
-def share_unique_id(rank, path, make_id=None, timeout_s=120.0):
+def _launch_tag(token):
+    import hashlib
+    return hashlib.sha256(b"impulse_hip rendezvous:" + (token if isinstance(token, bytes) else str(token).encode())).digest()[:16]
+
+
+def share_unique_id(rank, path, make_id=None, timeout_s=120.0, token=b""):
     """File rendezvous for the 128-byte RCCL unique id: rank 0 creates it (make_id()) and publishes it at ``path``
-    (written beside and renamed, so a reader never sees half of it); every other rank waits for the file.  ``path``
-    must be private to one launch (bench.py derives it from the launcher's run id and port)."""
+    (written beside and renamed, so a reader never sees half of it); every other rank waits for the file.
+
+    The file is self-validating: it starts with a 16-byte tag of ``token``, something every rank of ONE launch shares
+    and another launch does not (bench.py: run id, port and the launcher's pid), and readers skip files with another
+    tag - a rank that starts before rank 0 cannot pick up the id an earlier launch left behind (ncclCommInitRank with a
+    mismatched id has no timeout).  A file that already carries THIS launch's tag cannot be told from a stale one:
+    rank 0 refuses it loudly instead of guessing."""
     import os
     import time
+    tag = _launch_tag(token)
     if rank == 0:
         try:
-            os.remove(path)                               # a stale id left by an earlier launch must not be picked up
-        except OSError:
+            with open(path, "rb") as fh:
+                old = fh.read(16)
+            if old == tag:
+                raise FileExistsError(f"{path} already holds a communicator id with this launch's tag: the rendezvous path "
+                                      "(or the token) must be private to one launch - remove the file or pick another path")
+            os.remove(path)                               # another launch's leftover: readers skip it by its tag anyway
+        except FileNotFoundError:
             pass
         uid = make_id()
+        if len(uid) != 128:
+            raise ValueError("the unique id is 128 bytes")
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "wb") as fh:
-            fh.write(uid)
+            fh.write(tag + uid)
         os.replace(tmp, path)
         return uid
     t0 = time.monotonic()
     while True:
         try:
             with open(path, "rb") as fh:
-                uid = fh.read()
-            if len(uid) == 128:
-                return uid
+                blob = fh.read()
+            if len(blob) == 144 and blob[:16] == tag:
+                return blob[16:]
         except FileNotFoundError:
             pass
         if time.monotonic() - t0 > timeout_s:
-            raise TimeoutError(f"rank {rank}: no RCCL unique id at {path} after {timeout_s:.0f} s")
+            raise TimeoutError(f"rank {rank}: no RCCL unique id for this launch at {path} after {timeout_s:.0f} s")
         time.sleep(0.01)
 
 
-def broadcast_plan_spectrum_rccl(plan, ctx, rank, world_size, unique_id=None, rendezvous_path=None, src=0):
+def broadcast_plan_spectrum_rccl(plan, ctx, rank, world_size, unique_id=None, rendezvous_path=None, src=0, token=b""):
     """The spectrum broadcast done by libimpulse_hip itself over RCCL (imp_comm_*): no torch, no mpi4py in the data
     path.  Collective.  The 128-byte communicator id is either given (``unique_id``: made by rank 0 with
     _native.comm_unique_id() and handed round by the launcher's own control plane) or exchanged through a file
-    (``rendezvous_path``: must be private to this launch and must not exist beforehand).  Returns the bytes broadcast."""
+    (``rendezvous_path`` + ``token``, see share_unique_id).  Returns the bytes broadcast."""
     import os
     from . import _native
     if unique_id is None:
         if rendezvous_path is None:
             raise ValueError("give the communicator id or a rendezvous path")
-        unique_id = share_unique_id(rank, rendezvous_path, _native.comm_unique_id)
+        unique_id = share_unique_id(rank, rendezvous_path, _native.comm_unique_id, token=token)
     comm = _native.Comm(ctx, unique_id, rank, world_size)
     try:
         nbytes = comm.broadcast_plan_spectrum(plan, root=src)

@@ -46,15 +46,9 @@ const char* imp_version(void);
 const char* imp_last_error(void);
 int imp_device_count(int* n);
 int imp_ctx_create(int device_id, imp_ctx** out);
-/* A context whose streams (its own and the lanes of imp_plan_set_overlap) run on a SUBSET of the CUs: bit i of cu_mask =
- * CU i (mask_words 32-bit words, hipExtStreamCreateWithCUMask).  Two contexts with complementary masks share the GPU
- * without competing for CUs: the deconvolution + FIR chain keeps the latency-bound tail kernels (peak search, fused K5 -
- * workgroups that need a whole CU) on a few CUs of their own while the bandwidth-bound K1 passes fill the rest.
- * The streams of a masked context are kept for reuse by later contexts with the same (device, mask) instead of being
- * destroyed: the runtime does not recycle the hardware queue behind such a stream (creating and destroying ~470 of
- * them in one process makes hipExtStreamCreateWithCUMask hang). */
-int imp_ctx_create_masked(int device_id, const uint32_t* cu_mask, int mask_words, imp_ctx** out);
-/* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
+/* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the context's own.  The outgoing stream
+ * (owned or external) is drained first: the staging ring and the blocks imp_free has taken back are only ordered against
+ * work on the context's ONE stream, so nothing may still be in flight on the old one when later calls queue on the new. */
 int imp_ctx_set_stream(imp_ctx* ctx, void* hip_stream);
 int imp_ctx_synchronize(imp_ctx* ctx);
 void imp_ctx_destroy(imp_ctx* ctx);

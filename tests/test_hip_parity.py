@@ -2275,12 +2275,13 @@ def test_fir_chain_without_host_round_trip(gpu_ctx):
 
 
 @pytest.mark.parametrize("paired", [False, True])
-def test_fir_chain_with_lanes_tail_stream_and_cu_masks(paired):
+def test_fir_chain_with_lanes_and_tail_stream(paired):
     """The arrangement the library offers beside the one-stream chain (and bench.py measured slower):
-    the deconvolution plan on TWO lanes of a context restricted to CUs 32..255, the FIR plan on a second context restricted
-    to CUs 0..31 whose stream carries the peak search and K5 of every call (events order them; buffer sets rotate so that the
-    next call's K1 runs beside the previous call's tail).  Seven calls in flight with distinct inputs and outputs, every one
-    against the oracle; the deconvolution in mono and in pair mode."""
+    the deconvolution plan on TWO lanes of one context, the FIR plan on a second context whose stream carries the peak search
+    and K5 of every call (events order them; buffer sets rotate so that the next call's K1 runs beside the previous call's
+    tail).  Seven calls in flight with distinct inputs and outputs, every one against the oracle; the deconvolution in mono
+    and in pair mode.  The TAIL context is closed first: a chain is registered with both of its contexts, so whichever goes
+    first closes the chain before its plans (the chain keeps raw pointers into both)."""
     from impulse_hip import Context, ConvPlan
     from impulse_hip._native import FirChain
     from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
@@ -2292,7 +2293,7 @@ def test_fir_chain_with_lanes_tail_stream_and_cu_masks(paired):
     L, n, K, head, fade, B, calls = N + 2 * fs, 20000, 3000, 48, 400, 4, 7
     rng = np.random.default_rng(77)
     firs = rng.standard_normal((B, K)) * np.exp(-np.arange(K) / 200.0)
-    main, tail = Context(0, cus=range(32, 256)), Context(0, cus=range(0, 32))
+    main, tail = Context(0), Context(0)
     plan1 = ConvPlan(main, np.asarray(e.inverse_filter), L, "same", ws_channels=2 * B, fused=False, paired=paired)
     plan1.set_overlap(2)
     plan5 = ConvPlan(tail, firs, n, "full", ws_channels=B)
@@ -2328,10 +2329,12 @@ def test_fir_chain_with_lanes_tail_stream_and_cu_masks(paired):
                 s0 = min(max(want_pk - head, 0), L - n)
                 assert rel(y[c, :n + K - 1], fft_convolve(ir[s0:s0 + n] * w, firs[c], "full")) <= TIME_TOL
     finally:
+        tail.close()                                                # closes the chain, then plan5, then the context
+        assert chain._h is None and plan5._h is None and plan1._h
+        with pytest.raises(Exception):
+            chain.execute_device(bufs[0][0], L, bufs[0][1], po, bufs[0][2])
         chain.close()
         plan1.close()
-        plan5.close()
-        tail.close()
         main.close()
 
 

@@ -98,7 +98,7 @@ def test_sweep_sequence_and_split_roundtrip():
     for sp_idx, (track, s) in enumerate(zip((0, 2, 1), starts)):
         assert np.array_equal(seq[track, s:s + N], e.test_signal)
         assert not seq[track, :s].any()
-    for bad in (dict(speakers=["FL", "FL"], tracks="7.1"), dict(speakers=["FL"], tracks="9.9"),
+    for bad in (dict(speakers=["FL"], tracks="9.9"),
                 dict(speakers=["FL", "FR", "FC"], tracks="stereo"), dict(speakers=["XX"], tracks="stereo")):
         with pytest.raises(ValueError):
             e.sweep_sequence(**bad)
@@ -424,6 +424,21 @@ def test_unique_id_file_rendezvous(tmp_path):
     assert got == {1: want, 2: want, 3: want}
     with pytest.raises(TimeoutError):
         share_unique_id(1, str(tmp_path / "never"), timeout_s=0.05)
+    # a file left by ANOTHER launch (other token) is skipped by readers that start before rank 0 and replaced by rank 0
+    stale = bytes(reversed(range(128)))
+    path2 = str(tmp_path / "uid2")
+    assert share_unique_id(0, path2, lambda: stale, token="launch A") == stale
+    early = {}
+    t = threading.Thread(target=lambda: early.update(uid=share_unique_id(1, path2, timeout_s=30, token="launch B")))
+    t.start()
+    time.sleep(0.1)
+    assert not early                                            # still waiting: the stale id was not taken
+    assert share_unique_id(0, path2, lambda: want, token="launch B") == want
+    t.join(30)
+    assert early == {"uid": want}
+    # the same path AND token again: indistinguishable from a stale file, refused loudly
+    with pytest.raises(FileExistsError):
+        share_unique_id(0, path2, lambda: want, token="launch B")
 
 
 def test_line_fit_has_the_bits_of_numpy_cov():
@@ -474,3 +489,30 @@ def test_frequency_grid_is_cached_but_never_shared():
     assert np.array_equal(a, np.array(ref)) and np.array_equal(a, b) and not np.shares_memory(a, b)
     a[0] = -1.0
     assert generate_frequencies(10, 24000, 1.01)[0] == 10.0
+
+
+def test_surface_hygiene_refusals_and_reference_quirks():
+    """Out-of-scope methods refuse clearly instead of raising AttributeError (core/pipeline.py:631 calls
+    HRIR.correct_microphone_deviation); sweep_sequence follows the reference on duplicate speakers: its uniqueness loop
+    (core/impulse_response_estimator.py:186-189) never appends to the list it tests and so never raises."""
+    sys.path.insert(0, os.path.join(ROOT, "impulcifer-pip313_amd"))
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    e = ImpulseResponseEstimator(min_duration=0.2, fs=8000)
+    h = HRIR(e)
+    with pytest.raises(NotImplementedError, match="microphone"):
+        h.correct_microphone_deviation(correction_strength=0.7)
+    with pytest.raises(NotImplementedError, match="nnresample"):
+        h.resample(44100)
+    seq = e.sweep_sequence(["FL", "FL"], "7.1")                  # duplicates pass, as in the reference
+    slot = int(e.fs * 2.0 + len(e))
+    assert seq.shape == (8, int(slot * 2 + e.fs * 2.0))
+    for i in range(2):
+        start = int(slot * i + e.fs * 2.0)
+        np.testing.assert_array_equal(seq[0, start:start + len(e)], e.test_signal)
+    assert not seq[1:].any()
+    # no optional plot mixin is looked for any more
+    import impulse_hip.hrir as hrir_mod
+    import impulse_hip.impulse_response as ir_mod
+    for mod in (hrir_mod, ir_mod):
+        assert "plotting" not in open(mod.__file__).read()

@@ -42,14 +42,7 @@ def deconv_fir_leg(dev_index, est, rec, L, pitch, reps=300, lanes=3, per_meas=16
         """one chain: K1 on `k1_lanes` streams of one context, the peak search and K5 on the stream of a second context"""
 
         def __init__(self):
-            # IMPULSE_BENCH_CHAIN_TAIL_CUS = n: the tail context (peak search + fused K5: workgroups that need a whole CU) gets
-            # n CUs of its own - every (256 / n)-th CU - and the K1 context the rest
-            tail_cus = int(os.environ.get("IMPULSE_BENCH_CHAIN_TAIL_CUS", "0"))
-            if tail_cus > 0:
-                mine = set(range(0, 256, 256 // tail_cus))
-                self.ctx, self.tail = Context(dev_index, cus=set(range(256)) - mine), Context(dev_index, cus=mine)
-            else:
-                self.ctx, self.tail = Context(dev_index), Context(dev_index)
+            self.ctx, self.tail = Context(dev_index), Context(dev_index)
             self.plan1 = ConvPlan(self.ctx, np.asarray(est.inverse_filter, dtype=np.float64), L, "same",
                                   ws_channels=B * k1_lanes, paired=paired)
             self.plan1.set_overlap(k1_lanes)

@@ -45,13 +45,13 @@ def main():
         ctx.peak_index(rows)
         ctx.xcorr_argmax([r[:1440] for r in rows[:2]], [r[:1440] for r in rows[2:]])
         ctx.decay_times(rows, [0] * 4, [20000] * 4, [-80.0] * 4, [1440] * 4, 48000)
-        # round 3: pair-mode and three-launch plans, a chain with its events and buffer sets on a second (CU-masked) context
+        # round 3: pair-mode and three-launch plans, a chain with its events and buffer sets on a second context
         p = _native.ConvPlan(ctx, h[0], 60000, "same", paired=True)
         p.execute(x)
         p.close()
         p1 = _native.ConvPlan(ctx, np.concatenate([h[0], np.zeros(30000)]), 60000, "same", ws_channels=8, fused=False)
         p1.set_overlap(2)
-        tail = _native.Context(0, cus=range(0, 32))
+        tail = _native.Context(0)
         p5 = _native.ConvPlan(tail, h, 20000, "full", ws_channels=4)
         ch = _native.FirChain(p1, p5, 4, 48, 48, 200)
         d_x, d_o = ctx.malloc(x.nbytes), ctx.malloc(4 * 29600 * 4)
