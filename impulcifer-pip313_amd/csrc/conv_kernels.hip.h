@@ -1059,6 +1059,11 @@ struct FirBlockArgs {
 constexpr int kFirBlockPoints = 4 * kN2;                       // complex points of a block
 constexpr size_t kFirBlockLds = sizeof(cf) * 4 * 16 * kRowPad;
 
+// a loader whose row lengths live in device memory (slice_kernels.hip.h LoadRowsDeviceLen): the kernel then takes the
+// kept window's length and the filter of a row from the loader, and the blocks past a row's end exit at once
+template <class L, class = void> struct LoadHasDeviceLen { static constexpr bool value = false; };
+template <class L> struct LoadHasDeviceLen<L, decltype((void)L::kDeviceLen)> { static constexpr bool value = true; };
+
 template <class Load>
 __global__ __launch_bounds__(1024, 4) void fir_block_kernel(Load ld, FirBlockArgs a, Twiddles tw) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1067,6 +1072,13 @@ __global__ __launch_bounds__(1024, 4) void fir_block_kernel(Load ld, FirBlockArg
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int chan = (slot / a.blocks) * 8 + xcd, blk = a.first_block + slot % a.blocks;
   if (chan >= a.nchan) return;                                 // the grid is padded to eight channels (whole workgroup exits)
+  long long out_len = a.out_len;
+  int filt = chan;
+  if constexpr (LoadHasDeviceLen<Load>::value) {
+    out_len = ld.out_len(chan);
+    filt = ld.filter_of(chan);
+    if ((long long)blk * a.valid - a.out_start >= out_len) return;   // the grid covers the longest row the plan allows
+  }
   const int tid = threadIdx.x;
   const int pairq = __builtin_amdgcn_readfirstlane(tid >> 9);  // 0: rows (0, 2), 1: rows (1, 3)
   const int half = __builtin_amdgcn_readfirstlane((tid >> 8) & 1);
@@ -1106,7 +1118,7 @@ __global__ __launch_bounds__(1024, 4) void fir_block_kernel(Load ld, FirBlockArg
   for (int j = 0; j < 16; ++j) v[j] = lds[k1 * kN2 + t + 256 * j];
   __syncthreads();                                             // rows_core reuses the same LDS
   const __amdgpu_buffer_rsrc_t r_ab =
-      make_rsrc(a.ab + (long long)chan * a.ab_chan_stride + (long long)k1 * kN2, kN2 * sizeof(float4));
+      make_rsrc(a.ab + (long long)filt * a.ab_chan_stride + (long long)k1 * kN2, kN2 * sizeof(float4));
   // (16 waves per CU leave 128 VGPRs: four alpha/beta bins prefetched instead of the row pass's eight)
   rows_core<0, 4>(v, lds + pairq * (2 * 16 * kRowPad), half, pairq, k1, r_ab, tw, t);
 
@@ -1114,7 +1126,7 @@ __global__ __launch_bounds__(1024, 4) void fir_block_kernel(Load ld, FirBlockArg
 #pragma unroll
   for (int j = 0; j < 16; ++j) lds[k1 * kN2 + t + 256 * j] = v[j];
   __syncthreads();
-  const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out + (long long)chan * a.out_stride, (unsigned)a.out_len * 4u);
+  const __amdgpu_buffer_rsrc_t r_out = make_rsrc(a.out + (long long)chan * a.out_stride, (unsigned)out_len * 4u);
   const int o0 = blk * a.valid - a.kp - (int)a.out_start;      // output index of the block's position 0
 #pragma unroll
   for (int c = 0; c < 4; ++c) {

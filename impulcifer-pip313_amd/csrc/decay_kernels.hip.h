@@ -22,6 +22,10 @@ constexpr int kKneeMaxWindows = 2048;     // second-round windows the device sea
 constexpr int kKneeMaxFit = 128;          // points of one line fit (NumPy's pairwise mean is one block up to here)
 constexpr int kKneeRound1 = 68;           // 66 windows of 30 ms in 2 s, the noise tail, one spare
 enum { KNEE_OK = 0, KNEE_GUARD = 1, KNEE_RANGE = 2 };
+// KneeRow::why (diagnostics, tools/knee_stats.py): stage 1: 1 floor + 10 dB crossing, 2 first fit, 3 window count; stage 2: 4 knee window,
+// 5 level - 5 dB crossing, 6 tenth of the span, 7 noise range start, 8 noise range end, 9 floor + 8 dB, 10 floor + 28 dB, 11 late fit,
+// 12 new knee window, 13 knee sample
+#define KNEE_WHY(code) do { if (unsure && !r.why) r.why = (code); } while (0)
 
 struct KneeRow {
   long long src_off;     // first sample of the response in the fp32 rows
@@ -36,7 +40,7 @@ struct KneeRow {
   int tail_a, tail_b;    // round 1: the noise tail (one more mean, after the windows)
   int done;              // results are final
   int flags;             // KNEE_*
-  int pad;
+  int why;               // diagnostic: which decision put the row in its guard band first (WHY_* below), 0 = none
 };
 
 constexpr double kKneeU = 1.1102230246251565e-16;     // 2^-53
@@ -296,6 +300,7 @@ __global__ __launch_bounds__(64) void knee_stage1_kernel(KneeRow* __restrict__ r
   const double floor = lev[n];
   if (n == 0) return finish(r.n_sq, floor, r.n_sq > 1 ? r.n_sq : 1);
   const int hit = knee_first_le(lev, n, floor + 10.0, 4 * kKneeEl, unsure);
+  KNEE_WHY(1);
   int stop = hit > 0 ? hit : n;
   if (stop < 2) {
     if (n < 2) return finish(r.n_sq, floor, r.w);
@@ -308,6 +313,7 @@ __global__ __launch_bounds__(64) void knee_stage1_kernel(KneeRow* __restrict__ r
   }
   const KneeFit f = knee_fit(lev, 0, stop, 0.03, 0.0);
   if (!f.ok) unsure = true;                               // (includes the reference's NaN / |slope| < 1e-20 exits)
+  KNEE_WHY(2);
   if (unsure) {
     r.flags |= KNEE_GUARD;
     if (lane == 0) rows[b] = r;
@@ -329,6 +335,7 @@ __global__ __launch_bounds__(64) void knee_stage1_kernel(KneeRow* __restrict__ r
   }
   const double vg = 4.0 * v * ewd + 1e-12;
   if (v - __builtin_floor(v) <= vg || __builtin_ceil(v) - v <= vg) unsure = true;
+  KNEE_WHY(3);
   int n2 = (int)v;
   n2 = n2 > 1 ? n2 : 1;
   const int w2 = (int)(r.n_sq / (double)n2) > 1 ? (int)(r.n_sq / (double)n2) : 1;
@@ -367,6 +374,7 @@ __global__ __launch_bounds__(256) void knee_stage2_kernel(KneeRow* __restrict__ 
   const double gt = 4.0 * (n * wd) * ewd + 1e-15;         // |t_win[i] - host t_win[i]| for every i
   double knee_time = r.knee_time, ekt = r.ekt, floor = r.floor;
   int k_idx = knee_first_ge(n, wd, knee_time, gt + ekt, unsure);
+  KNEE_WHY(4);
   if (k_idx < 0) {
     k_idx = n - 1;
     knee_time = t_end;
@@ -375,19 +383,25 @@ __global__ __launch_bounds__(256) void knee_stage2_kernel(KneeRow* __restrict__ 
   double k_level = lev[k_idx];
   for (int it = 0; it < 5 && !unsure; ++it) {
     const int i0 = knee_first_le(lev, n, k_level - 5, 4 * kKneeEl, unsure);
+    KNEE_WHY(5);
     if (i0 < 0) break;
     const double tenth = 0.1 * total;
     const double t0 = fmax(knee_twin(i0, wd), tenth);
     // t0 > t_win[-1] can only come from the 0.1 total branch (t_win[i0] <= t_win[-1] on both sides, same expression)
     if (fabs(tenth - t_end) <= gt) unsure = true;
+    KNEE_WHY(6);
     if (tenth > t_end) break;
     const int a = grid.nearest_guarded(t0, gt, unsure);
+    KNEE_WHY(7);
     const int z = grid.nearest_guarded(fmin(t0 + knee_time, total), gt + ekt, unsure);
+    KNEE_WHY(8);
     if (a >= z) break;
     if (unsure) break;                                    // (uniform: every thread holds the same flags)
     floor = knee_db(block_fast_mean_sq(seg + a, top, (long long)(z - a)));
     int hi = knee_first_le(lev, n, floor + 8, 4 * kKneeEl, unsure);
+    KNEE_WHY(9);
     int lo = knee_first_le(lev, n, floor + 28, 4 * kKneeEl, unsure);
+    KNEE_WHY(10);
     if (hi < 0 || lo < 0) break;
     hi -= 1;
     lo = lo - 1 > 0 ? lo - 1 : 0;
@@ -399,13 +413,27 @@ __global__ __launch_bounds__(256) void knee_stage2_kernel(KneeRow* __restrict__ 
     const KneeFit f = knee_fit(lev, lo, hi, wd, ewd);
     if (!f.ok) {
       unsure = true;
+      KNEE_WHY(11);
       break;
     }
     const double raw = (floor - f.icpt) / f.slope;
     const double t_new = fmin(fmax(raw, knee_twin(0, wd)), t_end);
     const double etn = 4.0 * ((kKneeEl + f.e_icpt) / fabs(f.slope) + fabs(raw) * f.es) + gt;
-    int new_idx = knee_first_ge(n, wd, t_new, gt + etn, unsure);
-    if (new_idx < 0) new_idx = n - 1;
+    // np.clip pins t_new to t_win[0] / t_win[-1] on both sides when the raw intersection lies beyond them by more than its
+    // error bound: the answer is then the first / last window whatever the last ulps are (the comparison against the
+    // window's own time would otherwise read as "within the band" - a knee at the end of the span is the common case of a
+    // response that has not reached its floor within 2 s).  raw - etn > t_win[n - 2] + gt: every value the host may hold
+    // lies above window n - 2, clipped or not.
+    int new_idx;
+    if (n >= 2 && raw - etn > knee_twin(n - 2, wd) + gt) {
+      new_idx = n - 1;
+    } else if (raw + etn < knee_twin(0, wd) - gt) {
+      new_idx = 0;
+    } else {
+      new_idx = knee_first_ge(n, wd, t_new, gt + etn, unsure);
+      KNEE_WHY(12);
+      if (new_idx < 0) new_idx = n - 1;
+    }
     const bool same = new_idx == k_idx;
     k_idx = new_idx;
     knee_time = knee_twin(k_idx, wd);
@@ -414,6 +442,7 @@ __global__ __launch_bounds__(256) void knee_stage2_kernel(KneeRow* __restrict__ 
     k_level = lev[k_idx];
   }
   const int knee_off = grid.nearest_guarded(knee_time, ekt, unsure);
+  KNEE_WHY(13);
   r.knee = r.peak + knee_off;
   r.floor = floor;
   r.window = r.w;

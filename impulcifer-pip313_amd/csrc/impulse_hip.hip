@@ -15,6 +15,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "internal.h"
@@ -23,7 +24,8 @@
 #include "xcd_kernels.hip.h"
 #endif
 #include "ir_kernels.hip.h"
-#include "decay_kernels.hip.h"      // last: it switches fp contraction off for what follows
+#include "decay_kernels.hip.h"      // it switches fp contraction off for what follows
+#include "slice_kernels.hip.h"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -2451,6 +2453,8 @@ extern "C" int imp_rows_to_pcm_device(imp_ctx* ctx, const float* d_rows, const i
     return done(fail(IMP_ERR_HIP, "imp_rows_to_pcm_device: download failed"));
   return done(IMP_OK);
 }
+
+#include "slice_host.hip.inc"
 
 #ifdef IMP_PHASE_TRACE
 // Diagnostic build only (not in include/impulse_hip.h): copies the rows-kernel phase marks to the host.

@@ -106,3 +106,11 @@ int spectrum_alpha_beta_device(imp_ctx* ctx, const double* filters, int64_t M, i
 // length Nc = N1 * 4096 samples, all Nc bins, fp64 on the device, rounded once to fp32 into d_hs[N1][4096] in the row
 // pass's register order.
 int spectrum_pair_device(imp_ctx* ctx, const double* filter, int64_t M, int64_t Nc, int N1, cf* d_hs);
+
+// K2 of imp_slice (minphase.hip): maxima of the ear sums' magnitude responses for row lengths that live on the device
+struct SliceNorm;
+int slice_norm_create(imp_ctx* ctx, int64_t n_max, int64_t m_cap, SliceNorm** out);
+void slice_norm_destroy(SliceNorm* p);
+int64_t slice_norm_mfft(const SliceNorm* p);
+int slice_norm_run(imp_ctx* ctx, SliceNorm* p, const float* d_rows, int64_t pitch, int rows_per_meas, const long long* d_n,
+                   int64_t M, double* d_peak_db);

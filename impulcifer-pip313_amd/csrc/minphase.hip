@@ -704,6 +704,214 @@ static int magnitude_db_core(imp_ctx* ctx, const double* x, const float* d_rows,
 
 
 // ------------------------------------------------------------------------------------------------
+// K2 for imp_slice (HRIR.normalize, core/hrir.py:496-505): np.max of the magnitude response of each ear's sum, for M
+// measurements whose row length n_m is known ONLY ON THE DEVICE (crop_tails decided it there).  Same chirp-z identity as
+// above, but the chirp of each measurement is formed on the device from its n_m and the convolution length is fixed by
+// the slice's capacity (mfft >= 2 n_max - 1), so the launch sequence does not depend on any n_m: nothing is read back.
+// ------------------------------------------------------------------------------------------------
+struct SliceNorm {
+  int n_max = 0, mfft = 0, half_max = 0;
+  int64_t m_cap = 0;
+  std::vector<int> fac;
+  cdbl* roots = nullptr;
+  double* x = nullptr;       // [2 m_cap][n_max]   ear sums
+  cdbl* chirp = nullptr;     // [m_cap][n_max]
+  cdbl* bhat = nullptr;      // [m_cap][mfft]      transform of the conjugate chirp
+  cdbl* bwork = nullptr;
+  cdbl *a = nullptr, *b = nullptr;     // [2 m_cap][mfft]
+  double* out = nullptr;     // [2 m_cap][half_max]
+};
+
+namespace {
+
+// x[2 m + ear][i] = sum over the pairs q of rows[(m R + 2 q + ear) pitch + i], i < n_m, added in row order in fp64
+// (np.sum(np.vstack(...), axis=0) of core/hrir.py:496-503; the rows of a measurement are equally long after crop_tails)
+__global__ __launch_bounds__(256) void sn_sum_kernel(const float* __restrict__ rows, long long pitch, int rows_per_meas,
+                                                     const long long* __restrict__ n_of, double* __restrict__ x, int n_max) {
+  const int g = blockIdx.y, m = g >> 1, ear = g & 1;
+  long long n = n_of[m];
+  n = n < n_max ? n : n_max;
+  const float* base = rows + ((long long)m * rows_per_meas + ear) * pitch;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int q = 0; 2 * q < rows_per_meas; ++q) acc += (double)base[(long long)(2 * q) * pitch + i];
+    x[(long long)g * n_max + i] = acc;
+  }
+}
+
+// chirp[m][j] = exp(-i pi j^2 / n_m) (phase reduced exactly: j^2 mod 2 n_m), j < n_m; bb[m][j] = conj chirp[|j|] placed
+// circularly at j mod mfft, zero elsewhere
+__global__ __launch_bounds__(256) void sn_chirp_kernel(const long long* __restrict__ n_of, cdbl* __restrict__ chirp,
+                                                       cdbl* __restrict__ bb, int n_max, int mfft) {
+  const int m = blockIdx.y;
+  long long n = n_of[m];
+  n = n < n_max ? n : n_max;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= mfft) return;
+  auto c_at = [&](long long k) {
+    const double ang = -M_PI * (double)((k * k) % (2 * n)) / (double)n;
+    double sn, cs;
+    sincos(ang, &sn, &cs);
+    return make_double2(cs, sn);
+  };
+  cdbl v = make_double2(0.0, 0.0);
+  if (j < n) {
+    const cdbl c = c_at(j);
+    chirp[(long long)m * n_max + j] = c;
+    v = make_double2(c.x, -c.y);
+  } else if (j > 0 && mfft - j < n) {
+    const cdbl c = c_at(mfft - j);
+    v = make_double2(c.x, -c.y);
+  }
+  bb[(long long)m * mfft + j] = v;
+}
+
+__global__ __launch_bounds__(256) void sn_pre_kernel(const double* __restrict__ x, const cdbl* __restrict__ chirp,
+                                                     const long long* __restrict__ n_of, cdbl* __restrict__ a, int n_max,
+                                                     int mfft) {
+  const int g = blockIdx.y, m = g >> 1;
+  long long n = n_of[m];
+  n = n < n_max ? n : n_max;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= mfft) return;
+  cdbl v = make_double2(0.0, 0.0);
+  if (j < n) {
+    const double xv = x[(long long)g * n_max + j];
+    const cdbl c = chirp[(long long)m * n_max + j];
+    v = make_double2(xv * c.x, xv * c.y);
+  }
+  a[(long long)g * mfft + j] = v;
+}
+
+__global__ __launch_bounds__(256) void sn_mul_kernel(cdbl* __restrict__ a, const cdbl* __restrict__ bhat, int mfft) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= mfft) return;
+  cdbl* p = a + (long long)blockIdx.y * mfft + j;
+  *p = zmul(*p, bhat[(long long)(blockIdx.y >> 1) * mfft + j]);
+}
+
+__global__ __launch_bounds__(256) void sn_post_kernel(const cdbl* __restrict__ conv, const cdbl* __restrict__ chirp,
+                                                      const long long* __restrict__ n_of, double* __restrict__ out, int n_max,
+                                                      int mfft, int half_max) {
+  const int g = blockIdx.y, m = g >> 1;
+  long long n = n_of[m];
+  n = n < n_max ? n : n_max;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= (n + 1) / 2) return;
+  const cdbl v = zmul(conv[(long long)g * mfft + k], chirp[(long long)m * n_max + k]);
+  out[(long long)g * half_max + k] = 20.0 * log10(hypot(v.x, v.y) / (double)mfft);
+}
+
+// np.max of out[g][0 : ceil(n_m / 2)] (NaN if the row holds one; -inf for an empty row)
+__global__ __launch_bounds__(1024) void sn_rows_max_kernel(const double* __restrict__ out, const long long* __restrict__ n_of,
+                                                           int n_max, int half_max, double* __restrict__ peak) {
+  const int g = blockIdx.x;
+  long long n = n_of[g >> 1];
+  n = n < n_max ? n : n_max;
+  const int half = (int)((n + 1) / 2);
+  const double* row = out + (long long)g * half_max;
+  double m = -INFINITY;
+  bool nan = false;
+  for (int k0 = 0; k0 < half; k0 += 8 * 1024) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u * 1024 + (int)threadIdx.x;
+      v[u] = k < half ? row[k] : -INFINITY;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      nan = nan || v[u] != v[u];
+      m = v[u] > m ? v[u] : m;
+    }
+  }
+  __shared__ double s_m[1024];
+  __shared__ int s_nan;
+  if (threadIdx.x == 0) s_nan = 0;
+  __syncthreads();
+  s_m[threadIdx.x] = m;
+  if (nan) s_nan = 1;
+  __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) s_m[threadIdx.x] = s_m[threadIdx.x] > s_m[threadIdx.x + st] ? s_m[threadIdx.x] : s_m[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) peak[g] = s_nan ? __longlong_as_double(0x7ff8000000000000ll) : s_m[0];
+}
+
+}  // namespace
+
+void slice_norm_destroy(SliceNorm* p) {
+  if (!p) return;
+  (void)hipFree(p->roots); (void)hipFree(p->x); (void)hipFree(p->chirp); (void)hipFree(p->bhat); (void)hipFree(p->bwork);
+  (void)hipFree(p->a); (void)hipFree(p->b); (void)hipFree(p->out);
+  delete p;
+}
+
+int slice_norm_create(imp_ctx* ctx, int64_t n_max, int64_t m_cap, SliceNorm** out) {
+  *out = nullptr;
+  if (n_max < 1 || n_max > (1 << 22) || m_cap < 1) return fail(IMP_ERR_INVALID, "slice normalisation: bad n_max / capacity");
+  SliceNorm* p = new (std::nothrow) SliceNorm();
+  if (!p) return fail(IMP_ERR_ALLOC, "out of host memory");
+  p->n_max = (int)n_max;
+  p->half_max = (int)((n_max + 1) / 2);
+  p->m_cap = m_cap;
+  int mf = 4;
+  while (mf < 2 * (int)n_max - 1) mf <<= 1;
+  p->mfft = mf;
+  p->fac = factorise(mf);
+  const size_t M = (size_t)m_cap;
+  bool ok = upload_roots(&p->roots, mf, ctx->stream) == IMP_OK &&
+            hipMalloc((void**)&p->x, 2 * M * (size_t)n_max * sizeof(double)) == hipSuccess &&
+            hipMalloc((void**)&p->chirp, M * (size_t)n_max * sizeof(cdbl)) == hipSuccess &&
+            hipMalloc((void**)&p->bhat, M * (size_t)mf * sizeof(cdbl)) == hipSuccess &&
+            hipMalloc((void**)&p->bwork, M * (size_t)mf * sizeof(cdbl)) == hipSuccess &&
+            hipMalloc((void**)&p->a, 2 * M * (size_t)mf * sizeof(cdbl)) == hipSuccess &&
+            hipMalloc((void**)&p->b, 2 * M * (size_t)mf * sizeof(cdbl)) == hipSuccess &&
+            hipMalloc((void**)&p->out, 2 * M * (size_t)p->half_max * sizeof(double)) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    slice_norm_destroy(p);
+    return fail(IMP_ERR_ALLOC, "slice normalisation: device allocation failed (n_max %lld, %lld measurements)", (long long)n_max,
+                (long long)m_cap);
+  }
+  *out = p;
+  return IMP_OK;
+}
+
+int64_t slice_norm_mfft(const SliceNorm* p) { return p->mfft; }
+
+// d_rows: the equalised rows [M R][pitch]; d_n[m] = their length; d_peak_db[2 m + ear] receives the maxima.  Asynchronous
+// on the context's stream.
+int slice_norm_run(imp_ctx* ctx, SliceNorm* p, const float* d_rows, int64_t pitch, int rows_per_meas, const long long* d_n,
+                   int64_t M, double* d_peak_db) {
+  if (M < 1 || M > p->m_cap) return fail(IMP_ERR_INVALID, "slice normalisation: %lld measurements exceed the capacity %lld",
+                                         (long long)M, (long long)p->m_cap);
+  hipStream_t s = ctx->stream;
+  const int mf = p->mfft, nm = p->n_max;
+  auto grid = [&](int count, int64_t rows) { return dim3((unsigned)((count + 255) / 256), (unsigned)rows); };
+  hipLaunchKernelGGL(sn_sum_kernel, dim3((unsigned)std::min<int>(256, (nm + 255) / 256), (unsigned)(2 * M)), dim3(256), 0, s, d_rows,
+                     (long long)pitch, rows_per_meas, d_n, p->x, nm);
+  hipLaunchKernelGGL(sn_chirp_kernel, grid(mf, M), dim3(256), 0, s, d_n, p->chirp, p->bhat, nm, mf);
+  HIP_TRY(hipGetLastError());
+  int rc;
+  cdbl *cur = p->bhat, *oth = p->bwork;
+  if ((rc = run_fft(ctx, p->fac, p->roots, mf, M, -1, &cur, &oth))) return rc;
+  const cdbl* bhat = cur;                                  // (either buffer: both belong to the plan)
+  hipLaunchKernelGGL(sn_pre_kernel, grid(mf, 2 * M), dim3(256), 0, s, p->x, p->chirp, d_n, p->a, nm, mf);
+  HIP_TRY(hipGetLastError());
+  cdbl *c2 = p->a, *o2 = p->b;
+  if ((rc = run_fft(ctx, p->fac, p->roots, mf, 2 * M, -1, &c2, &o2))) return rc;
+  hipLaunchKernelGGL(sn_mul_kernel, grid(mf, 2 * M), dim3(256), 0, s, c2, bhat, mf);
+  HIP_TRY(hipGetLastError());
+  if ((rc = run_fft(ctx, p->fac, p->roots, mf, 2 * M, +1, &c2, &o2))) return rc;
+  hipLaunchKernelGGL(sn_post_kernel, grid(p->half_max, 2 * M), dim3(256), 0, s, c2, p->chirp, d_n, p->out, nm, mf, p->half_max);
+  hipLaunchKernelGGL(sn_rows_max_kernel, dim3((unsigned)(2 * M)), dim3(1024), 0, s, p->out, d_n, nm, p->half_max, d_peak_db);
+  HIP_TRY(hipGetLastError());
+  return IMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Filter spectra of convolution plans (alpha/beta planes), fp64 on the device.
 // The same arithmetic as host_rfft + host_alpha_beta in impulse_hip.hip (kept there as the debug /
 // cross-check path): one packed Nc-point complex FFT per filter, real-FFT unpack, then

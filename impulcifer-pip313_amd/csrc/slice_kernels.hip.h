@@ -1,0 +1,237 @@
+// imp_slice: the reference's stage sequence of a measurement (core/pipeline.py:565-573, 585-601, 647-692, 725-735) with
+// every decision taken where the data is.  The kernels here are the glue between the stages that already run on the device
+// (K1, K3, K7c, K4, K5, K2): each reads the previous stage's results from device memory and leaves the row tables and
+// window parameters of the next one there, so a call of M measurements is one stream-ordered sequence of launches and
+// the scalars (peaks, crop indices, knees, lengths, gains, flags) come back once, at the end.
+//   crop_heads   core/hrir.py:548-612   earlier ear's first peak - (speaker delay + head) per pair, Hann fade-in
+//   crop_tails   core/hrir.py:614-653   min(shortest row, next_fast_len(latest Lundeby knee)), Hann fade-out
+//   normalize    core/hrir.py:457-546   -max(spectrum of the ear sums) + peak_target, 10^(gain / 20) on every row
+// Included after decay_kernels.hip.h: fp contraction is off, the integer and fp64 scalar work below is plain IEEE.
+#pragma once
+
+namespace imp {
+
+// flags of a measurement (include/impulse_hip.h IMP_SLICE_*)
+enum {
+  SLICE_KNEE_GUARD = 1,      // a row's knee search has a decision inside its guard band: the host search decides
+  SLICE_KNEE_RANGE = 2,      // a row's knee search is outside the device path's limits
+  SLICE_KEEP_CAP = 4,        // crop_tails' length exceeds the capacity the slice was made for
+  SLICE_FADE = 8,            // fade-out longer than the cropped response (the reference raises ValueError)
+  SLICE_GAIN_GUARD = 16,     // 10^(gain / 20) is within the guard band of an fp32 rounding boundary
+  SLICE_GAIN_NONFINITE = 32, // all-zero or NaN spectra
+  SLICE_SHORT = 64,          // a row shorter than the head fade (the reference skips the fade for that pair)
+};
+
+struct SliceRowOut {         // per row, returned to the host at the end (imp_slice_row_result)
+  long long peak;            // ImpulseResponse.peak_index of the deconvolved column
+  long long cut;             // samples cropped from its head
+  long long len;             // length after crop_heads
+  long long knee;            // decay_params()[1] of the cropped row
+  int knee_flags;            // KNEE_*
+  int knee_why;              // diagnostic: KneeRow::why
+};
+
+struct SliceMeasOut {        // per measurement (imp_slice_result)
+  long long keep;            // crop_tails' return value
+  long long out_len;         // keep + taps - 1
+  double peak_db[2];         // np.max of the left / right ear sum's magnitude response
+  double gain_db;            // what normalize returns
+  float gain;                // 10^(gain_db / 20) as applied (fp32 rows)
+  int flags;                 // SLICE_*
+};
+
+// ---- crop_heads -------------------------------------------------------------------------------------------------------
+// One thread per ear pair.  Rows 2q / 2q + 1 of d_ir are the left / right ear (pitch_ir apart, row_len samples).
+__global__ __launch_bounds__(64) void slice_crop_heads_kernel(const RowPeak* __restrict__ res, const long long* __restrict__ delay,
+                                                              int pairs_per_meas, int n_pairs_total, long long pitch_ir,
+                                                              long long row_len, long long head,
+                                                              int64_t* __restrict__ off2, int64_t* __restrict__ len2,
+                                                              int64_t* __restrict__ fade_len, WindowParams* __restrict__ fade_par,
+                                                              SliceRowOut* __restrict__ rows, int* __restrict__ meas_flags) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_pairs_total) return;
+  long long pk[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const RowPeak rp = res[2 * q + s];
+    if (row_len == 0 || !(__uint_as_float(rp.maxabs_bits) >= 1e-20f)) pk[s] = 0;            // EPSILON rule
+    else pk[s] = (long long)(rp.first_peak != ~0ull ? rp.first_peak : rp.first_max);     // argmax fallback
+  }
+  const long long first = pk[0] < pk[1] ? pk[0] : pk[1];       // (equal peaks take the reference's else branch: same index)
+  long long at = first - delay[q % pairs_per_meas];
+  if (at < 0) at = 0;
+  const long long cut = at < row_len ? at : row_len;
+  const long long n = row_len - cut;
+  const bool fade = n >= head && head > 0;
+  if (!fade && head > 0) atomicOr(&meas_flags[q / pairs_per_meas], SLICE_SHORT);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int b = 2 * q + s;
+    off2[b] = (long long)b * pitch_ir + cut;
+    len2[b] = n;
+    fade_len[b] = fade ? head : 0;
+    WindowParams p;
+    p.gain = 1.0f;
+    p.fade_in = fade ? head : 0;
+    p.fade_out = 0;
+    p.decay_start = 0;
+    p.decay_half = -1;
+    p.decay_knee = 0;
+    p.decay_level_db = 0.f;
+    fade_par[b] = p;
+    SliceRowOut r;
+    r.peak = pk[s];
+    r.cut = cut;
+    r.len = n;
+    r.knee = 0;
+    r.knee_flags = 0;
+    r.knee_why = 0;
+    rows[b] = r;
+  }
+}
+
+// scipy.fftpack.next_fast_len: the smallest 2^a 3^b 5^c >= n (n <= 6: n itself)
+__device__ inline long long slice_next_fast_len(long long n) {
+  if (n <= 6) return n;
+  long long best = 1;
+  while (best < n) best <<= 1;
+  for (long long p5 = 1; p5 < best; p5 *= 5)
+    for (long long p35 = p5; p35 < best; p35 *= 3) {
+      long long q = p35;
+      while (q < n) q <<= 1;
+      if (q < best) best = q;
+    }
+  return best;
+}
+
+// ---- crop_tails: the common length of a measurement and the tables of the compaction + fade-out launch ----------------
+// One thread per measurement.
+__global__ __launch_bounds__(64) void slice_keep_kernel(const KneeRow* __restrict__ knee, const int64_t* __restrict__ off2,
+                                                        const int64_t* __restrict__ len2, int rows_per_meas, int n_meas,
+                                                        long long fade_out, long long keep_cap, long long pitch_crop,
+                                                        long long taps, int64_t* __restrict__ crop_dst_off,
+                                                        int64_t* __restrict__ crop_len, WindowParams* __restrict__ crop_par,
+                                                        long long* __restrict__ keep_out, long long* __restrict__ out_len,
+                                                        SliceRowOut* __restrict__ rows, SliceMeasOut* __restrict__ meas,
+                                                        int* __restrict__ meas_flags) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_meas) return;
+  int flags = meas_flags[m];
+  long long knee_max = 0, len_min = 0x7fffffffffffffffll;
+  for (int r = 0; r < rows_per_meas; ++r) {
+    const int b = m * rows_per_meas + r;
+    const KneeRow k = knee[b];
+    const int kf = k.done ? k.flags : (k.flags ? k.flags : (int)KNEE_GUARD);
+    if (kf & KNEE_GUARD) flags |= SLICE_KNEE_GUARD;
+    if (kf & KNEE_RANGE) flags |= SLICE_KNEE_RANGE;
+    rows[b].knee = k.knee;
+    rows[b].knee_flags = kf;
+    rows[b].knee_why = k.why;
+    knee_max = k.knee > knee_max ? k.knee : knee_max;
+    len_min = len2[b] < len_min ? len2[b] : len_min;
+  }
+  long long keep = slice_next_fast_len(knee_max);
+  if (len_min < keep) keep = len_min;
+  if (keep < 0) keep = 0;
+  if (fade_out > keep) flags |= SLICE_FADE;
+  if (keep > keep_cap) {
+    flags |= SLICE_KEEP_CAP;
+    keep = keep_cap;                                     // (the outputs of a flagged measurement are not used)
+  }
+  const long long fo = fade_out > keep ? keep : fade_out;
+  for (int r = 0; r < rows_per_meas; ++r) {
+    const int b = m * rows_per_meas + r;
+    crop_dst_off[b] = (long long)b * pitch_crop;
+    crop_len[b] = keep;
+    WindowParams p;
+    p.gain = 1.0f;
+    p.fade_in = 0;
+    p.fade_out = fo;
+    p.decay_start = 0;
+    p.decay_half = -1;
+    p.decay_knee = 0;
+    p.decay_level_db = 0.f;
+    crop_par[b] = p;
+  }
+  keep_out[m] = keep;
+  out_len[m] = keep > 0 ? keep + taps - 1 : 0;
+  meas[m].keep = keep;
+  meas[m].out_len = keep > 0 ? keep + taps - 1 : 0;
+  meas_flags[m] = flags;
+}
+
+// ---- normalize: gain from the two ear maxima, tables of the in-place gain launch ---------------------------------------
+// One thread per measurement.  gain = np.max([m_l, m_r]) * -1 + peak_target; rows *= 10 ** (gain / 20) (fp32 rows: the
+// gain is rounded to fp32 once).  The device's pow is not Python's: a value whose fp32 rounding depends on the last few
+// ulp of the fp64 result, or on the ~1e-12 dB by which two correct transforms of the spectrum differ, is flagged and the
+// host path decides that measurement.
+__global__ __launch_bounds__(64) void slice_gain_kernel(const double* __restrict__ peak_db /*[n_meas][2]*/,
+                                                        const long long* __restrict__ out_len, int rows_per_meas, int n_meas,
+                                                        double peak_target, double guard_rel, long long out_pitch,
+                                                        int64_t* __restrict__ g_off, int64_t* __restrict__ g_len,
+                                                        WindowParams* __restrict__ g_par, SliceMeasOut* __restrict__ meas,
+                                                        int* __restrict__ meas_flags) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_meas) return;
+  int flags = meas_flags[m];
+  const double ml = peak_db[2 * m], mr = peak_db[2 * m + 1];
+  const double top = (ml != ml || mr != mr) ? __longlong_as_double(0x7ff8000000000000ll) : (ml > mr ? ml : mr);   // np.max
+  const double gain_db = top * -1 + peak_target;
+  const double g = pow(10.0, gain_db / 20);
+  float g32 = (float)g;
+  if (!(g == g) || !(fabs(g) < 1e300) || !(fabs(gain_db) < 1e300) || out_len[m] <= 0) {
+    flags |= SLICE_GAIN_NONFINITE;
+    g32 = 1.0f;
+  } else if ((float)(g * (1.0 + guard_rel)) != g32 || (float)(g * (1.0 - guard_rel)) != g32) {
+    flags |= SLICE_GAIN_GUARD;
+  }
+  for (int r = 0; r < rows_per_meas; ++r) {
+    const int b = m * rows_per_meas + r;
+    g_off[b] = (long long)b * out_pitch;
+    g_len[b] = out_len[m];
+    WindowParams p;
+    p.gain = g32;
+    p.fade_in = 0;
+    p.fade_out = 0;
+    p.decay_start = 0;
+    p.decay_half = -1;
+    p.decay_knee = 0;
+    p.decay_level_db = 0.f;
+    g_par[b] = p;
+  }
+  meas[m].peak_db[0] = ml;
+  meas[m].peak_db[1] = mr;
+  meas[m].gain_db = gain_db;
+  meas[m].gain = g32;
+  meas[m].flags = flags;
+  meas_flags[m] = flags;
+}
+
+// K5's view of the cropped rows: row b belongs to measurement b / rows_per_meas, whose length crop_tails decided on the
+// device; its FIR is filter b % rows_per_meas.  fir_block_kernel reads lengths and the block count through these hooks.
+struct LoadRowsDeviceLen {
+  static constexpr bool kDeviceLen = true;
+  const float* __restrict__ base;
+  long long chan_stride;
+  const long long* __restrict__ len_of;     // [measurements]
+  int rows_per_meas;
+  long long taps;
+  __host__ __device__ LoadRowsDeviceLen shifted(long long, long long) const { return *this; }
+  struct Row {
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ cf finish(cf v, int) const { return v; }
+    __device__ __forceinline__ cf pair_at(int s) const { return bload_cf<kStreamAux>(r, (unsigned)s * 4u, 0u); }
+  };
+  __device__ __forceinline__ long long row_len(int b) const { return len_of[b / rows_per_meas]; }
+  __device__ __forceinline__ long long out_len(int b) const {
+    const long long n = row_len(b);
+    return n > 0 ? n + taps - 1 : 0;
+  }
+  __device__ __forceinline__ int filter_of(int b) const { return b % rows_per_meas; }
+  __device__ __forceinline__ Row open(int b) const {
+    const long long n = row_len(b);
+    return Row{make_rsrc(base + (long long)b * chan_stride, (unsigned)(n > 0 ? n : 0) * 4u)};
+  }
+};
+
+}  // namespace imp

@@ -43,6 +43,38 @@ class WindowParams(C.Structure):
     ]
 
 
+class SliceGeometry(C.Structure):
+    _fields_ = [
+        ("n_pairs", C.c_int64),
+        ("elem_stride", C.c_int64),
+        ("bits", C.c_int),
+        ("pair_offset", C.POINTER(C.c_int64)),
+        ("delay", C.POINTER(C.c_int64)),
+        ("head", C.c_int64),
+        ("fade_out", C.c_int64),
+        ("taps", C.c_int64),
+        ("keep_cap", C.c_int64),
+        ("fs", C.c_double),
+        ("peak_height", C.c_double),
+        ("peak_target_db", C.c_double),
+        ("gain_guard_rel", C.c_double),
+    ]
+
+
+class SliceRowResult(C.Structure):
+    _fields_ = [("peak", C.c_int64), ("cut", C.c_int64), ("len", C.c_int64), ("knee", C.c_int64),
+                ("knee_flags", C.c_int32), ("knee_why", C.c_int32)]
+
+
+class SliceResult(C.Structure):
+    _fields_ = [("keep", C.c_int64), ("out_len", C.c_int64), ("peak_db", C.c_double * 2), ("gain_db", C.c_double),
+                ("gain", C.c_float), ("flags", C.c_int32)]
+
+
+SLICE_KNEE_GUARD, SLICE_KNEE_RANGE, SLICE_KEEP_CAP, SLICE_FADE, SLICE_GAIN_GUARD, SLICE_GAIN_NONFINITE, SLICE_SHORT = (
+    1, 2, 4, 8, 16, 32, 64)
+SLICE_REDO = SLICE_KNEE_GUARD | SLICE_KNEE_RANGE | SLICE_KEEP_CAP | SLICE_FADE | SLICE_GAIN_GUARD | SLICE_GAIN_NONFINITE
+
 _vp = C.c_void_p
 _i64 = C.c_int64
 _pf = C.POINTER(C.c_float)
@@ -83,6 +115,12 @@ SIGNATURES = {
     "imp_chain_create": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, C.c_double, C.POINTER(_vp)]),
     "imp_chain_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp]),
     "imp_chain_destroy": (None, [_vp]),
+    "imp_slice_create": (C.c_int, [_vp, C.POINTER(SliceGeometry), _i64, C.POINTER(_vp)]),
+    "imp_slice_destroy": (None, [_vp]),
+    "imp_slice_info": (C.c_int, [_vp, _pi64, _pi64, _pi64, _pi64]),
+    "imp_slice_set_firs": (C.c_int, [_vp, _pd, _i64]),
+    "imp_slice_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64]),
+    "imp_slice_results": (C.c_int, [_vp, C.POINTER(SliceRowResult), C.POINTER(SliceResult)]),
     "imp_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "imp_comm_create": (C.c_int, [_vp, C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.POINTER(_vp)]),
     "imp_comm_destroy": (None, [_vp]),
@@ -582,6 +620,67 @@ class FirChain:
             pass
 
 
+class Slice:
+    """imp_slice: ingest -> crop_heads -> crop_tails -> equalize -> normalize for M measurements per call, device resident,
+    no host readback between the stages (include/impulse_hip.h).  Rows of flagged measurements (results()[1].flags &
+    SLICE_REDO) are not valid: the caller runs those through the staged path."""
+    _composite = True
+
+    def __init__(self, deconv_plan, pair_offsets, delays, elem_stride, bits, head, fade_out, taps, keep_cap, fs,
+                 peak_target=-0.1, max_measurements=1, peak_height=0.12589, gain_guard_rel=0.0):
+        self.ctx = deconv_plan.ctx
+        self._lib = self.ctx._lib
+        self._plan = deconv_plan                          # keep it alive
+        po = np.ascontiguousarray(pair_offsets, dtype=np.int64)
+        dl = np.ascontiguousarray(delays, dtype=np.int64)
+        if po.shape != dl.shape or po.ndim != 1 or len(po) < 1:
+            raise ValueError("pair_offsets and delays: one entry per ear pair")
+        g = SliceGeometry(len(po), int(elem_stride), int(bits), _ptr_i64(po), _ptr_i64(dl), int(head), int(fade_out), int(taps),
+                          int(keep_cap), float(fs), float(peak_height), float(peak_target), float(gain_guard_rel))
+        h = _vp()
+        _check(self._lib.imp_slice_create(deconv_plan.handle, C.byref(g), int(max_measurements), C.byref(h)))
+        self._h = h
+        self.ctx._plans.add(self)
+        r, m, o, f = _i64(), _i64(), _i64(), _i64()
+        _check(self._lib.imp_slice_info(h, C.byref(r), C.byref(m), C.byref(o), C.byref(f)))
+        self.rows, self.max_measurements, self.out_len_max, self.norm_fft_len = r.value, m.value, o.value, f.value
+        self.taps, self.keep_cap = int(taps), int(keep_cap)
+        self.last_M = 0
+
+    def set_firs(self, firs):
+        f = np.ascontiguousarray(firs, dtype=np.float64)
+        if f.shape != (self.rows, self.taps):
+            raise ValueError(f"FIRs must be [{self.rows}, {self.taps}], got {f.shape}")
+        _check(self._lib.imp_slice_set_firs(self._h, f.ctypes.data_as(_pd), self.taps))
+
+    def execute_device(self, d_rec, rec_stride, M, d_out, out_pitch):
+        _check(self._lib.imp_slice_execute_device(self._h, _vp(int(d_rec)), int(rec_stride), int(M), _vp(int(d_out)),
+                                                  int(out_pitch)))
+        self.last_M = int(M)
+
+    def results(self):
+        """(rows, measurements) of the last call as structured NumPy arrays; waits for the call."""
+        M = self.last_M
+        rows = (SliceRowResult * max(M * self.rows, 1))()
+        meas = (SliceResult * max(M, 1))()
+        _check(self._lib.imp_slice_results(self._h, rows, meas))
+        r = np.ctypeslib.as_array(rows)[:M * self.rows].copy() if M else np.zeros(0)
+        m = np.ctypeslib.as_array(meas)[:M].copy() if M else np.zeros(0)
+        return r, m
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if getattr(self.ctx, "_h", None):
+                self._lib.imp_slice_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 def comm_probe():
     """True if librccl loads with every entry point the library uses (no communicator is made)."""
     return load_library().imp_comm_probe() == 0
@@ -870,14 +969,23 @@ class ConvPlan:
         starts = [int(v) for v in column_starts]
         if any(s0 < 0 or s0 + self.L > n_frames for s0 in starts):
             raise ValueError("column outside the recording")
+        if self.paired and tracks == 2:
+            # a binaural recording: the two ears of a column are ONE complex signal, a stereo frame is one load (core/hrir.py:
+            # 326-341: track 0 = left ear, track 1 = right ear); columns in runs of equal spacing, one launch group per run
+            j = 0
+            while j < len(starts):
+                k = j + 1
+                step = starts[k] - starts[j] if k < len(starts) else 0
+                while step > 0 and k < len(starts) and starts[k] - starts[k - 1] == step:
+                    k += 1
+                if step <= 0:
+                    k = j + 1
+                self.execute_device_pairs(d_in + starts[j] * tracks * frames.itemsize, bits, k - j, step * tracks, 1, tracks,
+                                          d_out + 2 * j * pitch * 4, pitch)
+                j = k
+            return
         step = starts[1] - starts[0] if len(starts) > 1 else 0
         uniform = len(starts) > 1 and step > 0 and all(b - a == step for a, b in zip(starts, starts[1:]))
-        if self.paired and tracks == 2 and (uniform or len(starts) == 1):
-            # a binaural recording: the two ears of a column are ONE complex signal, a stereo frame is one load, and all
-            # columns go in one launch group (core/hrir.py:326-341: track 0 = left ear, track 1 = right ear)
-            self.execute_device_pairs(d_in + starts[0] * tracks * frames.itemsize, bits, len(starts), step * tracks, 1,
-                                      tracks, d_out, pitch)
-            return
         if uniform:
             for t in range(tracks):
                 self.execute_device_pcm(d_in + (starts[0] * tracks + t) * frames.itemsize, bits, len(starts),

@@ -180,7 +180,8 @@ def ingest_pcm_frames(estimator, expected_fs, fs, frames, speakers, side=None, s
     from .device_rows import DeviceBlock, Row
     for length, group in by_len.items():
         starts = sorted({origin + a for (_, _, _, a, _) in group})
-        plan = estimator._plan(length)
+        # a binaural recording (two tracks = the two ears of every column) takes the pair-mode plan
+        plan = estimator._plan(length, paired=(side is None and tracks == 2))
         # the deconvolved columns stay on the device as rows of one block (device_rows.py); `recording`, the raw
         # column the reference keeps beside every response (core/hrir.py:336-341), is cut from the PCM block on demand
         pitch = (plan.out_len + 63) // 64 * 64

@@ -116,14 +116,22 @@ class ImpulseResponseEstimator(object):
         return inv / scale
 
     # -- hot path (device) --------------------------------------------------------------------
-    def _plan(self, L):
+    def _plan(self, L, paired=False):
+        """The deconvolution plan for columns of L samples on the calling thread's context.  paired: the pair-mode plan
+        (two ears of a speaker as one complex signal, core/hrir.py:326-341 hands estimate() exactly such pairs) where the
+        lengths allow it, else the one-channel-per-transform plan - a pair plan has no even/odd unpack, whose rounding
+        error the un-cropped column shows near Nyquist."""
         L = int(L)
+        ctx = _native.default_context()
+        key = (L, bool(paired), id(ctx))
         with self._plan_lock:
-            plan = self._plans.get(L)
+            plan = self._plans.get(key)
+            if plan is not None and not plan._h:           # its context was closed
+                plan = None
             if plan is None:
-                ctx = _native.default_context()
-                plan = _native.ConvPlan(ctx, np.asarray(self.inverse_filter, dtype=np.float64), L, "same")
-                self._plans[L] = plan
+                plan = _native.ConvPlan(ctx, np.asarray(self.inverse_filter, dtype=np.float64), L, "same",
+                                        paired="auto" if paired else False)
+                self._plans[key] = plan
             return plan
 
     def estimate(self, recording):

@@ -50,14 +50,16 @@ def _expected_tasks(recordings):
 
 
 def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, decay=None, peak_target=-0.1,
-              hp_left=None, hp_right=None, eq_left=None, eq_right=None, stages=None):
+              hp_left=None, hp_right=None, eq_left=None, eq_right=None, stages=None, firs=None):
     """recordings: list of (path_or_(fs, array), speakers[, side]) measurement files.
     Returns the HRIR after: ingest (batched GPU deconvolution) -> crop_heads -> crop_tails ->
     per-channel minimum-phase FIR (batched GPU design) + equalize -> optional decay adjustment ->
     normalize.  ``stages`` (dict) receives copies of the intermediate channel data when given.
     The FIR design is a function of the curves and the target alone, so it is started first, on a worker thread with a
     context (stream) of its own, and collected where the reference's stage order needs it: same FIRs, same stage
-    results, the design's 0.46 ms hidden behind the upload of the recording."""
+    results, the design's 0.46 ms hidden behind the upload of the recording.
+    ``firs`` ({(speaker, side): taps}): FIRs already designed for the job (the curves are per job, not per measurement);
+    no design runs then."""
     hrir = HRIR(estimator)
     fs = estimator.fs
     common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
@@ -65,7 +67,7 @@ def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, deca
         target = FrequencyResponse(name="target", frequency=common.copy(), raw=0)
     eq_args = (room_frs, hp_left, hp_right, eq_left, eq_right, target, common, fs)
     planned = _expected_tasks(recordings)
-    design = _design_early(planned, *eq_args) if planned else None
+    design = _design_early(planned, *eq_args) if (planned and firs is None) else None
     for rec in recordings:
         src, speakers = rec[0], rec[1]
         side = rec[2] if len(rec) > 2 else None
@@ -88,8 +90,9 @@ def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, deca
     snap("crop_tails")
 
     tasks = [(sp, sd) for sp, pair in hrir.irs.items() for sd in pair]
-    firs = {(sp, sd): fir for sp, sd, fir in design.result()} if design is not None else {}
-    if set(firs) != set(tasks):                              # (a recording that brought other channels than announced)
+    if firs is None:
+        firs = {(sp, sd): fir for sp, sd, fir in design.result()} if design is not None else {}
+    if not set(tasks) <= set(firs):                          # (a recording that brought other channels than announced)
         firs = {(sp, sd): fir for sp, sd, fir in process_equalization_batch(tasks, *eq_args)}
     hrir.equalize_channels({t: firs[t] for t in tasks})
     snap("equalize")

@@ -1,0 +1,247 @@
+"""The hot-path slice of the reference's pipeline for MANY measurements per call, device resident.
+
+`pipeline_slice.run_slice` walks one measurement through the reference's stages (core/pipeline.py:565-573, 585-601,
+647-692, 725-735) with the class surface between them: every stage brings the scalars it decides with - peaks, knees,
+spectrum maxima - back to the host.  A job of many measurements with one layout (the same files, speakers and
+equalisation curves: a listener measured again, a room measured at several seats) does not need that: here the stage
+sequence of M measurements is ONE stream-ordered sequence of launches (imp_slice, include/impulse_hip.h), decisions
+are taken where the data is, and the scalars come back once at the end.
+
+What the device cannot promise to decide exactly as the host flow would - a Lundeby search with a decision inside its
+guard band, a gain on an fp32 rounding boundary, a crop_tails length above the capacity the slice was sized for - is
+flagged, never guessed: those measurements (rare) go through `run_slice`, the staged path, so every result is the staged
+path's result bit for bit.
+"""
+import warnings
+
+import numpy as np
+
+from . import _native
+from .constants import SPEAKER_DELAYS, speaker_side
+from .device_rows import DeviceBlock, Row
+from .hrir import HRIR, next_fast_len, split_recording
+from .impulse_response import ImpulseResponse
+
+
+class Layout:
+    """The files of one measurement: [(n_frames, tracks, speakers[, silence_length])], every file interleaved PCM frames of
+    one sample type with two tracks per speaker column (left ear, right ear: core/hrir.py:326-341)."""
+
+    def __init__(self, estimator, files, dtype=np.int32):
+        self.estimator = estimator
+        self.fs = estimator.fs
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.int16), np.dtype(np.int32), np.dtype(np.float32)):
+            raise ValueError("recordings are int16 / int32 PCM or float32 frames")
+        self.files = []
+        self.tasks = []                    # (speaker, side) in the order HRIR.irs lists them
+        pair_offsets, speakers, columns = [], [], []
+        base = 0
+        tracks0 = None
+        for spec in files:
+            n_frames, tracks, names = int(spec[0]), int(spec[1]), list(spec[2])
+            silence = spec[3] if len(spec) > 3 else 2.0
+            if tracks0 is None:
+                tracks0 = tracks
+            if tracks != tracks0 or tracks % 2:
+                raise ValueError("the resident slice takes recordings of one even track count")
+            shape_only = np.broadcast_to(np.zeros(1), (tracks, n_frames))
+            rec, jobs = split_recording(shape_only, names, len(estimator), self.fs, None, silence)
+            origin = n_frames - rec.shape[1]
+            for k in range(0, len(jobs), 2):
+                (sp, sd, tr, a, b), (sp2, sd2, tr2, a2, b2) = jobs[k], jobs[k + 1]
+                if (sp2, sd, sd2, tr2, a2, b2) != (sp, "left", "right", tr + 1, a, b):
+                    raise ValueError("recording geometry is not left / right pairs")
+                if sp in speakers:
+                    raise ValueError(f"speaker {sp} appears twice in the measurement")
+                speakers.append(sp)
+                columns.append((len(self.files), origin + a, b - a, tr))
+                pair_offsets.append(base + (origin + a) * tracks + tr)
+            self.files.append((n_frames, tracks, names, silence, base))
+            base += n_frames * tracks
+        if not speakers:
+            raise ValueError("no speaker column in the layout")
+        if len({c[2] for c in columns}) != 1:
+            raise ValueError("the resident slice takes columns of one length")
+        self.tracks = tracks0
+        self.samples = base                                # samples per measurement, all files
+        self.speakers = speakers
+        self.columns = columns
+        self.column_len = columns[0][2]
+        self.pair_offsets = np.array(pair_offsets, dtype=np.int64)
+        self.tasks = [(sp, sd) for sp in speakers for sd in ("left", "right")]
+
+    def pack(self, recordings):
+        """the files of one measurement ([frames[n_frames, tracks], ...]) as one block of samples"""
+        if len(recordings) != len(self.files):
+            raise ValueError("one frame block per file of the layout")
+        out = np.empty(self.samples, dtype=self.dtype)
+        for fr, (n_frames, tracks, _, _, base) in zip(recordings, self.files):
+            fr = np.asarray(fr)
+            if fr.shape != (n_frames, tracks) or fr.dtype != self.dtype:
+                raise ValueError(f"expected frames {(n_frames, tracks)} of {self.dtype}, got {fr.shape} of {fr.dtype}")
+            out[base:base + n_frames * tracks] = fr.reshape(-1)
+        return out
+
+
+class ResidentSlice:
+    """ingest -> crop_heads -> crop_tails -> equalize -> normalize for up to `max_measurements` measurements of one
+    layout per call.  FIRs are per job (set_firs); results are HRIR objects whose responses are device rows."""
+
+    def __init__(self, estimator, layout, max_measurements=8, head_ms=1, peak_target=-0.1, taps=None, keep_cap=None,
+                 paired=True):
+        self.estimator, self.layout = estimator, layout
+        fs = estimator.fs
+        self.fs = fs
+        self.head_ms, self.peak_target = head_ms, peak_target
+        self.head = int(head_ms * fs / 1000)
+        per_octave = len(estimator) / estimator.fs / estimator.n_octaves
+        self.fade = 2 * int(fs * per_octave * (1 / 24)) // 2
+        self.taps = int(taps) if taps is not None else _fir_taps(fs)
+        self.plan = estimator._plan(layout.column_len, paired=paired and layout.tracks == 2)
+        self.ctx = self.plan.ctx
+        self.max_measurements = int(max_measurements)
+        self.delays = [int(np.round(SPEAKER_DELAYS[sp] * fs)) + self.head for sp in layout.speakers]
+        self.bits = {np.dtype(np.int16): 16, np.dtype(np.int32): 32, np.dtype(np.float32): 0}[layout.dtype]
+        self.firs = None
+        self.slice = None
+        self.stats = dict(measurements=0, staged=0, regrown=0)
+        self._make(self._cap_for(int(1.1 * fs)) if keep_cap is None else int(keep_cap))
+
+    def _cap_for(self, keep):
+        """the largest crop_tails length whose normalisation transform (2^k >= 2 (keep + taps - 1) - 1 points) is the one
+        `keep` needs: 55 937 samples (1.17 s) at 48 kHz / 9 600 taps, 111 873 at 96 kHz / 19 200"""
+        want = int(keep) + self.taps
+        size = 1 << max(2 * want - 2, 1).bit_length()
+        return (size + 1) // 2 - self.taps + 1
+
+    def _make(self, keep_cap):
+        if self.slice is not None:
+            self.slice.close()
+        self.keep_cap = int(min(keep_cap, self.plan.out_len))
+        self.slice = _native.Slice(self.plan, self.layout.pair_offsets, self.delays, self.layout.tracks, self.bits, self.head,
+                                   self.fade, self.taps, self.keep_cap, self.fs, peak_target=self.peak_target,
+                                   max_measurements=self.max_measurements)
+        self.out_pitch = (self.slice.out_len_max + 63) // 64 * 64
+        if self.firs is not None:
+            self.slice.set_firs(self.firs)
+
+    def grow_for(self, rows):
+        """After a call that flagged IMP_SLICE_KEEP_CAP: size the slice for the crop_tails lengths those rows ask for (the
+        knees came back with the scalars), so that the call can be repeated.  The capacity only ever grows."""
+        R = self.slice.rows
+        need = 0
+        for m in range(len(rows) // R):
+            r = rows[m * R:(m + 1) * R]
+            need = max(need, min(int(r["len"].min()), next_fast_len(int(r["knee"].max()))))
+        if need <= self.keep_cap:
+            return False
+        self.stats["regrown"] += 1
+        self._make(self._cap_for(need))
+        return True
+
+    def set_firs(self, firs):
+        """firs: {(speaker, side): taps} or a [2 * speakers, taps] matrix in layout.tasks order"""
+        if isinstance(firs, dict):
+            firs = np.stack([np.asarray(firs[t], dtype=np.float64) for t in self.layout.tasks])
+        self.firs = np.ascontiguousarray(firs, dtype=np.float64)
+        self.slice.set_firs(self.firs)
+
+    def execute_device(self, d_rec, M, d_out=None):
+        """M measurements already on the device (layout.samples apart, first at d_rec).  Asynchronous; returns the output
+        block (rows [M * rows][out_pitch] fp32).  collect() brings the scalars back and builds the HRIRs."""
+        block = None
+        if d_out is None:
+            block = DeviceBlock(self.ctx, M * self.slice.rows * self.out_pitch)
+            d_out = block.ptr
+        self.slice.execute_device(d_rec, self.layout.samples, M, d_out, self.out_pitch)
+        return block
+
+    def collect(self, block, recordings=None, staged=None):
+        """[(HRIR, gain dB)] of the last call.  Measurements the device flagged are replaced by staged(m) (the staged
+        path of measurement m); without `staged` a flagged measurement raises."""
+        rows, meas = self.slice.results()
+        R = self.slice.rows
+        out = []
+        for m in range(len(meas)):
+            self.stats["measurements"] += 1
+            fl = int(meas["flags"][m])
+            if fl & _native.SLICE_REDO:
+                self.stats["staged"] += 1
+                if staged is None:
+                    raise _native.NativeError(-3, f"measurement {m}: the device left a decision to the staged path (flags {fl})")
+                out.append(staged(m))
+                continue
+            self._warn_sides(rows[m * R:(m + 1) * R])
+            hrir = HRIR(self.estimator)
+            n = int(meas["out_len"][m])
+            for q, sp in enumerate(self.layout.speakers):
+                pair = {}
+                for s, sd in enumerate(("left", "right")):
+                    b = m * R + 2 * q + s
+                    pair[sd] = ImpulseResponse.on_device(Row(block, b * self.out_pitch, n), self.fs,
+                                                         self._column(recordings, m, q, s))
+                hrir.irs[sp] = pair
+            out.append((hrir, float(meas["gain_db"][m])))
+        return out
+
+    def _column(self, recordings, m, q, s):
+        if recordings is None:
+            return None
+        f, start, length, tr = self.layout.columns[q]
+        scale = 1.0 if self.layout.dtype == np.float32 else 1.0 / float(2 ** (8 * self.layout.dtype.itemsize - 1))
+        return lambda: np.asarray(recordings[m][f])[start:start + length, tr + s].astype(np.float64) * scale
+
+    def _warn_sides(self, rows):
+        """crop_heads' warning for a speaker whose sound reaches the far ear first (core/hrir.py:569-596)"""
+        for q, sp in enumerate(self.layout.speakers):
+            p_left, p_right = int(rows["peak"][2 * q]), int(rows["peak"][2 * q + 1])
+            wrong = "right" if p_left < p_right else "left"
+            if speaker_side(sp) == wrong:
+                early = "left" if wrong == "right" else "right"
+                itd_ms = abs(p_left - p_right) / self.fs * 1000
+                warnings.warn(
+                    f"Warning: {sp} measurement has lower delay to {early} ear than to {wrong} ear. "
+                    f"{sp} should be at the {wrong} side of the head so the sound should arrive first in the "
+                    f"{wrong} ear. This is usually a problem with the measurement process or the speaker order "
+                    f"given is not correct. Detected delay difference is {itd_ms:.4f} milliseconds.")
+
+    def run(self, measurements):
+        """measurements: [[frames of file 0, frames of file 1, ...], ...] in host memory.  Returns [(HRIR, gain dB)]:
+        uploads, runs the resident sequence in calls of up to max_measurements, replaces flagged measurements by the
+        staged path."""
+        from .pipeline_slice import run_slice
+        if self.firs is None:
+            raise ValueError("set_firs first")
+        results = []
+        firs = {t: self.firs[i] for i, t in enumerate(self.layout.tasks)}
+        for m0 in range(0, len(measurements), self.max_measurements):
+            batch = measurements[m0:m0 + self.max_measurements]
+            M = len(batch)
+            d_rec = self.ctx.malloc(M * self.layout.samples * self.layout.dtype.itemsize)
+            try:
+                for m, recs in enumerate(batch):
+                    self.ctx.h2d(d_rec + m * self.layout.samples * self.layout.dtype.itemsize, self.layout.pack(recs))
+                block = self.execute_device(d_rec, M)
+                rows, meas = self.slice.results()
+                if np.any(meas["flags"] & _native.SLICE_KEEP_CAP) and self.grow_for(rows):
+                    block = self.execute_device(d_rec, M)      # once more, with room for the longest response
+            finally:
+                self.ctx.free(d_rec)                       # ordered on the stream
+
+            def staged(m, batch=batch):
+                jobs = [((self.fs, np.asarray(fr)), spec[2], None) for fr, spec in zip(batch[m], self.layout.files)]
+                return run_slice(self.estimator, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=firs)
+
+            results.extend(self.collect(block, batch, staged))
+        return results
+
+    def close(self):
+        self.slice.close()
+
+
+def _fir_taps(fs):
+    """taps of minimum_phase_impulse_response(fs, f_res=5): next_fast_len(round(fs // 2 / (f_res / 2)))
+    (autoeq/frequency_response.py:637-681 as process_equalization_worker calls it)"""
+    from .hrir import next_fast_len
+    return next_fast_len(int(round(fs // 2 / (5 / 2))))

@@ -409,6 +409,89 @@ int imp_chain_execute_device(imp_chain* chain, const float* d_x, int64_t chan_st
                              float* d_out, int64_t chan_stride_out, long long* d_peaks_out);
 void imp_chain_destroy(imp_chain* chain);
 
+/* ---- the reference's stage sequence, device resident and batched ----------------------------------------------------
+ * core/pipeline.py:565-573 (open measurements) -> :585-601 (crop_heads, crop_tails) -> :647-692 (equalize) -> :725-735
+ * (normalize), i.e. core/hrir.py:307-355, :548-612, :614-653, core/impulse_response.py:110-119, core/hrir.py:457-546, for
+ * M measurements per call with NO host readback between the stages:
+ *   ingest      every column of every recording through K1 (the plan's filter = the estimator's inverse filter)
+ *   crop_heads  first peak of every row (K3); per ear pair the earlier peak minus (speaker delay + head), both rows of the
+ *               pair cropped there, Hann fade-in of `head` samples (skipped for a pair shorter than head, as the reference)
+ *   crop_tails  peak + Lundeby knee of every cropped row (K7c); per measurement min(shortest row, next_fast_len(latest
+ *               knee)), rows truncated to it with a Hann fade-out of `fade_out` samples
+ *   equalize    row r of every measurement convolved with FIR r ('full': keep + taps - 1 samples, K5 in one launch)
+ *   normalize   np.max of the magnitude response of each ear's sum (K2, fp64) -> gain = -max + peak_target, every row
+ *               scaled by 10^(gain / 20)
+ * Every length and offset a later stage needs is left in device memory by the stage that decides it; the launch sequence
+ * is sized for the worst case the slice was made for (rows no longer than keep_cap after crop_tails) and workgroups past a
+ * measurement's actual lengths exit at once.  The scalars come back once, with imp_slice_results.
+ *
+ * A measurement = n_pairs ear pairs; pair q is rows 2q (left) and 2q + 1 (right) of the measurement, in the order
+ * HRIR.irs lists the speakers.  Its recording samples: left ear sample i at base[pair_offset[q] + i * elem_stride], right
+ * ear at + 1 (adjacent tracks of interleaved frames, core/hrir.py:326-341); the files of a measurement are laid out one
+ * after the other in one device block.  Measurement m of a call starts rec_stride samples after measurement m - 1.
+ *
+ * Decisions the device cannot promise to take as the host would are FLAGGED, never guessed (result.flags != 0): a knee
+ * search with a decision inside its guard band (IMP_SLICE_KNEE_GUARD / _RANGE, see imp_decay_knees_device), a crop_tails
+ * length above keep_cap, a fade-out longer than the cropped rows (the reference raises), a gain whose fp32 rounding
+ * depends on the last ulps of pow() or of the transform (IMP_SLICE_GAIN_GUARD), empty / non-finite spectra.  The rows of
+ * a flagged measurement are not valid: the caller runs that measurement through the staged entry points instead (the
+ * Python host does).  For measurements with flags == 0 the rows are bit-identical to the staged sequence
+ * imp_conv_execute_device_pairs -> imp_peak_index_device -> imp_apply_window_device -> imp_decay_knees_device ->
+ * imp_apply_window_device -> imp_conv_execute_device (fused FIR plan) -> imp_apply_window_device(gain). */
+#define IMP_SLICE_KNEE_GUARD 1
+#define IMP_SLICE_KNEE_RANGE 2
+#define IMP_SLICE_KEEP_CAP 4
+#define IMP_SLICE_FADE 8
+#define IMP_SLICE_GAIN_GUARD 16
+#define IMP_SLICE_GAIN_NONFINITE 32
+#define IMP_SLICE_SHORT 64          /* informational: a pair shorter than the head fade kept its head un-faded */
+typedef struct imp_slice imp_slice;
+typedef struct imp_slice_geometry {
+  int64_t n_pairs;               /* ear pairs per measurement */
+  int64_t elem_stride;           /* samples between consecutive frames of one ear (= tracks of the recordings) */
+  int bits;                      /* 16 / 32: PCM as in imp_conv_execute_device_pcm; 0: float32 frames */
+  const int64_t* pair_offset;    /* [n_pairs] sample offset of the left ear's first sample from the measurement's base */
+  const int64_t* delay;          /* [n_pairs] int(round(SPEAKER_DELAYS[speaker] * fs)) + head (core/hrir.py:566-567) */
+  int64_t head;                  /* int(head_ms * fs / 1000) */
+  int64_t fade_out;              /* int(fs * seconds_per_octave / 24): hann(2 fade_out)[fade_out:] (core/hrir.py:636-638) */
+  int64_t taps;                  /* FIR length (<= 24 577) */
+  int64_t keep_cap;              /* longest crop_tails length the slice is sized for */
+  double fs;
+  double peak_height;            /* 0.12589 */
+  double peak_target_db;         /* normalize(peak_target=...) */
+  double gain_guard_rel;         /* 0 = default 1e-10: relative band around fp32 rounding boundaries of the gain */
+} imp_slice_geometry;
+typedef struct imp_slice_row_result {
+  int64_t peak;                  /* peak_index of the deconvolved column */
+  int64_t cut;                   /* samples crop_heads removed */
+  int64_t len;                   /* length after crop_heads */
+  int64_t knee;                  /* decay_params()[1] of the cropped row */
+  int32_t knee_flags;            /* flags_out of imp_decay_knees_device */
+  int32_t knee_why;              /* diagnostic: which decision of the search fell into its guard band first (0: none) */
+} imp_slice_row_result;
+typedef struct imp_slice_result {
+  int64_t keep;                  /* crop_tails' return value */
+  int64_t out_len;               /* keep + taps - 1: samples per output row */
+  double peak_db[2];             /* left, right: np.max of the ear sum's magnitude response */
+  double gain_db;                /* normalize's return value */
+  float gain;                    /* 10^(gain_db / 20) as applied */
+  int32_t flags;                 /* IMP_SLICE_* */
+} imp_slice_result;
+/* deconv: a 'same' plan (mono or pair mode) of the column length on the slice's context, lanes = 1; it must outlive the slice */
+int imp_slice_create(imp_plan* deconv, const imp_slice_geometry* geometry, int64_t max_measurements, imp_slice** out);
+void imp_slice_destroy(imp_slice* slice);
+int imp_slice_info(const imp_slice* slice, int64_t* rows_per_measurement, int64_t* max_measurements, int64_t* out_len_max,
+                   int64_t* norm_fft_len);
+/* the FIRs of a job (host fp64 [2 n_pairs][ld], row r = FIR of row r of every measurement): the curves are per job,
+ * core/pipeline.py:668-688 designs them once.  Drains the stream. */
+int imp_slice_set_firs(imp_slice* slice, const double* firs, int64_t ld);
+/* asynchronous on the context's stream; d_out: [M * 2 n_pairs][out_pitch] fp32, out_pitch >= keep_cap + taps - 1; row
+ * m * 2 n_pairs + r holds result.out_len valid samples */
+int imp_slice_execute_device(imp_slice* slice, const void* d_rec, int64_t rec_stride, int64_t M, float* d_out,
+                             int64_t out_pitch);
+/* waits for the last call and copies its scalars: rows_out [M * 2 n_pairs], meas_out [M] (either may be NULL) */
+int imp_slice_results(imp_slice* slice, imp_slice_row_result* rows_out, imp_slice_result* meas_out);
+
 /* ---- the one collective: RCCL broadcast of the prepared filter spectrum -----------------------------
  * Channels shard across GPUs with no data-path collective; the only shared datum is the inverse-sweep spectrum rank 0
  * prepares.  The library does that broadcast itself over RCCL (xGMI inside a node), so the host side needs no

@@ -1,0 +1,241 @@
+"""imp_slice: the reference's stage sequence (core/pipeline.py:565-573, 585-601, 647-692, 725-735) for M measurements per
+call with no host readback between the stages, against
+
+  * the staged class path (HRIR.open_recording_frames -> crop_heads -> crop_tails -> equalize_channels -> normalize, one
+    host readback per stage): BIT FOR BIT - lengths, gains and every fp32 sample;
+  * the oracle composition of the same stages (NumPy fp64 restatement of the reference): within the fp32 tolerances of
+    tests/test_hip_parity.py.
+
+Sizes: a 1 s sweep layout (fast, several files per measurement), BASELINE C2 (7.1 x 2 ears, 6.15 s sweep, M = 8) and C3
+(13 speakers x 2 ears at 96 kHz)."""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TIME_TOL = 1e-6
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - b)) / np.max(np.abs(b)))
+
+
+def synth_frames(e, speakers, seed, rt60=0.25, level=0.4, noise_db=-85.0, lead_s=2.0):
+    """One binaural recording file: [n_frames, 2] int32 PCM, 2 s lead + one column (sweep + 2 s) per speaker; per speaker
+    and ear a direct sound plus an exponentially decaying noise tail and a background floor, so that peaks, Lundeby knees
+    and the tail crop are decided by the signal."""
+    fs, N = e.fs, len(e)
+    L = N + 2 * fs
+    lead = int(lead_s * fs)
+    rng = np.random.default_rng(seed)
+    tracks = np.zeros((2, lead + L * len(speakers)))
+    room = int(0.6 * fs)
+    nfft = 1 << int(np.ceil(np.log2(N + room)))
+    S = np.fft.rfft(level * np.asarray(e.test_signal, dtype=np.float64), nfft)
+    t = np.arange(room) / fs
+    for i in range(len(speakers)):
+        for ear in range(2):
+            h = rng.standard_normal(room) * 0.04 * 10 ** (-3.0 * t / (rt60 * (1 + 0.1 * rng.random())))
+            d0 = 40 + 7 * i + int(rng.integers(0, 30)) * ear + int(rng.integers(0, 9))
+            h[: d0 + 30] = 0.0
+            h[d0] = 1.0 - 0.3 * ear
+            y = np.fft.irfft(S * np.fft.rfft(h, nfft), nfft)[: N + room - 1]
+            seg = tracks[ear, lead + i * L: lead + (i + 1) * L]
+            seg[: min(len(y), L)] = y[:L]
+    tracks += rng.standard_normal(tracks.shape) * 10 ** (noise_db / 20)
+    return np.ascontiguousarray(np.clip(np.rint(tracks.T * 2.0 ** 31), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int32))
+
+
+def synth_firs(tasks, taps, seed):
+    rng = np.random.default_rng(seed)
+    firs = rng.standard_normal((len(tasks), taps)) * np.exp(-np.arange(taps) / 300.0) * 0.05
+    firs[:, 0] += 1.0
+    return {t: firs[i] for i, t in enumerate(tasks)}
+
+
+def staged_measurement(e, files, firs):
+    """the staged class path of one measurement (one host readback per stage)"""
+    from impulse_hip.pipeline_slice import run_slice
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return run_slice(e, [((e.fs, fr), sp) for fr, sp in files], firs=firs)
+
+
+def oracle_measurement(oe, files, firs, fs):
+    """the oracle composition: estimate -> crop_heads -> crop_tails -> FIR 'full' -> normalize (fp64)"""
+    from oracle import hrir as ohrir
+    from oracle.scipy_restated import fft_convolve
+    N = len(oe)
+    irs = {}
+    for fr, speakers in files:
+        stored = fr.T.astype(np.float64) / 2.0 ** 31
+        for sp, sd, col in ohrir.split_recording(stored, speakers, N, fs):
+            irs.setdefault(sp, {})[sd] = oe.estimate(col)
+    irs = ohrir.crop_heads(irs, fs, head_ms=1)
+    tail_ind, irs = ohrir.crop_tails(irs, fs, N, oe.n_octaves)
+    for sp in irs:
+        for sd in irs[sp]:
+            irs[sp][sd] = fft_convolve(irs[sp][sd], firs[(sp, sd)], "full")
+    g = ohrir.normalization_gain_db(irs, fs, peak_target=-0.1)
+    return tail_ind, g, {sp: {sd: irs[sp][sd] * 10 ** (g / 20) for sd in irs[sp]} for sp in irs}
+
+
+def assert_same_as_staged(got, want):
+    (h1, g1), (h2, g2) = got, want
+    assert list(h1.irs) == list(h2.irs)
+    # the gain in dB: two correct fp64 transforms of the ear sums (the staged path plans its chirp-z transform for the length
+    # it read back, the resident one for the slice's capacity) agree to ~1e-14 dB; what is APPLIED is that gain rounded to
+    # fp32, and a gain whose rounding could depend on such a difference is flagged and recomputed by the staged path
+    # (IMP_SLICE_GAIN_GUARD) - so the samples below are identical to the last bit
+    assert abs(g1 - g2) <= 1e-11
+    for sp in h1.irs:
+        for sd in ("left", "right"):
+            a, b = h1.irs[sp][sd].peek(), h2.irs[sp][sd].peek()
+            assert a.shape == b.shape, (sp, sd, a.shape, b.shape)
+            assert np.array_equal(a, b), (sp, sd, float(np.max(np.abs(a - b))))
+
+
+def test_resident_slice_small_layout_bitwise_and_oracle():
+    """Three measurements of a two-file layout (FL,FR + FC; 1 s sweep at 48 kHz) in ONE call: bit-identical to the staged
+    path of each measurement, and within fp32 tolerance of the oracle composition; the scalars that came back once (peaks,
+    crop indices, knees, lengths) are the staged path's integers."""
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.resident_slice import Layout, ResidentSlice
+    from oracle import estimator as oest
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=fs)
+    oe = oest.Estimator(min_duration=1.0, fs=fs)
+    files_spk = [["FL", "FR"], ["FC"]]
+    meas = [[synth_frames(e, spk, 1000 * m + 17 * k, rt60=0.2 + 0.05 * m) for k, spk in enumerate(files_spk)] for m in range(3)]
+    layout = Layout(e, [(fr.shape[0], 2, spk) for fr, spk in zip(meas[0], files_spk)])
+    assert layout.speakers == ["FL", "FR", "FC"] and layout.tracks == 2
+    rs = ResidentSlice(e, layout, max_measurements=4)
+    assert rs.plan.paired
+    firs = synth_firs(layout.tasks, rs.taps, 5)
+    rs.set_firs(firs)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = rs.run(meas)
+    # nothing was left to the staged path; the synthetic rooms' knees (1.3 - 1.9 s) are past the default capacity of 1.17 s:
+    # the first call came back flagged IMP_SLICE_KEEP_CAP with the knees, the slice was re-made for them and the call repeated
+    assert rs.stats == dict(measurements=3, staged=0, regrown=1)
+    rows, res = rs.slice.results()
+    assert np.all(res["flags"] & 63 == 0)
+    for m in range(3):
+        files = list(zip(meas[m], files_spk))
+        want = staged_measurement(e, files, firs)
+        assert_same_as_staged(got[m], want)
+        tail_ind, g, o_irs = oracle_measurement(oe, files, firs, fs)
+        assert int(res["keep"][m]) == tail_ind
+        assert got[m][1] == pytest.approx(g, abs=1e-5)
+        for sp in o_irs:
+            for sd in o_irs[sp]:
+                y = got[m][0].irs[sp][sd].peek()
+                assert y.shape == o_irs[sp][sd].shape
+                assert rel(y, o_irs[sp][sd]) <= 2 * TIME_TOL, (m, sp, sd)
+    rs.close()
+
+
+def test_resident_slice_flagged_measurements_take_the_staged_path():
+    """A decision the device does not take is flagged, never guessed: with a capacity below the crop_tails length
+    (IMP_SLICE_KEEP_CAP) and with a gain guard band as wide as the fp32 grid (IMP_SLICE_GAIN_GUARD) every measurement is
+    handed to the staged path - and the results are the staged path's."""
+    from impulse_hip import _native
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.resident_slice import Layout, ResidentSlice
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=fs)
+    spk = ["FL", "FR"]
+    meas = [[synth_frames(e, spk, 77 + m)] for m in range(2)]
+    layout = Layout(e, [(meas[0][0].shape[0], 2, spk)])
+    for kwargs, flag in ((dict(keep_cap=2000), _native.SLICE_KEEP_CAP), (dict(), _native.SLICE_GAIN_GUARD)):
+        rs = ResidentSlice(e, layout, max_measurements=2, **kwargs)
+        rs.grow_for = lambda rows: False                              # (keep the capacity where the test put it)
+        if flag == _native.SLICE_GAIN_GUARD:
+            rs._make(rs._cap_for(3 * fs))
+            rs.slice.close()
+            rs.slice = _native.Slice(rs.plan, layout.pair_offsets, [rs.head] * 2, 2, 32, rs.head, rs.fade, rs.taps, rs.keep_cap, fs,
+                                     max_measurements=2, gain_guard_rel=1e-6)
+        firs = synth_firs(layout.tasks, rs.taps, 9)
+        rs.set_firs(firs)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = rs.run(meas)
+        _, res = rs.slice.results()
+        assert np.all(res["flags"] & flag), res["flags"]
+        assert rs.stats == dict(measurements=2, staged=2, regrown=0)
+        for m in range(2):
+            assert_same_as_staged(got[m], staged_measurement(e, [(meas[m][0], spk)], firs))
+        rs.close()
+
+
+@pytest.mark.parametrize("pairs", [True, False])
+def test_resident_slice_mono_plan_and_pcm16(pairs, monkeypatch):
+    """The one-channel-per-transform deconvolution plan (what lengths beyond the pair plans take; forced here with
+    IMPULSE_HIP_NO_PAIRS) and 16-bit PCM frames through the same resident sequence, bit-identical to the staged path on
+    the same plan kind."""
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.resident_slice import Layout, ResidentSlice
+    if not pairs:
+        monkeypatch.setenv("IMPULSE_HIP_NO_PAIRS", "1")
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=fs)
+    spk = ["FL", "FC", "FR"]
+    fr32 = synth_frames(e, spk, 4242, noise_db=-70.0)
+    fr16 = (fr32 >> 16).astype(np.int16)
+    layout = Layout(e, [(fr16.shape[0], 2, spk)], dtype=np.int16)
+    rs = ResidentSlice(e, layout, max_measurements=1)
+    assert rs.plan.paired == pairs
+    firs = synth_firs(layout.tasks, rs.taps, 11)
+    rs.set_firs(firs)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = rs.run([[fr16]])
+        assert_same_as_staged(got[0], staged_measurement(e, [(fr16, spk)], firs))
+    rs.close()
+
+
+@pytest.mark.parametrize("config", ["c2", "c3"])
+def test_resident_slice_full_size(config):
+    """BASELINE C2 (7.1 layout x 2 ears, 6.15 s sweep at 48 kHz, M = 8 measurements per call) and C3 (13 speakers x 2 ears
+    at 96 kHz, 2 measurements): every measurement bit-identical to the staged class path; one measurement against the oracle
+    composition."""
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.resident_slice import Layout, ResidentSlice
+    from oracle import estimator as oest
+    if config == "c2":
+        fs, spk, M = 48000, ["FL", "FR", "FC", "BL", "BR", "SL", "SR", "WL"], 8
+    else:
+        from impulse_hip.constants import TRUEHD_13CH_ORDER
+        fs, spk, M = 96000, list(TRUEHD_13CH_ORDER), 2
+    e = ImpulseResponseEstimator(min_duration=5.0, fs=fs)
+    base = synth_frames(e, spk, 0xC2 if config == "c2" else 0xC3, rt60=0.22)
+    meas = [[base]]
+    rng = np.random.default_rng(99)
+    for m in range(1, M):                                             # same rooms, other noise and level: other peaks' neighbourhoods, knees, gains
+        g = 1.0 - 0.07 * m
+        noise = rng.standard_normal(base.shape) * (2.0 ** 31 * 10 ** (-80 / 20))
+        meas.append([np.clip(np.rint(base * g + noise), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int32)])
+    layout = Layout(e, [(base.shape[0], 2, spk)])
+    rs = ResidentSlice(e, layout, max_measurements=M)
+    assert rs.plan.paired and rs.plan.n1 == (132 if config == "c2" else 288)
+    firs = synth_firs(layout.tasks, rs.taps, 21)
+    rs.set_firs(firs)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = rs.run(meas)
+    _, res = rs.slice.results()
+    assert rs.stats["measurements"] == M
+    assert rs.stats["staged"] <= 1, res["flags"]                      # (a guard-band flag is legitimate, and rare)
+    for m in range(M):
+        assert_same_as_staged(got[m], staged_measurement(e, [(meas[m][0], spk)], firs))
+    oe = oest.Estimator(min_duration=5.0, fs=fs)
+    tail_ind, g, o_irs = oracle_measurement(oe, [(meas[0][0], spk)], firs, fs)
+    assert int(res["keep"][0]) == tail_ind
+    assert got[0][1] == pytest.approx(g, abs=1e-5)
+    for sp in o_irs:
+        for sd in o_irs[sp]:
+            assert rel(got[0][0].irs[sp][sd].peek(), o_irs[sp][sd]) <= 2 * TIME_TOL, (sp, sd)
+    rs.close()
