@@ -43,6 +43,9 @@ sys.path.insert(0, ROOT)
 
 PITCH_ALIGN = int(os.environ.get("IMPULSE_BENCH_PITCH_ALIGN", "64"))     # samples
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# what ANY streaming kernel moves across the L2<->fabric boundary with in-place read + write traffic on an Infinity-Cache
+# resident footprint (profiles/r02_stream_probe2.txt: 5.1 - 5.3 TB/s; K1's workspace round trips are that pattern)
+FABRIC_CEILING_GBS = 5300.0
 BROADCAST_VIA = None           # set when the in-library RCCL broadcast had to be replaced
 RCCL_RANKS_SEEN = None         # ranks the library's own communicator counted (ncclCommCount), set by spectrum_broadcast
 RCCL_COMM = None               # the rank's communicator (impulse_hip._native.Comm), made at the first broadcast
@@ -86,7 +89,8 @@ def parse_args(argv=None):
                          "records from perturbing the throughput being measured)")
     ap.add_argument("--blocks", type=int, default=0,
                     help="resident input blocks per step (0: 320 at C2 = 15 GiB; a block = the measurements of one chain call)")
-    ap.add_argument("--stage", default="chain", choices=["chain", "deconv"],
+    ap.add_argument("--no-slice", action="store_true", help="skip the slice / slice_resident blocks")
+    ap.add_argument("--stage", default="chain", choices=["chain", "deconv", "slice"],
                     help="what `value` times: the deconvolution + FIR chain (the metric) or K1 alone (C4 / C5 always K1)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--strong", action="store_true", help="add the strong_c5 block at N = 1 too")
@@ -221,6 +225,103 @@ def slice_rate(est, rec, L, reps=20):
                 note="end to end: PCM frames in host memory -> float64 responses in host memory, incl. PCIe; 16 IRs per "
                      "measurement, one measurement after the other (the FIR design of a measurement runs on a second stream "
                      "while its recording uploads); not the headline metric")
+
+
+def measurement_frames(est, rec, L, speakers):
+    """bench.py's synthetic channels laid out as ONE binaural recording file: 2 s lead + one column per speaker, the two
+    ears as the two tracks, interleaved 32-bit PCM frames [n_frames, 2] (what a capture buffer or a WAV data chunk holds)"""
+    fs = est.fs
+    tracks = np.zeros((2, 2 * fs + L * len(speakers)), dtype=np.float64)
+    for i in range(len(speakers)):
+        for ear in range(2):
+            tracks[ear, 2 * fs + i * L: 2 * fs + (i + 1) * L] = rec[2 * i + ear, :L]
+    return np.ascontiguousarray(np.clip(np.rint(tracks.T * 2.0 ** 31), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int32))
+
+
+SLICE_SPEAKERS = {"c2": ["FL", "FR", "FC", "BL", "BR", "SL", "SR", "WL"],
+                  "c3": ["FL", "FR", "FC", "BL", "BR", "SL", "SR", "TFL", "TFR", "TSL", "TSR", "TBL", "TBR"]}
+
+
+class SliceTeam:
+    """The reference's stage sequence for M measurements per call, device resident (imp_slice): `n_streams` slices, each on
+    a context (stream) of its own, fed round robin by one host thread; the recordings of a call sit in HBM (a ring of
+    `ring` call blocks per stream, so that a call's inputs were last touched 2+ calls ago)."""
+
+    def __init__(self, est, rec, L, n_streams=2, M=8, ring=3, speakers=None, quiet_setup=False):
+        from impulse_hip import Context
+        from impulse_hip._native import using_context
+        from impulse_hip.resident_slice import Layout, ResidentSlice
+        self.est, self.M = est, M
+        n_spk = rec.shape[0] // 2
+        speakers = speakers or (SLICE_SPEAKERS["c2"] if n_spk == 8 else SLICE_SPEAKERS["c3"])[:n_spk]
+        self.speakers = speakers
+        self.frames = measurement_frames(est, rec, L, speakers)
+        self.layout = Layout(est, [(self.frames.shape[0], 2, speakers)])
+        packed = self.layout.pack([self.frames])
+        self.lanes = []
+        self.firs = None
+        for i in range(n_streams):
+            ctx = Context(0)
+            with using_context(ctx):
+                rs = ResidentSlice(est, self.layout, max_measurements=M)
+            if self.firs is None:
+                self.firs = synth_firs(len(self.layout.tasks), rs.taps)
+            rs.set_firs(self.firs)
+            d_in = []
+            for _ in range(ring):
+                p = ctx.malloc(M * packed.nbytes)
+                for m in range(M):
+                    ctx.h2d(p + m * packed.nbytes, packed)
+                d_in.append(p)
+            self.lanes.append(dict(ctx=ctx, rs=rs, d_in=d_in, d_out=None, k=0))
+        self.rows = self.lanes[0]["rs"].slice.rows
+        # size every slice for the knees these recordings have (first call: flagged KEEP_CAP with the knees, grown once)
+        for ln in self.lanes:
+            self._alloc_out(ln)
+            ln["rs"].slice.execute_device(ln["d_in"][0], self.layout.samples, M, ln["d_out"], ln["rs"].out_pitch)
+            rows, meas = ln["rs"].slice.results()
+            if np.any(meas["flags"] & 4) and ln["rs"].grow_for(rows):
+                self._alloc_out(ln)
+
+    def _alloc_out(self, ln):
+        if ln["d_out"]:
+            ln["ctx"].free(ln["d_out"])
+        ln["d_out"] = ln["ctx"].malloc(self.M * self.rows * ln["rs"].out_pitch * 4)
+
+    def describe(self):
+        rs = self.lanes[0]["rs"]
+        return (f"{len(self.lanes)} streams x {self.M} measurements per call, {self.rows} rows each, column {self.layout.column_len}, "
+                f"keep_cap {rs.keep_cap}, taps {rs.taps}, normalisation transform {rs.slice.norm_fft_len} points, "
+                f"{'pair' if rs.plan.paired else 'mono'} plan of {rs.plan.n1} rows")
+
+    def step(self):
+        for ln in self.lanes:
+            ln["rs"].slice.execute_device(ln["d_in"][ln["k"] % len(ln["d_in"])], self.layout.samples, self.M, ln["d_out"],
+                                          ln["rs"].out_pitch)
+            ln["k"] += 1
+
+    def sync(self):
+        for ln in self.lanes:
+            ln["ctx"].synchronize()
+
+    def flags(self):
+        return sorted({int(f) for ln in self.lanes for f in ln["rs"].slice.results()[1]["flags"]})
+
+    def results(self, lane=0):
+        return self.lanes[lane]["rs"].slice.results()
+
+    def fetch(self, lane=0):
+        ln = self.lanes[lane]
+        out = np.empty((self.M * self.rows, ln["rs"].out_pitch), dtype=np.float32)
+        ln["ctx"].synchronize()
+        ln["ctx"].d2h(out, ln["d_out"])
+        return out
+
+    def release(self):
+        for ln in self.lanes:
+            ln["rs"].close()
+            ln["ctx"].close()
+        self.lanes = []
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -596,10 +697,151 @@ def live_pmc_traffic(workload):
         shutil.rmtree(out, ignore_errors=True)
 
 
+SLICE_PMC_CALLS, SLICE_PMC_M = 3, 4
+
+
+def slice_pmc_child(args):
+    """--pmc-child --stage slice: set-up, then SLICE_PMC_CALLS serial calls of SLICE_PMC_M measurements on one stream"""
+    est = make_estimator(args.workload)
+    rec, L, _, _ = synth_recordings(est, WORKLOADS[args.workload][2], seed0=0xC2)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        team = SliceTeam(est, rec, L, n_streams=1, M=SLICE_PMC_M, ring=1, quiet_setup=True)
+        for _ in range(SLICE_PMC_CALLS):
+            team.step()
+            team.sync()
+        team.release()
+    return 0
+
+
+def live_slice_traffic(workload):
+    """L2<->fabric bytes one measurement of the resident slice moves (every kernel of a call: FETCH_SIZE x2 + WRITE_SIZE
+    summed over the dispatches of the child's calls / measurements), from two `rocprofv3 --pmc` child runs; None if it cannot
+    be collected"""
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL")) for k in os.environ)
+    if not os.path.exists(rocprof) or profiled:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    out = tempfile.mkdtemp(prefix="impulse_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "IMPULSE_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    try:
+        tot = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, counter)
+            cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--pmc-child", "--stage", "slice"]
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
+            if res.returncode != 0:
+                sys.stderr.write(f"[bench] rocprofv3 --pmc {counter} slice child failed (rc {res.returncode}): {res.stderr[-400:]}\n")
+                return None
+            t = pmc_summary.totals_from(d, "cols_")          # a call starts with K1's forward column pass; set-up has none
+            if counter not in t:
+                return None
+            tot[counter] = t[counter]
+        n_meas = SLICE_PMC_CALLS * SLICE_PMC_M + SLICE_PMC_M   # + the sizing call SliceTeam makes
+        kb = 2 * tot["FETCH_SIZE"][0] + tot["WRITE_SIZE"][0]  # gfx950: FETCH_SIZE counts half of a coalesced read stream
+        return dict(bytes_per_measurement=kb * 1024 / n_meas, dispatches_per_call=tot["FETCH_SIZE"][1] / (SLICE_PMC_CALLS + 1))
+    except Exception as exc:                                  # noqa: BLE001 - a reported figure, never fatal
+        sys.stderr.write(f"[bench] live slice PMC collection failed: {exc!r}\n")
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def slice_resident_block(est, rec, L, workload, no_pmc=False, n_streams=3, M=8, budget_s=0.5):
+    """`slice_resident`: the reference's real stage order (ingest -> crop_heads with the earlier-ear rule -> crop_tails at
+    the Lundeby length -> equalize -> normalize) as imp_slice runs it - M measurements per call, no host readback between the
+    stages, recordings resident in HBM.  Checked in the same run: no measurement flagged, and measurement 0 bit-identical to
+    the staged class path (one readback per stage)."""
+    import warnings
+    from impulse_hip.pipeline_slice import run_slice
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        team = SliceTeam(est, rec, L, n_streams=n_streams, M=M, ring=3)
+        desc = team.describe()
+        for _ in range(2):
+            team.step()
+        team.sync()
+        t0 = time.perf_counter()
+        team.step()
+        team.sync()
+        one = max(time.perf_counter() - t0, 1e-4)
+        calls = int(max(4, min(400, budget_s / one)))
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            team.step()
+        team.sync()
+        dt = time.perf_counter() - t0
+        flags = team.flags()
+        rows, meas = team.results(0)
+        out = team.fetch(0)
+        rs = team.lanes[0]["rs"]
+        firs = {t: team.firs[i] for i, t in enumerate(team.layout.tasks)}
+        hrir, gain = run_slice(est, [((est.fs, team.frames), team.speakers)], firs=firs)
+        n = int(meas["out_len"][0])
+        same = abs(float(meas["gain_db"][0]) - gain) <= 1e-11
+        for q, sp in enumerate(team.speakers):
+            for s_, sd in enumerate(("left", "right")):
+                want = hrir.irs[sp][sd].peek()
+                got = out[2 * q + s_, :n].astype(np.float64)
+                same = same and got.shape == want.shape and bool(np.array_equal(got, want))
+        rows_per = team.rows
+        in_bytes = team.frames.nbytes / rows_per
+        out_bytes = 4.0 * n
+        team.release()
+    irs = calls * n_streams * M * rows_per
+    rate = irs / dt
+    alg = in_bytes + out_bytes
+    block = dict(value=rate, unit="IR/s", timed_region_s=dt, calls=calls * n_streams, measurements_per_call=M, streams=n_streams,
+                 ms_per_call_per_stream=dt / calls * 1e3, arrangement=desc,
+                 keep=int(meas["keep"][0]), out_len=n, flags_seen=flags, no_measurement_flagged=flags == [0],
+                 bit_identical_to_staged_path=bool(same),
+                 algorithmic_bytes_per_ir=alg, path_achieved=rate * alg / 1e9, path_frac=rate * alg / 1e9 / HBM_PEAK_GBS,
+                 note="the reference's stage sequence (core/pipeline.py:565-573, 585-601, 647-692, 725-735) per measurement: "
+                      "PCM frames in HBM -> K1 (pair mode) -> first peaks -> crop_heads (earlier ear of each pair - 1 ms, fade-in) -> "
+                      "Lundeby knees (K7c) -> crop_tails at min(shortest row, next_fast_len(latest knee)) + fade-out -> per-channel "
+                      f"{rs.taps}-tap FIR (K5) -> normalize (K2 of the ear sums, gain on the device); scalars read back once per call; "
+                      "FIRs set once per job.  algorithmic bytes per IR = the recording's PCM bytes / 16 in + 4 (keep + taps - 1) out")
+    if not no_pmc:
+        live = live_slice_traffic(workload)
+        if live:
+            per_ir = live["bytes_per_measurement"] / rows_per
+            block["l2_fabric_traffic"] = dict(bytes_per_ir=per_ir, rate=rate * per_ir / 1e9, unit="GB/s", source="live",
+                                              dispatches_per_call=live["dispatches_per_call"],
+                                              over_algorithmic=per_ir / alg,
+                                              note="FETCH_SIZE x2 + WRITE_SIZE of every kernel of a call (rocprofv3 --pmc child runs "
+                                                   "made by this run, serial calls), per IR; Infinity-Cache hits included: a fabric "
+                                                   "figure, not HBM bytes")
+    return block
+
+
 def pmc_child(args):
     """what the --pmc children run: a few strictly serial chain calls (every kernel alone on the chip)"""
+    if args.stage == "slice":
+        return slice_pmc_child(args)
     from impulse_hip import Context
     est = make_estimator(args.workload)
+    if args.workload in ("c4", "c5"):
+        # K1 alone, launch groups of GROUP_CHANNELS channels as the timed leg runs them, strictly serial
+        g = GROUP_CHANNELS[args.workload]
+        rec, L, pitch, _ = synth_recordings(est, g, seed0=0xC5, column=len(est))
+        ctx = Context(0)
+        ring = InputRing(ctx, rec, 2)
+        dec = K1Team([ctx], np.asarray(est.inverse_filter, dtype=np.float64), ring, g, L, pitch, len(est), g)
+        for k in range(4):
+            dec.call(ring.ptrs[k % 2], lane=0)
+            dec.sync()
+        dec.release()
+        ring.release()
+        ctx.close()
+        return 0
     B = WORKLOADS[args.workload][2] * MEASUREMENTS_PER_BLOCK.get(args.workload, 1)
     rec, L, pitch, _ = synth_recordings(est, B, seed0=0xC2)
     ctx = Context(0)
@@ -989,7 +1231,11 @@ def main(argv=None):
         elapsed = chain_elapsed if stage == "chain" else dec_elapsed
         value = irs_per_step * steps_timed / elapsed
         dec_value = dec_rate_rank * world
-        alg_k1_launch = 8.0 * L * B / groups_per_call                    # algorithmic bytes of one K1 launch group
+        # channels per K1 launch group: of the leg whose HIP events time the kernels (the chain deconvolves a whole call as ONE
+        # group, K1 alone runs groups of `group_channels`), of the serial isolated calls (K1 alone), of the --pmc children
+        timed_group = B if stage == "chain" else group_channels
+        pmc_group = group_channels if strong else B
+        alg_k1_launch = 8.0 * L * timed_group                            # algorithmic bytes of one timed K1 launch group
         alg_chain_ir = 4.0 * L + 4.0 * (n_fir + K_fir - 1)                # recording in, equalised cropped response out
         names = ("cols_kernel<fwd> (K1 pass A)", "rows_kernel (K1 pass B)", "cols_kernel<inv> (K1 pass C)")
         # per-kernel times over the TIMED region: from the chains' K1 plans when the chain is what is timed
@@ -1000,9 +1246,9 @@ def main(argv=None):
             dom = int(np.argmax(avg_ms))
             achieved = alg_k1_launch / (avg_ms[dom] * 1e-3) / 1e9
             iso_avg = [m / max(iso_n, 1) for m in iso_ms]
-            iso_achieved = alg_k1_launch / (iso_avg[dom] * 1e-3) / 1e9
+            iso_achieved = 8.0 * L * group_channels / (iso_avg[dom] * 1e-3) / 1e9
             prof, prof_src, live = None, None, False
-            if world == 1 and not args.no_pmc and not strong:
+            if world == 1 and not args.no_pmc:
                 prof = live_pmc_traffic(args.workload)
                 live = prof is not None
                 prof_src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command, made by this run"
@@ -1010,13 +1256,14 @@ def main(argv=None):
                 prof, prof_src = load_profile_traffic(args.workload)
             roof = dict(bound="hbm", kernel=names[dom], achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS,
-                        traffic=(prof or {}).get("rows_kernel_bytes_per_launch"),
+                        traffic=(prof or {}).get("rows_kernel_bytes_per_launch", 0.0) * timed_group / pmc_group if prof else None,
                         traffic_source=("live" if live else "committed summary") if prof else None,
                         traffic_note=(f"L2<->fabric bytes per launch of the dominant kernel (FETCH_SIZE x2 + WRITE_SIZE, "
                                       f"Infinity-Cache hits INCLUDED, so not HBM bytes); separate --pmc passes, strictly serial "
                                       f"launches; source: {prof_src}") if prof else None,
                         avg_kernel_ms=dict(zip(("pass_a", "pass_b", "pass_c"), avg_ms)),
-                        events_sampled=int(t_n), launch_groups_in_flight=lanes,
+                        events_sampled=int(t_n), launch_groups_in_flight=lanes, channels_per_timed_launch_group=timed_group,
+                        channels_per_isolated_launch_group=group_channels, channels_per_pmc_launch_group=pmc_group,
                         note="achieved/frac: algorithmic bytes (8 L per IR) of one K1 launch group / HIP-event time of the "
                              "dominant kernel over the timed region; with several launch groups in flight that time includes "
                              "the share of the chip the kernel cedes to the others, so `isolated` (strictly serial groups) "
@@ -1039,14 +1286,22 @@ def main(argv=None):
             else:
                 roof["path_achieved"], roof["path_frac"] = roof["deconv_only_path_achieved"], roof["deconv_only_path_frac"]
             if prof and all(k + "_bytes_per_launch" in prof for k in ("rows_kernel", "cols_fwd", "cols_inv")):
-                moved_k1 = sum(prof[k + "_bytes_per_launch"] for k in ("rows_kernel", "cols_fwd", "cols_inv"))
+                moved_k1 = sum(prof[k + "_bytes_per_launch"] for k in ("rows_kernel", "cols_fwd", "cols_inv"))   # per pmc_group channels
                 moved_tail = sum(prof.get(k + "_bytes_per_launch", 0.0) for k in ("peak_search", "fir_block"))
-                per_call = moved_k1 * groups_per_call + (moved_tail if stage == "chain" else 0.0)
+                per_call = moved_k1 * B / pmc_group + (moved_tail if stage == "chain" else 0.0)
                 rate = per_call * n_blocks / (elapsed / steps_timed) / 1e9
+                # the ceiling of this decomposition: the algorithmic share of the bytes K1 must move across the fabric, at the
+                # rate the fabric gives such traffic
+                roof["ceiling_frac"] = (8.0 * L * pmc_group / moved_k1) * FABRIC_CEILING_GBS / HBM_PEAK_GBS
+                roof["ceiling_note"] = (f"algorithmic bytes / live-PMC fabric bytes of K1 ({8.0 * L * pmc_group / 1e6:.1f} / {moved_k1 / 1e6:.1f} MB per "
+                                        f"{pmc_group}-channel group) x {FABRIC_CEILING_GBS / 1e3:.1f} TB/s (what in-place read + write streams reach "
+                                        "across the L2<->fabric boundary, profiles/r02_stream_probe2.txt) / 8 TB/s: what K1 alone "
+                                        "(`deconv_only_path_frac`) can reach with two workspace round trips")
+                roof["deconv_only_fabric_rate"] = dec_value / world / pmc_group * moved_k1 / 1e9
                 roof["l2_fabric_traffic"] = dict(
                     bytes_per_call=per_call, k1_bytes_per_launch_group=moved_k1,
                     peak_search_plus_fused_k5_bytes_per_call=moved_tail if stage == "chain" else None,
-                    rate=rate, unit="GB/s", source=prof_src,
+                    rate=rate, unit="GB/s", source=prof_src, k1_channels_per_pmc_launch_group=pmc_group,
                     note=f"bytes the kernels of one call ({B} channels) move across the L2<->fabric boundary (rocprofv3 --pmc, "
                          "see traffic_note) / this run's time per call.  Infinity-Cache hits are counted, so this is a FABRIC "
                          "rate, not achieved HBM bandwidth; it is not compared with the HBM peak")
@@ -1085,12 +1340,18 @@ def main(argv=None):
                 parity["real_demo_column"] = dict(error=repr(exc))
             peaks_ok &= max(errs) <= 1e-6
             parity["peak_indices_exact"] = bool(peaks_ok)
-        whole_slice = None
-        if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
+        whole_slice = slice_res = None
+        if world == 1 and args.workload == "c2" and not args.no_cpu_baseline and not args.no_slice:
             try:
                 whole_slice = slice_rate(est, rec[:B_meas], L)
             except Exception as exc:                          # noqa: BLE001 - secondary figure only
                 whole_slice = dict(error=repr(exc))
+        if world == 1 and args.workload in ("c2", "c3") and not args.no_slice:
+            try:
+                slice_res = slice_resident_block(est, rec[:B_meas], L, args.workload, no_pmc=args.no_pmc)
+                peaks_ok &= bool(slice_res["bit_identical_to_staged_path"])
+            except Exception as exc:                          # noqa: BLE001 - secondary figure only
+                slice_res = dict(error=repr(exc))
         result = {
             "metric": METRIC, "value": value, "unit": "IR/s", "n_gpus": world, "steps": steps_timed,
             "warmup": args.warmup, "ms_per_step": elapsed / steps_timed * 1e3,
@@ -1115,6 +1376,8 @@ def main(argv=None):
                        "layout": f"planar fp32, row pitch {pitch} samples (multiple of {PITCH_ALIGN})",
                        "nfft": nfft, "chains_in_flight": lanes, "workspace_channels": plan_ws,
                        "device_memory": "libimpulse_hip (imp_malloc); torch only as the launcher's control plane at N > 1",
+                       "environment_switches": {k: v for k, v in sorted(os.environ.items())
+                                                if k.startswith(("IMPULSE_BENCH_", "IMPULSE_HIP_"))},
                        "sharding": (f"channels x{world}, no data-path collective; "
                                     f"one {(BROADCAST_VIA or 'RCCL (by libimpulse_hip, no torch in the data path)') if backend == 'nccl' else backend + ' (rehearsal)'} broadcast of "
                                     f"{bcast_bytes[0]} B spectrum at plan creation") if dist is not None else
@@ -1126,7 +1389,7 @@ def main(argv=None):
                                        "cropped stores fall on cache lines",
                                 note="K1 alone over the same resident inputs (last round's headline), algorithmic bytes 8 L per IR",
                                 pair_mode=pair_block),
-            "slice": whole_slice, "strong_c5": strong_c5,
+            "slice": whole_slice, "slice_resident": slice_res, "strong_c5": strong_c5,
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(result) + "\n").encode())

@@ -38,6 +38,21 @@ def main(root):
     return res
 
 
+def totals_from(root, first_kernel_substr):
+    """{counter: (sum of Counter_Value over every dispatch from the first one whose kernel name contains the substring,
+    number of such dispatches)} - the counters of the calls a child run makes after its set-up."""
+    out = {}
+    for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
+        started = False
+        for row in rows:
+            started = started or first_kernel_substr in row["Kernel_Name"]
+            if started:
+                tot, cnt = out.get(row["Counter_Name"], (0.0, 0))
+                out[row["Counter_Name"]] = (tot + float(row["Counter_Value"]), cnt + 1)
+    return out
+
+
 if __name__ == "__main__":
     import json
     r = main(sys.argv[1])
