@@ -197,34 +197,55 @@ def synth_firs(B, K, seed=0xF1):
     return firs
 
 
-def slice_rate(est, rec, L, reps=20):
-    """SURVEY 8(d) secondary figure: the whole hot-path slice (ingest K1 -> crop_heads K3/K4 -> crop_tails K7/K4 ->
-    EQ curves + FIR design K12/K6 -> equalize K5 -> normalize K2) on ONE 7.1 x 2-ear measurement laid out as a recording
-    (2 s lead + one column per speaker): interleaved PCM frames in, float64 host arrays out; the responses stay on the
-    device between the stages."""
+def slice_rate(est, rec, L, reps=24, workers=3):
+    """SURVEY 8(d) secondary figure: the whole hot-path slice end to end over a job of `reps` measurements (7.1 x 2 ears each,
+    one recording file per measurement: interleaved PCM frames in host memory) to float64 responses in host memory:
+    ingest K1 -> crop_heads K3/K4 -> crop_tails K7c/K4 -> equalize K5 -> normalize K2, the stage sequence of every
+    measurement device resident (imp_slice), `workers` host threads with a stream each so that the upload of measurement
+    i + 1 overlaps the compute of measurement i; the FIRs are designed once per job (K12 -> K6), inside the timed region."""
+    from impulse_hip.frequency_response import FrequencyResponse
+    from impulse_hip.parallel_workers import process_equalization_batch
+    from impulse_hip.resident_slice import Layout, SliceRunner
     from impulse_hip.pipeline_slice import run_slice
     fs = est.fs
-    speakers = ["FL", "FR", "FC", "BL", "BR", "SL", "SR", "WL"]
-    tracks = np.zeros((2, 2 * fs + L * 8), dtype=np.float64)
-    for i in range(8):
-        for ear in range(2):
-            tracks[ear, 2 * fs + i * L: 2 * fs + (i + 1) * L] = rec[2 * i + ear, :L]
-    # the recording as a capture buffer / WAV data chunk holds it: interleaved 32-bit PCM frames
-    frames = np.ascontiguousarray(np.clip(np.rint(tracks.T * 2.0 ** 31), -2.0 ** 31, 2.0 ** 31 - 1).astype(np.int32))
-    job = [((fs, frames), speakers)]
+    speakers = SLICE_SPEAKERS["c2"][:rec.shape[0] // 2]
+    frames = measurement_frames(est, rec, L, speakers)
+    layout = Layout(est, [(frames.shape[0], 2, speakers)])
+    common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
+    target = FrequencyResponse(name="target", frequency=common.copy(), raw=0)
+
+    runner = SliceRunner(est, layout, workers=workers)       # lanes (context + slice each) live across jobs
+
+    def job(n, to_host=True):
+        firs = {(sp, sd): fir for sp, sd, fir in process_equalization_batch(layout.tasks, None, None, None, None, None, target, common, fs)}
+        return runner.run([[frames]] * n, firs, to_host=to_host), firs
+
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for _ in range(2):
-            run_slice(est, job)[0].to_host()                  # plans, tables, the allocator's steady state
+        job(reps)                                             # plans, tables, the allocator's steady state
+        runner.times()
         t0 = time.perf_counter()
-        for _ in range(reps):
-            run_slice(est, job)[0].to_host()                  # float64 host arrays out
+        res, firs = job(reps)
         dt = (time.perf_counter() - t0) / reps
-    return dict(value=16 / dt, unit="IR/s", ms_per_measurement=dt * 1e3,
-                note="end to end: PCM frames in host memory -> float64 responses in host memory, incl. PCIe; 16 IRs per "
-                     "measurement, one measurement after the other (the FIR design of a measurement runs on a second stream "
-                     "while its recording uploads); not the headline metric")
+        lane_ms = {k: v / reps * 1e3 for k, v in runner.times().items() if k != "measurements"}
+        # the same measurement through the staged class path (one host readback per stage): identical samples
+        hrir, gain = run_slice(est, [((fs, frames), speakers)], firs=firs)
+        same = all(np.array_equal(res[k][0].irs[sp][sd].data, hrir.irs[sp][sd].data) for k in (0, reps - 1) for sp in speakers
+                   for sd in ("left", "right"))
+        t0 = time.perf_counter()
+        for _ in range(4):
+            run_slice(est, [((fs, frames), speakers)], firs=firs)[0].to_host()
+        staged_ms = (time.perf_counter() - t0) / 4 * 1e3
+        runner.close()
+    return dict(value=16 / dt, unit="IR/s", ms_per_measurement=dt * 1e3, measurements=reps, workers=workers,
+                identical_to_staged_path=bool(same), staged_path_ms_per_measurement=staged_ms, lane_ms_per_measurement=lane_ms,
+                pcie_bytes_per_measurement=int(frames.nbytes),
+                note="end to end: PCM frames in host memory -> float64 responses in host memory, incl. PCIe "
+                     f"({frames.nbytes / 1e6:.1f} MB up per measurement) and the once-per-job FIR design; {workers} host threads, a "
+                     "stream and a one-measurement resident slice each: upload i + 1 overlaps compute i; "
+                     "staged_path_ms_per_measurement = the class path with a host readback per stage, one measurement after "
+                     "the other (FIRs given); not the headline metric")
 
 
 def measurement_frames(est, rec, L, speakers):

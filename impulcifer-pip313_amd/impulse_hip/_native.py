@@ -1107,6 +1107,11 @@ _default_lock = threading.Lock()
 _thread_ctx = threading.local()
 
 
+def default_device():
+    """the device index the package's default context lives on (IMPULSE_HIP_DEVICE, default 0)"""
+    return int(os.environ.get("IMPULSE_HIP_DEVICE", "0"))
+
+
 def default_context():
     """Process-wide context on IMPULSE_HIP_DEVICE (default 0) - or the one `using_context` installed for this thread."""
     global _default_ctx

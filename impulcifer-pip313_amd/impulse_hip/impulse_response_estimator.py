@@ -66,6 +66,12 @@ class ImpulseResponseEstimator(object):
                 p.close()
             self._plans = {}
 
+    def _forget_context(self, ctx):
+        """close the plans made on `ctx` (a worker's context that is about to be closed)"""
+        with self._plan_lock:
+            for key in [k for k in self._plans if k[2] == id(ctx)]:
+                self._plans.pop(key).close()
+
     def __len__(self):
         return len(self.test_signal)
 

@@ -12,6 +12,7 @@ guard band, a gain on an fp32 rounding boundary, a crop_tails length above the c
 flagged, never guessed: those measurements (rare) go through `run_slice`, the staged path, so every result is the staged
 path's result bit for bit.
 """
+import time
 import warnings
 
 import numpy as np
@@ -236,8 +237,145 @@ class ResidentSlice:
             results.extend(self.collect(block, batch, staged))
         return results
 
+    def upload(self, d_rec, recordings):
+        """the files of one measurement to their places in a device block (no host-side packing: every file goes up as it
+        is)"""
+        item = self.layout.dtype.itemsize
+        for fr, (n_frames, tracks, _, _, base) in zip(recordings, self.layout.files):
+            fr = np.asarray(fr)
+            if fr.shape != (n_frames, tracks) or fr.dtype != self.layout.dtype:
+                raise ValueError(f"expected frames {(n_frames, tracks)} of {self.layout.dtype}, got {fr.shape} of {fr.dtype}")
+            self.ctx.h2d(d_rec + base * item, fr)
+
     def close(self):
         self.slice.close()
+
+
+class SliceRunner:
+    """Jobs of many measurements of one layout, end to end from host memory.
+
+    `workers` lanes, each a host thread with a context (stream) of its own and a one-measurement resident slice, all kept
+    for the runner's life: while one measurement's recording crosses PCIe, another's stage sequence runs and a third's
+    responses come back - the upload of measurement i + 1 overlaps the compute of measurement i."""
+
+    def __init__(self, estimator, layout, workers=3, head_ms=1, peak_target=-0.1):
+        import queue
+        import threading
+        self.estimator, self.layout = estimator, layout
+        self.head_ms, self.peak_target = head_ms, peak_target
+        self.lanes = []
+        self._job = None
+        self._lock = threading.Lock()
+        for k in range(max(1, int(workers))):
+            ln = dict(todo=queue.Queue(), done=queue.Queue(), ready=threading.Event(), error=None, times={})
+            ln["thread"] = threading.Thread(target=self._worker, args=(ln,), name=f"impulse-slice-{k}", daemon=True)
+            ln["thread"].start()
+            self.lanes.append(ln)
+        for ln in self.lanes:
+            ln["ready"].wait()
+            if ln["error"] is not None:
+                raise ln["error"]
+
+    def _worker(self, ln):
+        """a lane's thread: makes its context and slice, then serves jobs until it is told to stop"""
+        from .pipeline_slice import run_slice
+        est, layout = self.estimator, self.layout
+        try:
+            ctx = _native.Context(_native.default_device())
+            with _native.using_context(ctx):
+                rs = ResidentSlice(est, layout, max_measurements=1, head_ms=self.head_ms, peak_target=self.peak_target)
+            d_rec = ctx.malloc(layout.samples * layout.dtype.itemsize)
+            ln.update(ctx=ctx, rs=rs, d_rec=d_rec)
+        except BaseException as exc:                       # noqa: BLE001 - reported to the constructor
+            ln["error"] = exc
+            ln["ready"].set()
+            return
+        ln["ready"].set()
+        with _native.using_context(ctx):
+            while True:
+                job = ln["todo"].get()
+                if job is None:
+                    break
+                try:
+                    rs.set_firs(job["firs"])
+                    while True:
+                        with self._lock:
+                            i = job["next"]
+                            job["next"] += 1
+                        if i >= len(job["measurements"]):
+                            break
+                        recs = job["measurements"][i]
+                        t0 = time.perf_counter()
+                        rs.upload(d_rec, recs)
+                        t1 = time.perf_counter()
+                        block = rs.execute_device(d_rec, 1)
+                        t2 = time.perf_counter()
+                        rows, meas = rs.slice.results()
+                        t3 = time.perf_counter()
+                        if np.any(meas["flags"] & _native.SLICE_KEEP_CAP) and rs.grow_for(rows):
+                            block = rs.execute_device(d_rec, 1)
+
+                        def staged(m, recs=recs):
+                            jobs = [((est.fs, np.asarray(fr)), spec[2], None) for fr, spec in zip(recs, layout.files)]
+                            return run_slice(est, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=job["firs"])
+
+                        res = rs.collect(block, [recs], staged)[0]
+                        t4 = time.perf_counter()
+                        if job["to_host"]:
+                            res[0].to_host()
+                        job["out"][i] = res
+                        t5 = time.perf_counter()
+                        for k, dt in (("upload", t1 - t0), ("launch", t2 - t1), ("wait", t3 - t2), ("collect", t4 - t3),
+                                      ("to_host", t5 - t4), ("measurements", 1)):
+                            ln["times"][k] = ln["times"].get(k, 0.0) + dt
+                    ln["done"].put(None)
+                except BaseException as exc:               # noqa: BLE001 - re-raised in the caller's thread
+                    ln["done"].put(exc)
+            ctx.free(d_rec)
+            rs.close()
+            est._forget_context(ctx)
+        ctx.close()
+
+    def run(self, measurements, firs, to_host=True):
+        """[(HRIR, gain dB)] in the order of `measurements` ([[frames of file 0, ...], ...]).  firs: {(speaker, side):
+        taps}, designed once per job (the curves belong to the job, core/pipeline.py:668-688).  to_host: True = the
+        responses as float64 host arrays (as the reference's classes hold them), converted inside the workers;
+        False = left on the device."""
+        job = dict(measurements=measurements, firs=firs, to_host=to_host, next=0, out=[None] * len(measurements))
+        lanes = self.lanes[:max(1, min(len(self.lanes), len(measurements)))]
+        for ln in lanes:
+            ln["todo"].put(job)
+        errors = [e for e in (ln["done"].get() for ln in lanes) if e is not None]
+        if errors:
+            raise errors[0]
+        return job["out"]
+
+    def times(self, reset=True):
+        """seconds the lanes spent per stage since the last reset, summed over lanes: {upload, launch, wait, collect,
+        to_host, measurements}"""
+        tot = {}
+        for ln in self.lanes:
+            for k, v in ln["times"].items():
+                tot[k] = tot.get(k, 0.0) + v
+            if reset:
+                ln["times"] = {}
+        return tot
+
+    def close(self):
+        for ln in self.lanes:
+            ln["todo"].put(None)
+        for ln in self.lanes:
+            ln["thread"].join()
+        self.lanes = []
+
+
+def run_slice_jobs(estimator, layout, measurements, firs, workers=3, head_ms=1, peak_target=-0.1):
+    """one job through a SliceRunner made for it (responses on the host); callers with several jobs keep a SliceRunner"""
+    runner = SliceRunner(estimator, layout, workers=workers, head_ms=head_ms, peak_target=peak_target)
+    try:
+        return runner.run(measurements, firs, to_host=True)
+    finally:
+        runner.close()
 
 
 def _fir_taps(fs):

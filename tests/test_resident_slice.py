@@ -239,3 +239,24 @@ def test_resident_slice_full_size(config):
         for sd in o_irs[sp]:
             assert rel(got[0][0].irs[sp][sd].peek(), o_irs[sp][sd]) <= 2 * TIME_TOL, (sp, sd)
     rs.close()
+
+
+def test_run_slice_jobs_workers_overlap_and_order():
+    """A job of five measurements through run_slice_jobs (two worker threads, a context and a one-measurement slice each):
+    results in job order, each identical to the staged path of its measurement, responses on the host as float64."""
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.resident_slice import Layout, run_slice_jobs
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=fs)
+    spk = ["FL", "FR"]
+    meas = [[synth_frames(e, spk, 500 + m, rt60=0.18 + 0.02 * m)] for m in range(5)]
+    layout = Layout(e, [(meas[0][0].shape[0], 2, spk)])
+    from impulse_hip.resident_slice import _fir_taps
+    firs = synth_firs(layout.tasks, _fir_taps(fs), 3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = run_slice_jobs(e, layout, meas, firs, workers=2)
+    assert len(got) == 5
+    for m in range(5):
+        assert got[m][0].irs["FL"]["left"]._data is not None and got[m][0].irs["FL"]["left"].data.dtype == np.float64
+        assert_same_as_staged(got[m], staged_measurement(e, [(meas[m][0], spk)], firs))
