@@ -46,6 +46,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # what ANY streaming kernel moves across the L2<->fabric boundary with in-place read + write traffic on an Infinity-Cache
 # resident footprint (profiles/r02_stream_probe2.txt: 5.1 - 5.3 TB/s; K1's workspace round trips are that pattern)
 FABRIC_CEILING_GBS = 5300.0
+# gate on the whole un-cropped column's magnitude spectrum (tests/test_hip_parity.py FULL_COLUMN_TOL): the fp32 floor of
+# these column lengths is 1.1 - 2.6e-6 for any single-precision transform
+WHOLE_COLUMN_TOL = 3e-6
+WHOLE_COLUMN_SLACK = 1.25
 BROADCAST_VIA = None           # set when the in-library RCCL broadcast had to be replaced
 RCCL_RANKS_SEEN = None         # ranks the library's own communicator counted (ncclCommCount), set by spectrum_broadcast
 RCCL_COMM = None               # the rank's communicator (impulse_hip._native.Comm), made at the first broadcast
@@ -69,6 +73,16 @@ DEFAULT_BLOCKS = {"c2": 320, "c3": 96, "c4": 12, "c5": 12}
 # 8-channel groups x 2 streams 138 k IR/s, x 3: 130 k, x 1: 111 k, x 4: 119 k; groups of 4 / 6 / 12 / 16 / 32 at their best
 # 131 / 132 / 129 / 126 / 123 k - three 6.3 MB workspaces per channel in flight no longer fit beside inputs and outputs)
 CHAINS = {"c2": 3, "c3": 2, "c4": 2, "c5": 2}
+# K1's plan kind of the headline legs: pair mode (two ears per complex transform: what the classes take for ear pairs) where the
+# one-channel-per-transform plan's even/odd unpack costs accuracy on the un-cropped column (C3: 4.1e-6 against 2.3e-6, C5:
+# 3.7e-6 against 3.0e-6); at C2 both kinds sit inside the fp32 floor and the mono plan is 4 % faster.
+# The other kind runs as the secondary leg.  IMPULSE_BENCH_K1_PLAN=mono|pair overrides.
+K1_PAIRED = {"c2": False, "c3": True, "c4": False, "c5": True}
+
+
+def k1_paired(workload):
+    env = os.environ.get("IMPULSE_BENCH_K1_PLAN", "")
+    return {"mono": False, "pair": True}.get(env, K1_PAIRED[workload])
 
 
 def parse_args(argv=None):
@@ -380,7 +394,7 @@ class ChainTeam:
     peak search and K5 - tails="own" / "shared", the library supports it - measured 15 % slower: 320 k against 375 k IR/s;
     the event edges between streams cost more than the overlap buys.  tools/chain_team_rate.py.)"""
 
-    def __init__(self, contexts, est, inv, ring, L, pitch, B, firs=None, k1_plan0=None, tails="none"):
+    def __init__(self, contexts, est, inv, ring, L, pitch, B, firs=None, k1_plan0=None, tails="none", paired=False):
         from impulse_hip import Context, ConvPlan
         from impulse_hip._native import FirChain
         self.ring, self.L, self.pitch, self.B = ring, L, pitch, B
@@ -403,9 +417,9 @@ class ChainTeam:
             if i == 0 and k1_plan0 is not None:
                 plan1 = k1_plan0(ctx)                               # rank 0: from the filter; other ranks: empty + broadcast
             elif i == 0:
-                plan1 = ConvPlan(ctx, inv, L, "same", ws_channels=B, fused=False)
+                plan1 = ConvPlan(ctx, inv, L, "same", ws_channels=B, fused=False, paired=paired)
             else:
-                plan1 = ConvPlan(ctx, None, L, "same", ws_channels=B, empty_M=len(inv), n_filters=1, fused=False)
+                plan1 = ConvPlan(ctx, None, L, "same", ws_channels=B, empty_M=len(inv), n_filters=1, fused=False, paired=paired)
                 copy_spectrum(plan1, self.lanes[0]["plan1"], ctx)
             plan5 = ConvPlan(tail, self.firs, self.n, "full", ws_channels=B)
             chain = FirChain(plan1, plan5, B, self.head, self.head, self.fade)
@@ -703,6 +717,8 @@ def live_pmc_traffic(workload):
                 sys.stderr.write(f"[bench] rocprofv3 --pmc {counter} child failed (rc {res.returncode}): {res.stderr[-400:]}\n")
                 return None
         pm = pmc_summary.main(out)
+        if "rows_kernel" not in pm and "rows_single" in pm:
+            pm["rows_kernel"] = pm["rows_single"]              # pair-mode plans: rows_single_kernel is the row pass
         if not all(k in pm and "FETCH_SIZE" in pm[k] and "WRITE_SIZE" in pm[k] for k in ("rows_kernel", "cols_fwd", "cols_inv")):
             return None
         # gfx950: FETCH_SIZE counts half of a coalesced read stream (MI355X_MICROARCH.md)
@@ -855,7 +871,8 @@ def pmc_child(args):
         rec, L, pitch, _ = synth_recordings(est, g, seed0=0xC5, column=len(est))
         ctx = Context(0)
         ring = InputRing(ctx, rec, 2)
-        dec = K1Team([ctx], np.asarray(est.inverse_filter, dtype=np.float64), ring, g, L, pitch, len(est), g)
+        dec = K1Team([ctx], np.asarray(est.inverse_filter, dtype=np.float64), ring, g, L, pitch, len(est), g,
+                     paired=k1_paired(args.workload))
         for k in range(4):
             dec.call(ring.ptrs[k % 2], lane=0)
             dec.sync()
@@ -868,7 +885,7 @@ def pmc_child(args):
     ctx = Context(0)
     ring = InputRing(ctx, rec, 2)
     inv = np.asarray(est.inverse_filter, dtype=np.float64)
-    team = ChainTeam([ctx], est, inv, ring, L, pitch, B)
+    team = ChainTeam([ctx], est, inv, ring, L, pitch, B, paired=k1_paired(args.workload))
     for _ in range(3):
         team.step()
         team.sync()
@@ -958,10 +975,11 @@ def strong_block(args, torch, dist, comm_device, device, ctx, rank, world, backe
     # 8 ch x 3 lanes 132 k, 12 x 2 139 k, 12 x 3 126 k, 16 x 2 136 k IR/s)
     grp = 12
     lanes = max(1, min(args.lanes or 2, 2))
+    paired = k1_paired("c5")                              # the 384-row pair plan: inside the fp32 floor on the whole column
     if rank == 0:
-        plan = ConvPlan(ctx, np.asarray(est.inverse_filter, dtype=np.float64), M, "same", ws_channels=lanes * grp)
+        plan = ConvPlan(ctx, np.asarray(est.inverse_filter, dtype=np.float64), M, "same", ws_channels=lanes * grp, paired=paired)
     else:
-        plan = ConvPlan(ctx, None, M, "same", ws_channels=lanes * grp, empty_M=M, n_filters=1)
+        plan = ConvPlan(ctx, None, M, "same", ws_channels=lanes * grp, empty_M=M, n_filters=1, paired=paired)
     bcast = 0
     if dist is not None:
         bcast = spectrum_broadcast(plan, ctx, dist, torch, device, backend, rank, world)
@@ -1034,7 +1052,7 @@ def strong_block(args, torch, dist, comm_device, device, ctx, rank, world, backe
         out = dict(workload=WORKLOADS["c5"][3], channels=total, scaling="strong", n_gpus=world,
                    ranks_seen=dist.get_world_size() if dist is not None else 1, rccl_ranks_seen=RCCL_RANKS_SEEN,
                    channels_per_rank=hi - lo, passes=args.strong_passes, value=rate, unit="IR/s",
-                   ms_per_pass=el_n / args.strong_passes * 1e3, nfft=nfft,
+                   ms_per_pass=el_n / args.strong_passes * 1e3, nfft=nfft, plan="pair" if paired else "mono",
                    path_frac=rate / world * 8.0 * L / 1e9 / HBM_PEAK_GBS,
                    broadcast_bytes=bcast, peaks_exact_and_tiles_bit_equal=bool(flag_ok))
         if el_1 is not None:
@@ -1166,7 +1184,9 @@ def main(argv=None):
     shape = fir_stage_shape(est)
     n_fir, K_fir, head, fade = shape
     # ---------------------------------------------------------------- K1 alone (secondary; headline for C4 / C5)
-    dec = K1Team(contexts, inv, ring, B, L, pitch, M, group_channels, plan0=lambda c: k1_plan(c, group_channels))
+    main_paired = k1_paired(args.workload)
+    dec = K1Team(contexts, inv, ring, B, L, pitch, M, group_channels, plan0=lambda c: k1_plan(c, group_channels, main_paired),
+                 paired=main_paired)
     dec_steps = args.steps if stage == "deconv" else max(2, args.steps // 4)
     groups_per_call = -(-B // group_channels)
     groups_timed = dec_steps * n_blocks * groups_per_call
@@ -1193,26 +1213,28 @@ def main(argv=None):
     nfft, plan_ws, skew = dec.plan.nfft, dec.plan.ws_channels * len(contexts), dec.skew
     dec.release()
     dec_rate_rank = irs_per_step_rank * dec_steps / dec_elapsed
-    # pair mode on the same planar rows (two channels per complex transform), where the lengths allow it
-    pair_block = None
-    if not strong and rank == 0 and world == 1:
+    # the other plan kind on the same planar rows (pair mode = two channels per complex transform, where the lengths allow it)
+    pair_block, y_pair = None, None
+    if rank == 0 and world == 1:
         try:
             from impulse_hip._native import plan_geometry_paired
-            if plan_geometry_paired(M, L, "same") is not None:
-                pdec = K1Team(contexts, inv, ring, B, L, pitch, M, group_channels, paired=True)
+            if main_paired or plan_geometry_paired(M, L, "same") is not None:
+                pdec = K1Team(contexts, inv, ring, B, L, pitch, M, group_channels, paired=not main_paired)
                 psteps = max(2, args.steps // 4)
                 pel = timed_steps(pdec, psteps, 1)
                 pys = pdec.outputs()
+                y_pair = pys[-1]
                 p_ok = all(int(np.argmax(np.abs(yy[c]))) == M // 2 + delays[c] for yy in pys for c in range(B))
                 peaks_ok &= p_ok
                 prate = irs_per_step_rank * psteps / pel
-                pair_block = dict(value=prate, unit="IR/s", rows=pdec.plan.n1, path_frac=prate * 8.0 * L / 1e9 / HBM_PEAK_GBS,
-                                  peak_indices_exact=bool(p_ok), max_rel_diff_vs_mono=float(
+                pair_block = dict(plan="mono" if main_paired else "pair", value=prate, unit="IR/s", rows=pdec.plan.n1,
+                                  path_frac=prate * 8.0 * L / 1e9 / HBM_PEAK_GBS,
+                                  peak_indices_exact=bool(p_ok), max_rel_diff_vs_headline_plan=float(
                                       np.max(np.abs(pys[-1].astype(np.float64) - y_k1)) / np.max(np.abs(y_k1))),
-                                  note="K1 in pair mode on the same planar rows: channels (2q, 2q + 1) as ONE complex signal "
-                                       "x_L + i x_R, pointwise H in the row pass (rows_single_kernel); same circular length, "
-                                       "same workspace bytes - DESIGN.md section 7 has the per-pass times and why both modes "
-                                       "meet the same fabric ceiling")
+                                  note="K1 with the OTHER plan kind on the same planar rows.  pair = channels (2q, 2q + 1) as ONE "
+                                       "complex signal x_L + i x_R, pointwise H in the row pass (rows_single_kernel); mono = one "
+                                       "channel per transform, even/odd packed; same circular length, same workspace bytes - "
+                                       "DESIGN.md section 7 has the per-pass times and why both meet the same fabric ceiling")
                 pdec.release()
         except Exception as exc:                              # noqa: BLE001 - secondary figure only
             pair_block = dict(error=repr(exc))
@@ -1221,7 +1243,7 @@ def main(argv=None):
     team, chain_elapsed, chain_k1, chain_k5, firs = None, None, None, None, None
     y_chain = pk_chain = None
     if stage == "chain":
-        team = ChainTeam(contexts, est, inv, ring, L, pitch, B, k1_plan0=lambda c: k1_plan(c, B),
+        team = ChainTeam(contexts, est, inv, ring, L, pitch, B, k1_plan0=lambda c: k1_plan(c, B, main_paired), paired=main_paired,
                          tails=os.environ.get("IMPULSE_BENCH_CHAIN_TAILS", "none"))
         team.step()
         barrier(team)
@@ -1246,6 +1268,13 @@ def main(argv=None):
         strong_c5, s_ok = strong_block(args, torch, dist, comm_device, device, ctx, rank, world, backend)
         peaks_ok &= s_ok
 
+    # every leg's GPU objects are released: close their streams before the host-side report - the slice legs below bring
+    # streams of their own, and a HIP process has four hardware queues (more streams than that are multiplexed)
+    if RCCL_COMM is not None:
+        RCCL_COMM.close()
+    for c in reversed(contexts):
+        c.close()
+    contexts = []
     if rank == 0:
         irs_per_step = irs_per_step_rank * world
         steps_timed = args.steps if stage == "chain" else dec_steps
@@ -1258,7 +1287,8 @@ def main(argv=None):
         pmc_group = group_channels if strong else B
         alg_k1_launch = 8.0 * L * timed_group                            # algorithmic bytes of one timed K1 launch group
         alg_chain_ir = 4.0 * L + 4.0 * (n_fir + K_fir - 1)                # recording in, equalised cropped response out
-        names = ("cols_kernel<fwd> (K1 pass A)", "rows_kernel (K1 pass B)", "cols_kernel<inv> (K1 pass C)")
+        names = ("cols_kernel<fwd> (K1 pass A)", ("rows_single_kernel" if main_paired else "rows_kernel") + " (K1 pass B)",
+                 "cols_kernel<inv> (K1 pass C)")
         # per-kernel times over the TIMED region: from the chains' K1 plans when the chain is what is timed
         t_ms, t_n = (chain_k1 if stage == "chain" else (np.asarray(k1_ms), k1_n))
         roof = None
@@ -1330,25 +1360,36 @@ def main(argv=None):
         if world == 1 and not args.no_cpu_baseline:
             with_fir = stage == "chain"
             cpu, outs = cpu_baseline(est, rec, L, firs, shape, with_fir)
-            errs, errs_full, chain_errs = [], [], []
+            errs, errs_full, errs_full_pair, chain_errs = [], [], [], []
             for c, (ref, pk_ref, ref_out) in outs.items():
                 pk = int(np.argmax(np.abs(ref)))
                 peaks_ok &= pk == int(np.argmax(np.abs(y_k1[c])))
                 for sl, acc in ((slice(pk - fs // 1000, pk - fs // 1000 + int(0.68 * fs)), errs), (slice(None), errs_full)):
                     A, R = np.abs(np.fft.rfft(y_k1[c][sl].astype(np.float64))), np.abs(np.fft.rfft(ref[sl]))
                     acc.append(float(np.max(np.abs(A - R)) / np.max(R)))
+                if y_pair is not None:
+                    A, R = np.abs(np.fft.rfft(y_pair[c].astype(np.float64))), np.abs(np.fft.rfft(ref))
+                    errs_full_pair.append(float(np.max(np.abs(A - R)) / np.max(R)))
                 if with_fir:
                     peaks_ok &= int(pk_chain[c]) == pk_ref
                     chain_errs.append(float(np.max(np.abs(y_chain[c] - ref_out)) / np.max(np.abs(ref_out))))
-            floor = fp32_fft_floor(est, rec[0], L)
+            floors = {c: fp32_fft_floor(est, rec[c], L) for c in outs}
+            floor = max(v for v in floors.values() if v is not None) if any(v is not None for v in floors.values()) else None
+            column_gate = max(WHOLE_COLUMN_TOL, WHOLE_COLUMN_SLACK * floor) if floor else WHOLE_COLUMN_TOL
             parity = dict(peak_indices_exact=bool(peaks_ok), spectrum_max_rel_err=max(errs), tolerance=1e-6,
                           spectrum_window="IR cropped as the pipeline does before any magnitude_response: peak - 1 ms, 0.68 s long",
-                          whole_column_spectrum_max_rel_err=max(errs_full),
+                          whole_column_spectrum_max_rel_err=max(errs_full), whole_column_plan="pair" if main_paired else "mono",
+                          whole_column_other_plan_max_rel_err=max(errs_full_pair) if errs_full_pair else None,
+                          whole_column_gate=column_gate,
                           whole_column_meets_1e_6=bool(max(errs_full) <= 1e-6),
                           whole_column_pocketfft_fp32_err=floor,
-                          whole_column_note=f"un-cropped {L}-sample column: above 1e-6 for every fp32 transform (the "
-                                            "reference's own pocketfft in single precision is listed beside it); reported, "
-                                            "not gated",
+                          whole_column_note=f"un-cropped {L}-sample column (the function's own output): north_star's 1e-6 is not "
+                                            "reachable in fp32 - the transform's white rounding noise gains sqrt(L) in the spectrum - "
+                                            "every fp32 transform sits at 1 - 2.5e-6 (the reference's own pocketfft in single "
+                                            "precision, run on the SAME channels, is listed beside it: maximum over them).  GATED: the "
+                                            f"headline plan's maximum <= max({WHOLE_COLUMN_TOL:g}, {WHOLE_COLUMN_SLACK:g} x pocketfft-fp32's "
+                                            "maximum) - the statistic is a maximum over 2 - 5 x 10^5 bins of white noise and moves by "
+                                            "up to 2x between channels of one transform; the other plan kind is reported",
                           channels_checked=len(errs))
             if with_fir:
                 parity["chain_time_max_rel_err"] = max(chain_errs)
@@ -1360,6 +1401,7 @@ def main(argv=None):
             except Exception as exc:                          # noqa: BLE001 - reported figure only
                 parity["real_demo_column"] = dict(error=repr(exc))
             peaks_ok &= max(errs) <= 1e-6
+            peaks_ok &= max(errs_full) <= column_gate
             parity["peak_indices_exact"] = bool(peaks_ok)
         whole_slice = slice_res = None
         if world == 1 and args.workload == "c2" and not args.no_cpu_baseline and not args.no_slice:
@@ -1408,16 +1450,13 @@ def main(argv=None):
                                 path_frac=dec_value / world * 8.0 * L / 1e9 / HBM_PEAK_GBS,
                                 layout=f"planar fp32; output rows start {skew} samples into 256-byte aligned buffers so the "
                                        "cropped stores fall on cache lines",
-                                note="K1 alone over the same resident inputs (last round's headline), algorithmic bytes 8 L per IR",
-                                pair_mode=pair_block),
+                                plan="pair" if main_paired else "mono",
+                                note="K1 alone over the same resident inputs, algorithmic bytes 8 L per IR",
+                                other_plan=pair_block),
             "slice": whole_slice, "slice_resident": slice_res, "strong_c5": strong_c5,
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
-    if RCCL_COMM is not None:
-        RCCL_COMM.close()
-    for c in reversed(contexts):
-        c.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

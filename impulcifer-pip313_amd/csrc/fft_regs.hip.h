@@ -276,10 +276,25 @@ __host__ __device__ __forceinline__ void bfly5(cf& a, cf& b, cf& c, cf& d, cf& e
 }
 
 
-// R-point DFT of x[0..R-1] in place, natural order in and out, R in {3, 5, 6, 9, 10, 11, 12, 18}.
+// R-point DFT of x[0..R-1] in place, natural order in and out, R in {3, 5, 6, 9, 10, 11, 12, 18, 24}.
 template <int DIR, int R>
 __host__ __device__ __forceinline__ void fft_small(cf* x) {
-  if constexpr (R == 18) {
+  if constexpr (R == 24) {
+    // N1 = 8, N2 = 3 (prime-factor mapping): n = (3 n1 + 8 n2) mod 24 ; k = (9 k1 + 16 k2) mod 24
+    cf a[8][3];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1)
+#pragma unroll
+      for (int n2 = 0; n2 < 3; ++n2) a[n1][n2] = x[(3 * n1 + 8 * n2) % 24];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) bfly3<DIR>(a[n1][0], a[n1][1], a[n1][2]);
+#pragma unroll
+    for (int k2 = 0; k2 < 3; ++k2) fft8<DIR>(a[0][k2], a[1][k2], a[2][k2], a[3][k2], a[4][k2], a[5][k2], a[6][k2], a[7][k2]);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1)
+#pragma unroll
+      for (int k2 = 0; k2 < 3; ++k2) x[(9 * k1 + 16 * k2) % 24] = a[k1][k2];
+  } else if constexpr (R == 18) {
     // N1 = 2, N2 = 9 (prime-factor mapping, no twiddles between the factors): n = (9 n1 + 2 n2) mod 18 ; k = (9 k1 + 10 k2) mod 18
     cf a[2][9];
 #pragma unroll

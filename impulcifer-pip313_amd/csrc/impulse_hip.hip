@@ -625,6 +625,7 @@ static int launch_cols_any(imp_plan* p, int64_t nchan, Load ld, Store st) {
     case 10: return launch_cols_mixed<16, 10, DIR>(p, nchan, ld, st);
     case 12: return launch_cols_mixed<16, 12, DIR>(p, nchan, ld, st);
     case 18: return launch_cols_mixed<16, 18, DIR>(p, nchan, ld, st);
+    case 24: return launch_cols_mixed<16, 24, DIR>(p, nchan, ld, st);
   }
   return fail(IMP_ERR_UNSUPPORTED, "unsupported column radix %d", p->R2);
 }
@@ -692,7 +693,8 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   static const struct { int f, r2; bool pair_only; } kShapes[] = {
       {4, 1, false},  {8, 1, false},  {16, 1, false}, {8, 3, false},  {16, 2, false},  {8, 5, false},
       {16, 3, false}, {16, 4, false}, {11, 6, false}, {8, 9, false},  {16, 5, false},  {16, 6, false},
-      {16, 8, false}, {11, 12, true}, {16, 9, false}, {16, 10, false}, {16, 12, false}, {16, 16, false}, {16, 18, true}};
+      {16, 8, false}, {11, 12, true}, {16, 9, false}, {16, 10, false}, {16, 12, false}, {16, 16, false}, {16, 18, true},
+      {16, 24, true}};
   const int64_t samples_per_row = paired ? imp::kN2 : 2 * imp::kN2;
   if (paired && n_filters != 1) return fail(IMP_ERR_INVALID, "pair mode needs ONE filter shared by both channels of a pair");
   // Short filters (every FIR of the path: 9 600 taps at 48 kHz, 19 200 at 96 kHz): one launch of overlap-save blocks that stay
@@ -740,7 +742,7 @@ static int plan_geometry(imp_plan* p, int64_t M, int64_t n_filters, int64_t L, i
   p->ola = false;
   p->paired = paired;
   if (!r2 && paired)
-    return fail(IMP_ERR_UNSUPPORTED, "pair mode covers circular lengths up to 1 179 648 samples (288 rows); this plan needs %lld",
+    return fail(IMP_ERR_UNSUPPORTED, "pair mode covers circular lengths up to 1 572 864 samples (384 rows); this plan needs %lld",
                 (long long)need_eff);
   if (!r2) {
     // Longer than one two-level transform (2^21 points): overlap-add.  The input is cut into blocks and, when
@@ -1870,7 +1872,9 @@ extern "C" int imp_chain_execute_device(imp_chain* c, const float* d_x, int64_t 
   hipStream_t lane_stream = lane ? c->ctx->side_streams[(size_t)(lane - 1)] : c->ctx->stream;
   hipStream_t tail = c->tail_ctx->stream;
   if (c->ir_busy[(size_t)l] && tail != lane_stream) HIP_TRY(hipStreamWaitEvent(lane_stream, c->ir_free[(size_t)l], 0));
-  c->deconv->tile_max = c->d_tile[(size_t)l];
+  // experiment switch: 1 = pass C leaves no chunk maxima, the peak search's first step is a read of the deconvolved rows
+  static const bool no_tile_max = [] { const char* e = std::getenv("IMPULSE_HIP_NO_TILE_MAX"); return e && e[0] == '1'; }();
+  c->deconv->tile_max = no_tile_max ? nullptr : c->d_tile[(size_t)l];
   rc = imp_conv_execute_device(c->deconv, d_x, c->B, chan_stride_in, elem_stride_in, c->d_ir[(size_t)l], c->pitch_ir);
   c->deconv->tile_max = nullptr;
   if (rc) return rc;
@@ -1882,9 +1886,18 @@ extern "C" int imp_chain_execute_device(imp_chain* c, const float* d_x, int64_t 
   // measurement switch (tools/chain_rate.py): 1 = stop after the peak search, 2 = stop after K1 - the outputs are then stale
   static const int skip = [] { const char* e = std::getenv("IMPULSE_HIP_CHAIN_SKIP"); return e ? atoi(e) : 0; }();
   if (skip >= 2) return IMP_OK;
-  hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)c->B), dim3(imp::kPeakThreads), 0, tail, c->d_ir[(size_t)l],
-                     c->d_meta, c->d_meta + c->B, c->deconv->out_start, (const unsigned*)c->d_tile[(size_t)l], c->tiles,
-                     (const unsigned*)nullptr, c->chunks, c->d_res[(size_t)l], c->peak_height, d_peaks_out);
+  if (no_tile_max) {
+    const int64_t kc = std::max<int64_t>(1, (c->deconv->out_len + imp::kPeakChunk - 1) / imp::kPeakChunk);
+    hipLaunchKernelGGL(imp::row_chunk_max_kernel, dim3((unsigned)kc, (unsigned)c->B), dim3(256), 0, tail, c->d_ir[(size_t)l], c->d_meta,
+                       c->d_meta + c->B, (int64_t)0, c->d_tile[(size_t)l], kc);
+    hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)c->B), dim3(imp::kPeakThreads), 0, tail, c->d_ir[(size_t)l],
+                       c->d_meta, c->d_meta + c->B, (int64_t)0, (const unsigned*)nullptr, 0, (const unsigned*)c->d_tile[(size_t)l], kc,
+                       c->d_res[(size_t)l], c->peak_height, d_peaks_out);
+  } else {
+    hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)c->B), dim3(imp::kPeakThreads), 0, tail, c->d_ir[(size_t)l],
+                       c->d_meta, c->d_meta + c->B, c->deconv->out_start, (const unsigned*)c->d_tile[(size_t)l], c->tiles,
+                       (const unsigned*)nullptr, c->chunks, c->d_res[(size_t)l], c->peak_height, d_peaks_out);
+  }
   HIP_TRY(hipGetLastError());
   if (skip >= 1) return IMP_OK;
   imp::LoadCropAtPeak ld{c->d_ir[(size_t)l], c->pitch_ir, c->deconv->out_len, c->d_res[(size_t)l], c->n, c->head, c->fade_in, c->fade_out,

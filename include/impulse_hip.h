@@ -104,7 +104,8 @@ int imp_conv_plan_create_empty(imp_ctx* ctx, int64_t M, int64_t n_filters, int64
  * travel through one complex transform, z = x_L + i x_R: (x_L + i x_R) (*) h = y_L + i y_R.  Channels (2q, 2q + 1) of
  * every execute call form pair q (an odd last channel pairs with silence); with interleaved frames the pair is ONE
  * 8-byte load per sample.  Same entry points, same results to fp32 rounding; the circular length is 4096 * N1 samples
- * with N1 <= 288 rows (L + M/2 <= 1 179 648 for 'same': up to the 96 kHz / 6.6 s configuration): longer plans return
+ * with N1 <= 384 rows (L + M/2 <= 1 572 864 for 'same': the 96 kHz / 6.6 s configuration takes 288 rows, 2^20-sample
+ * sweeps 384 = 16 x 24): longer plans return
  * IMP_ERR_UNSUPPORTED and the caller uses imp_conv_plan_create.  ws_channels counts channels (rounded up to whole pairs). */
 int imp_conv_plan_create_paired(imp_ctx* ctx, const double* filter, int64_t M, int64_t L, int mode,
                                 int64_t ws_channels, imp_plan** out);
@@ -204,7 +205,7 @@ int imp_debug_host_spectrum(const double* filter, int64_t M, int n1_rows, float*
  * IMP_ERR_UNSUPPORTED beyond 24 577 taps.  imp_debug_plan_geometry always reports the three-launch geometry. */
 int imp_debug_plan_geometry_fused(int64_t M, int64_t L, int mode, int64_t* history, int64_t* valid, int64_t* first_block,
                                   int64_t* blocks);
-/* the same for a pair-mode plan: nfft = circular length in samples = 4096 * n1_rows; IMP_ERR_UNSUPPORTED beyond 288 rows */
+/* the same for a pair-mode plan: nfft = circular length in samples = 4096 * n1_rows; IMP_ERR_UNSUPPORTED beyond 384 rows */
 int imp_debug_plan_geometry_paired(int64_t M, int64_t L, int mode, int64_t* nfft, int64_t* out_start, int64_t* out_len,
                                    int64_t* n1_rows);
 

@@ -23,12 +23,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 SPEC_TOL = 1e-6            # max |dA| / max |A| on |rfft(cropped ir)|  (and on whole noise-like outputs)
-# The same metric on an UN-CROPPED sweep-recording column at 48 kHz (1.0 s and 6.15 s sweeps: the only sizes it is asserted
-# on).  Measured floor of every fp32 transform there (profiles/r03_column_error.txt): this path 1.2-2.3e-6
-# depending on the plan's row count, pocketfft in single precision 2.5e-6 on the same input.  A maximum over 2-4 x 10^5 bins
-# of white rounding noise (time-domain rms 3-5e-10 of the peak), it moves by up to 2x between channels of one plan.  Nothing
-# the reference computes sees it: magnitude_response only ever runs on cropped responses (SPEC_TOL).  C3 / C5 whole-column
-# figures are reported by bench.py, not asserted (the C3 excess is located in DESIGN.md section 5).
+# The same metric on an UN-CROPPED sweep-recording column.  north_star's 1e-6 is not reachable there in fp32: measured floor
+# of every fp32 transform (profiles/r04_column_error.txt): this path 1.1-2.3e-6 in pair mode (the plan the
+# classes take for ear pairs) at C2, C3 and C5, pocketfft in single precision 2.1-2.5e-6 on the same inputs.  A maximum over
+# 2-5 x 10^5 bins of white rounding noise (time-domain rms 3-5e-10 of the peak), it moves by up to 2x between channels of one
+# plan.  Nothing the reference computes sees it: magnitude_response only ever runs on cropped responses (SPEC_TOL).  Asserted
+# at all three BASELINE shapes (tests/test_pair_mode.py::test_whole_column_at_the_fp32_floor) and gated by bench.py.
 FULL_COLUMN_TOL = 3e-6
 TIME_TOL = 1e-6            # max |dy| / max |y|
 
@@ -1531,7 +1531,18 @@ def test_bench_contract_line(gpu_ctx):
     assert d["value"] > 100 * c["value"]
     k1 = d["deconv_only"]
     assert k1["value"] > d["value"] and 0 < k1["path_frac"] < 1
-    assert k1["pair_mode"]["peak_indices_exact"] and k1["pair_mode"]["rows"] == 132 and k1["pair_mode"]["max_rel_diff_vs_mono"] < 2e-6
+    other = k1["other_plan"]
+    assert k1["plan"] == "mono" and other["plan"] == "pair" and other["peak_indices_exact"] and other["rows"] == 132
+    assert other["max_rel_diff_vs_headline_plan"] < 2e-6
+    # the function's own output, the whole column: gated against the fp32 floor measured on the same channels
+    assert p["whole_column_spectrum_max_rel_err"] <= p["whole_column_gate"] <= 1.25 * max(p["whole_column_pocketfft_fp32_err"], 3e-6)
+    # the reference's real stage order, device resident (imp_slice): bit-identical to the staged class path, nothing flagged
+    sr = d["slice_resident"]
+    assert sr["bit_identical_to_staged_path"] and sr["no_measurement_flagged"] and sr["value"] > 100e3
+    assert sr["l2_fabric_traffic"]["source"] == "live" and sr["l2_fabric_traffic"]["over_algorithmic"] > 1
+    assert "ceiling_frac" in r and 0 < r["ceiling_frac"] < 0.4
+    assert d["slice"]["identical_to_staged_path"] and d["slice"]["value"] > 0
+    assert isinstance(cfg["environment_switches"], dict)
 
 
 def test_bench_two_ranks_started_plainly(gpu_ctx):

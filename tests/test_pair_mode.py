@@ -21,11 +21,14 @@ def test_pair_plan_geometry_needs_no_gpu():
     # C3 (96 kHz): 1 145 947 samples -> 280 rows -> the 288-row plan (16 x 18), the same circular length as the mono plan's 144
     assert plan_geometry_paired(635965, 827965, "same") == (288 * 4096, (635965 - 1) // 2, 827965, 288)
     assert plan_geometry(635965, 827965, "same")[0] == 288 * 4096
-    # C5 (2^20 x 2^20) needs 384 rows: not available, the caller keeps the mono plan
-    assert plan_geometry_paired(1 << 20, 1 << 20, "same") is None
+    # C5 (2^20 x 2^20): 1 572 864 samples -> 384 rows (16 x 24), the same circular length as the mono plan's 192
+    assert plan_geometry_paired(1 << 20, 1 << 20, "same") == (384 * 4096, ((1 << 20) - 1) // 2, 1 << 20, 384)
+    assert plan_geometry(1 << 20, 1 << 20, "same")[0] == 384 * 4096
+    # beyond that pair mode is not available, the caller keeps the mono plan
+    assert plan_geometry_paired(1 << 20, 3 << 19, "same") is None
 
 
-# every column shape of pair mode: N1 = 4, 4, 8, 16, 24, 32, 40, 48, 64, 66, 72, 80, 96, 128, 132, 144, 160, 192, 256, 288 (C3)
+# every column shape of pair mode: N1 = 4, 4, 8, 16, 24, 32, 40, 48, 64, 66, 72, 80, 96, 128, 132, 144, 160, 192, 256, 288 (C3), 384 (C5)
 @pytest.mark.gpu
 @pytest.mark.parametrize("L,M,mode", [(1, 1, "same"), (17, 5, "full"), (20000, 9600, "full"), (32640, 9600, "full"),
                                       (70001, 61000, "same"), (100000, 30000, "full"), (150000, 20000, "same"),
@@ -33,7 +36,7 @@ def test_pair_plan_geometry_needs_no_gpu():
                                       (270000, 60000, "same"), (300000, 50000, "same"), (300000, 150000, "same"),
                                       (391270, 200000, "same"), (391270, 295270, "same"), (500000, 150000, "same"),
                                       (500000, 300000, "same"), (500000, 250000, "full"), (800000, 400000, "same"),
-                                      (827965, 635965, "same")])
+                                      (827965, 635965, "same"), (1 << 20, 1 << 20, "same")])
 def test_pair_conv_matches_oracle(gpu_ctx, L, M, mode):
     from impulse_hip import ConvPlan
     from impulse_hip._native import plan_geometry_paired
@@ -210,8 +213,8 @@ def test_pair_plan_refill_and_errors(gpu_ctx):
     with pytest.raises(ValueError):
         ConvPlan(gpu_ctx, np.stack([h1, h2]), L, "full", paired=True)          # per-channel filters cannot pair
     with pytest.raises(NativeError):
-        ConvPlan(gpu_ctx, rng.standard_normal(1 << 20), 1 << 20, "same", paired=True)   # C5: beyond 288 rows
-    auto = ConvPlan(gpu_ctx, rng.standard_normal(1 << 20), 1 << 20, "same", paired="auto")
+        ConvPlan(gpu_ctx, rng.standard_normal(1 << 20), 3 << 19, "same", paired=True)   # beyond 384 rows
+    auto = ConvPlan(gpu_ctx, rng.standard_normal(1 << 20), 3 << 19, "same", paired="auto")
     assert not auto.paired
     auto.close()
     mono = ConvPlan(gpu_ctx, h1, L, "full")
@@ -265,3 +268,37 @@ def test_pair_mode_c3_size_all_loaders(gpu_ctx):
         whole_pair, whole_mono = spec_rel(y_planar[c], ref), spec_rel(y_mono[c], ref)
         print(f"C3 whole column ch{c}: pair mode {whole_pair:.2e}, mono plan {whole_mono:.2e}")
         assert whole_pair <= FULL_COLUMN_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["c2", "c3", "c5"])
+def test_whole_column_at_the_fp32_floor(gpu_ctx, config):
+    """The function's own output - the whole un-cropped column of estimate() (core/impulse_response_estimator.py:149-151) -
+    on BASELINE's three K1 shapes, through the plan the classes take for ear pairs (pair mode: 132 / 288 / 384 rows): the
+    magnitude spectrum against the float64 oracle.  north_star's 1e-6 is not reachable on these columns in fp32: the
+    transform's white rounding noise (time-domain rms 3 - 5e-10 of the peak) gains sqrt(L) in the spectrum, and the maximum over
+    2 - 5 x 10^5 bins lands at 1.1 - 2.3e-6 here, 1.3 - 2.5e-6 for the reference's own pocketfft in single precision (measured
+    in this test on the same channels; the statistic moves by up to 2x between channels of one transform).  Gated: every
+    channel within FULL_COLUMN_TOL, and the mean over the channels within 1.25 x pocketfft-fp32's (C2 and C5 sit below
+    it, C3 15 % above); the cropped window (all the reference ever transforms) stays within SPEC_TOL."""
+    import bench
+    from impulse_hip import ConvPlan
+    from oracle.estimator import estimate
+    est = bench.make_estimator(config)
+    fs = est.fs
+    rec, L, pitch, delays = bench.synth_recordings(est, 2, seed0=0xC2, column=(len(est) if config == "c5" else None))
+    inv = np.asarray(est.inverse_filter, dtype=np.float64)
+    plan = ConvPlan(gpu_ctx, inv, L, "same", paired=True)
+    assert plan.paired and plan.n1 == {"c2": 132, "c3": 288, "c5": 384}[config]
+    y = plan.execute(rec[:, :L])
+    plan.close()
+    ours, floor = [], []
+    for c in range(2):
+        ref = estimate(rec[c, :L].astype(np.float64), inv)
+        assert int(np.argmax(np.abs(y[c]))) == int(np.argmax(np.abs(ref)))
+        assert spec_rel_cropped(y[c], ref, fs=fs) <= SPEC_TOL
+        ours.append(spec_rel(y[c], ref))
+        floor.append(bench.fp32_fft_floor(est, rec[c], L))
+    print(f"{config} whole column: this path {ours}, pocketfft fp32 {floor}")
+    assert max(ours) <= FULL_COLUMN_TOL
+    assert np.mean(ours) <= 1.25 * np.mean(floor)
