@@ -231,7 +231,8 @@ def slice_rate(est, rec, L, reps=24, workers=3):
     runner = SliceRunner(est, layout, workers=workers)       # lanes (context + slice each) live across jobs
 
     def job(n, to_host=True):
-        firs = {(sp, sd): fir for sp, sd, fir in process_equalization_batch(layout.tasks, None, None, None, None, None, target, common, fs)}
+        firs = {(sp, sd): fir for sp, sd, fir in process_equalization_batch(layout.tasks, None, None, None, None, None, target, common, fs,
+                                                                            on_device=True)}
         return runner.run([[frames]] * n, firs, to_host=to_host), firs
 
     import warnings

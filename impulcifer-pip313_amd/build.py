@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libimpulse_hip.so")
 SOURCES = ["impulse_hip.hip", "minphase.hip", "curves.hip", "comm.hip"]
 HEADERS = ["conv_kernels.hip.h", "xcd_kernels.hip.h", "fft_regs.hip.h", "ir_kernels.hip.h", "decay_kernels.hip.h",
-           "slice_kernels.hip.h", "slice_host.hip.inc", "internal.h",
+           "slice_kernels.hip.h", "slice_host.hip.inc", "fft64.hip.h", "internal.h",
            os.path.join("..", "..", "include", "impulse_hip.h")]
 
 

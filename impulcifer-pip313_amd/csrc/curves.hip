@@ -573,7 +573,8 @@ static int curves_fir_grid(imp_curves* c, double fs, double f_res, imp_curves::F
   return IMP_OK;
 }
 
-int minphase_fir_from_device_gain(imp_ctx* ctx, const double* d_gain, int64_t B, int64_t n, double fs, double* fir_out_host);
+int minphase_fir_from_device_gain(imp_ctx* ctx, const double* d_gain, int64_t B, int64_t n, double fs, double* fir_out_host,
+                                  double* d_fir_out);
 
 extern "C" int imp_curves_fir_taps(imp_curves* c, double fs, double f_res, int64_t* ntaps) {
   if (!c || !ntaps) return fail(IMP_ERR_INVALID, "imp_curves_fir_taps: null argument");
@@ -588,7 +589,7 @@ extern "C" int imp_curves_fir_taps(imp_curves* c, double fs, double f_res, int64
 
 // equalization curves (host, or the device result of the previous step when eq == NULL) -> minimum-phase FIRs
 static int curves_fir_from(imp_curves* c, const double* d_eq, int64_t B, double fs, double f_res, int normalize,
-                           double* gain_out, double* fir_out) {
+                           double* gain_out, double* fir_out, double* d_fir_out = nullptr) {
   imp_curves::FirGrid g;
   int rc = curves_fir_grid(c, fs, f_res, &g);
   if (rc) return rc;
@@ -615,7 +616,7 @@ static int curves_fir_from(imp_curves* c, const double* d_eq, int64_t B, double 
   hipLaunchKernelGGL(curves_fir_gain_kernel, dim3((unsigned)B, tiles), dim3(kT), (size_t)c->n * sizeof(double), s, a);
   HIP_TRY(hipGetLastError());
   if (gain_out) HIP_TRY(hipMemcpyAsync(gain_out, c->d_gain, need * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (fir_out) return minphase_fir_from_device_gain(c->ctx, c->d_gain, B, g.ntaps, fs, fir_out);
+  if (fir_out || d_fir_out) return minphase_fir_from_device_gain(c->ctx, c->d_gain, B, g.ntaps, fs, fir_out, d_fir_out);
   HIP_TRY(hipStreamSynchronize(s));
   return IMP_OK;
 }
@@ -649,4 +650,38 @@ extern "C" int imp_curves_equalization_fir(imp_curves* c, const double* error, i
   if (equalization_out)
     HIP_TRY(hipMemcpyAsync(equalization_out, c->d_c, (size_t)B * c->n * sizeof(double), hipMemcpyDeviceToHost, c->ctx->stream));
   return curves_fir_from(c, c->d_c, B, fs, f_res, normalize, nullptr, fir_out);
+}
+
+// the whole worker with the FIRs LEFT ON THE DEVICE: *d_fir_out = [B][ntaps] fp64 in a block of the context's pool (the
+// caller hands it back with imp_free); nothing waits for the device unless equalization_out is asked for
+extern "C" int imp_curves_equalization_fir_device(imp_curves* c, const double* error, int64_t B, int smoothen_first, double max_gain,
+                                                  double treble_f_lower, double treble_f_upper, double treble_max_gain,
+                                                  double treble_gain_k, int smoothen_kinks, double fs, double f_res, int normalize,
+                                                  double* equalization_out, void** d_fir_out, int64_t* ntaps_out) {
+  if (!c || !d_fir_out || (B && !error)) return fail(IMP_ERR_INVALID, "imp_curves_equalization_fir_device: null argument");
+  *d_fir_out = nullptr;
+  if (B < 1) return fail(IMP_ERR_INVALID, "B < 1");
+  IMP_CTX_LOCK(c->ctx);
+  int rc = ctx_bind(c->ctx);
+  if (rc) return rc;
+  imp_curves::FirGrid g;
+  if ((rc = curves_fir_grid(c, fs, f_res, &g))) return rc;
+  if (ntaps_out) *ntaps_out = g.ntaps;
+  void* d_fir = nullptr;
+  if ((rc = ctx_block_get(c->ctx, (size_t)B * g.ntaps * sizeof(double), &d_fir))) return rc;
+  rc = curves_equalization_device(c, error, B, smoothen_first, max_gain, treble_f_lower, treble_f_upper, treble_max_gain,
+                                  treble_gain_k, smoothen_kinks);
+  if (!rc && equalization_out) {
+    if (hipMemcpyAsync(equalization_out, c->d_c, (size_t)B * c->n * sizeof(double), hipMemcpyDeviceToHost, c->ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(c->ctx->stream) != hipSuccess)
+      rc = fail(IMP_ERR_HIP, "imp_curves_equalization_fir_device: download failed");
+  }
+  if (!rc) rc = curves_fir_from(c, c->d_c, B, fs, f_res, normalize, nullptr, nullptr, (double*)d_fir);
+  if (rc) {
+    (void)hipStreamSynchronize(c->ctx->stream);
+    (void)ctx_block_put(c->ctx, d_fir);
+    return rc;
+  }
+  *d_fir_out = d_fir;
+  return IMP_OK;
 }

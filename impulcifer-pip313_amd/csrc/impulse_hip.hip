@@ -851,11 +851,16 @@ extern "C" int imp_conv_plan_create_empty_paired(imp_ctx* ctx, int64_t M, int64_
   return plan_create_empty_impl(ctx, M, 1, L, mode, ws_channels, true, out);
 }
 
-// the plan's spectrum planes from host filters (fp64 on the device, rounded once); work in flight must be drained
-static int plan_fill_spectrum(imp_plan* p, const double* filter, int64_t filter_ld) {
+// the plan's spectrum planes from host filters (fp64 on the device, rounded once); work in flight must be drained.
+// on_device: the filters are device memory (mono / fused plans without overlap-add): nothing is uploaded and nothing waits.
+static int plan_fill_spectrum(imp_plan* p, const double* filter, int64_t filter_ld, bool on_device = false) {
   imp_ctx* ctx = p->ctx;
   const int64_t M = p->M, n_filters = p->n_filters;
   const int64_t ld = n_filters > 1 ? filter_ld : M;
+  if (on_device) {
+    if (p->paired || p->ola) return fail(IMP_ERR_UNSUPPORTED, "device filters: mono and fused plans without overlap-add");
+    return spectrum_alpha_beta_device(ctx, filter, M, n_filters, ld, p->Nc, p->N1, p->ab, true);
+  }
   if (p->paired) return spectrum_pair_device(ctx, filter, M, p->Nc, p->N1, p->hs);
   const size_t plane = (size_t)p->N1 * imp::kN2;
   // IMPULSE_HIP_HOST_SPECTRUM=1 keeps the fp64 host preparation (the cross-check path of the tests)
@@ -943,6 +948,17 @@ extern "C" int imp_plan_set_filters(imp_plan* p, const double* filter, int64_t f
   if (rc) return rc;
   if ((rc = plan_sync_lanes(p))) return rc;
   return plan_fill_spectrum(p, filter, filter_ld);
+}
+
+extern "C" int imp_plan_set_filters_device(imp_plan* p, const double* d_filter, int64_t filter_ld) {
+  if (!p || !d_filter) return fail(IMP_ERR_INVALID, "imp_plan_set_filters_device: null argument");
+  IMP_CTX_LOCK(p->ctx);
+  if (p->n_filters > 1 && filter_ld < p->M) return fail(IMP_ERR_INVALID, "filter_ld < M");
+  if (p->lanes != 1) return fail(IMP_ERR_INVALID, "imp_plan_set_filters_device: the plan must run in stream order (lanes = 1)");
+  int rc = ctx_bind(p->ctx);
+  if (rc) return rc;
+  // stream order does the rest: launches queued earlier still read the old planes, later ones the new
+  return plan_fill_spectrum(p, d_filter, filter_ld, true);
 }
 
 extern "C" int imp_debug_plan_geometry(int64_t M, int64_t L, int mode, int64_t* nfft, int64_t* out_start,

@@ -101,7 +101,7 @@ void fft_roots_destroy(imp_ctx* ctx);
 // 2 Nc, computed in fp64 ON THE DEVICE and rounded once to fp32 into d_ab[n_filters][N1*4096]
 // (register order of the row pass).  minphase.hip, next to the fp64 Stockham FFT it uses.
 int spectrum_alpha_beta_device(imp_ctx* ctx, const double* filters, int64_t M, int64_t n_filters, int64_t filter_ld,
-                               int64_t Nc, int N1, float4* d_ab);
+                               int64_t Nc, int N1, float4* d_ab, bool filters_on_device = false);
 // Pair-mode spectrum (conv_kernels.hip.h rows_single_kernel): H[k] / Nc of ONE real filter zero-padded to the circular
 // length Nc = N1 * 4096 samples, all Nc bins, fp64 on the device, rounded once to fp32 into d_hs[N1][4096] in the row
 // pass's register order.

@@ -25,6 +25,7 @@
 #include <utility>
 
 #include "internal.h"
+#include "fft64.hip.h"
 
 typedef double2 cdbl;
 
@@ -198,6 +199,42 @@ __global__ __launch_bounds__(256) void take_real(const cdbl* __restrict__ c, dou
   out[(long long)blockIdx.y * ntaps + k] = c[(long long)blockIdx.y * N + k].x / (double)N;
 }
 
+// The same elementwise steps as load hooks of the tile transform (fft64.hip.h): op(value read, transform, index within it).
+struct WindowIn {                    // firwin2_window: the value comes from the [B][nirf] time-domain buffer
+  int nirf, numtaps;
+  __device__ __forceinline__ cdbl operator()(cdbl t, long long, long long k) const {
+    const double w = 0.54 - 0.46 * cos(2.0 * M_PI * (double)k / (double)(numtaps - 1));
+    const double v = t.x / (double)nirf;
+    return make_double2(v * w, 0.0);
+  }
+};
+struct HalfLogIn {                   // half_log
+  const unsigned long long* __restrict__ minbits;
+  __device__ __forceinline__ cdbl operator()(cdbl h, long long b, long long) const {
+    const double mn = __longlong_as_double((long long)minbits[b]);
+    return make_double2(0.5 * log(h.x + 1e-7 * mn), 0.0);
+  }
+};
+struct CepstralIn {                  // cepstral_window
+  int N;
+  __device__ __forceinline__ cdbl operator()(cdbl c, long long, long long k) const {
+    const int stop = N / 2;
+    double w = 0.0;
+    if (k == 0) w = 1.0;
+    else if (k < stop) w = 2.0;
+    else if (k == stop && (N & 1)) w = 1.0;
+    return make_double2(c.x / (double)N * w, 0.0);
+  }
+};
+struct ExpIn {                       // complex_exp
+  __device__ __forceinline__ cdbl operator()(cdbl c, long long, long long) const {
+    const double e = exp(c.x);
+    double sn, cs;
+    sincos(c.y, &sn, &cs);
+    return make_double2(e * cs, e * sn);
+  }
+};
+
 // ---- K2 when n is a product of the radices above (crop_tails leaves next_fast_len lengths): the DFT itself ----
 __global__ __launch_bounds__(256) void real_to_complex(const double* __restrict__ x, cdbl* __restrict__ a, int n) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -347,9 +384,10 @@ void minphase_plans_destroy(imp_ctx* ctx) {
   ctx->minphase_plans.clear();
 }
 
-// batched FFT: result ends in *cur (either buf0 or buf1)
-static int run_fft(imp_ctx* ctx, const std::vector<int>& fac, const cdbl* roots, int N, int64_t B, int dir, cdbl** cur,
-                   cdbl** other) {
+// one launch per radix pass through global memory (kept for lengths the tile transform does not take, and as its cross-check:
+// IMPULSE_HIP_FFT64_GENERIC=1)
+static int run_fft_passes(imp_ctx* ctx, const std::vector<int>& fac, const cdbl* roots, int N, int64_t B, int dir, cdbl** cur,
+                          cdbl** other) {
   int n = N, s = 1;
   for (int r : fac) {
     const int threads = N / r;
@@ -372,17 +410,119 @@ static int run_fft(imp_ctx* ctx, const std::vector<int>& fac, const cdbl* roots,
   return IMP_OK;
 }
 
+// one pass of the tile transform (fft64.hip.h)
+template <int T, class InOp, class OutOp>
+static int fft64_launch(imp_ctx* ctx, const fft64::Args& a, InOp in_op, OutOp out_op) {
+  auto kern = fft64::tile_kernel<T, InOp, OutOp>;
+  const size_t lds = fft64::tile_lds(a.P, T);
+  int rc = ctx_kernel_lds(ctx, reinterpret_cast<const void*>(kern), (size_t)160 * 1024);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((a.n_groups + T - 1) / T)), dim3(256), lds, ctx->stream, a, in_op, out_op);
+  HIP_TRY(hipGetLastError());
+  return IMP_OK;
+}
+
+template <class InOp, class OutOp>
+static int fft64_pass(imp_ctx* ctx, fft64::Args a, int64_t B, InOp in_op, OutOp out_op) {
+  a.n_groups = (long long)B * a.nvec;
+  if ((double)a.n_groups * (double)a.nvec >= 4294967296.0)
+    return fail(IMP_ERR_UNSUPPORTED, "fp64 transform batch of %lld vectors: beyond the kernel's 32-bit index arithmetic", (long long)a.n_groups);
+  a.m_nvec = fft64::magic_of((unsigned)a.nvec);
+  for (int st = 0, blk = a.P; st < a.nstages; ++st) {
+    blk /= a.radix[st];
+    a.m_blk[st] = fft64::magic_of((unsigned)blk);
+  }
+  switch (fft64::tile_vectors(a.P, a.n_groups)) {
+    case 16: return fft64_launch<16>(ctx, a, in_op, out_op);
+    case 8: return fft64_launch<8>(ctx, a, in_op, out_op);
+    default: return fft64_launch<4>(ctx, a, in_op, out_op);
+  }
+}
+
+static bool fft64_wanted() {
+  static const bool generic = [] { const char* e = std::getenv("IMPULSE_HIP_FFT64_GENERIC"); return e && e[0] == '1'; }();
+  return !generic;
+}
+
+// Batched N-point transforms of B rows ([B][N], roots = exp(-2 pi i k / N)): the tile transform in one or two launches
+// where N splits into factors it holds (every length of the path does), else one launch per radix pass.  The result ends
+// in *cur.  in_op is applied to every value read from *cur, out_op to every value of the result (elementwise hooks, so
+// that the kernels between two transforms need no launch and no pass over memory of their own).
+template <class InOp, class OutOp>
+static int run_fft_ops(imp_ctx* ctx, const std::vector<int>& fac, const cdbl* roots, int N, int64_t B, int dir, cdbl** cur,
+                       cdbl** other, InOp in_op, OutOp out_op, bool* used_tiles = nullptr, int64_t in_pitch = 0) {
+  const fft64::Plan pl = fft64_wanted() ? fft64::make_plan(N) : fft64::Plan();
+  if (used_tiles) *used_tiles = pl.ok;
+  if (!pl.ok) return run_fft_passes(ctx, fac, roots, N, B, dir, cur, other);
+  fft64::Args a = {};
+  a.roots = roots;
+  a.n_roots = N;
+  a.dir = dir;
+  a.in_batch = in_pitch > 0 ? in_pitch : N;              // rows of the input may be further apart than N (hooks that read a
+  a.out_batch = N;                                       // longer buffer: the FIR design's window step)
+  int rc;
+  if (pl.P2 == 1) {
+    a.in = *cur;
+    a.out = *other;
+    a.nvec = 1;
+    a.P = N;
+    a.in_vec = a.out_vec = N;
+    a.in_elem = a.out_elem = 1;
+    a.twiddle = 0;
+    a.nstages = (int)pl.r1.size();
+    for (int i = 0; i < a.nstages; ++i) a.radix[i] = pl.r1[(size_t)i];
+    if ((rc = fft64_pass(ctx, a, B, in_op, out_op))) return rc;
+    std::swap(*cur, *other);
+    return IMP_OK;
+  }
+  // pass 1: the P2 columns, P1 points each, x w_N^(n2 k1) -> Y[k1][n2]
+  a.in = *cur;
+  a.out = *other;
+  a.nvec = pl.P2;
+  a.P = pl.P1;
+  a.in_vec = 1;
+  a.in_elem = pl.P2;
+  a.out_vec = 1;
+  a.out_elem = pl.P2;
+  a.twiddle = 1;
+  a.nstages = (int)pl.r1.size();
+  for (int i = 0; i < a.nstages; ++i) a.radix[i] = pl.r1[(size_t)i];
+  if ((rc = fft64_pass(ctx, a, B, in_op, fft64::NoOp{}))) return rc;
+  // pass 2: the P1 rows of Y, P2 points each -> X[k1 + P1 k2]
+  a.in = *other;
+  a.out = *cur;
+  a.in_batch = N;
+  a.nvec = pl.P1;
+  a.P = pl.P2;
+  a.in_vec = pl.P2;
+  a.in_elem = 1;
+  a.out_vec = 1;
+  a.out_elem = pl.P1;
+  a.twiddle = 0;
+  a.nstages = (int)pl.r2.size();
+  for (int i = 0; i < a.nstages; ++i) a.radix[i] = pl.r2[(size_t)i];
+  return fft64_pass(ctx, a, B, fft64::NoOp{}, out_op);
+}
+
+// batched FFT: result ends in *cur (either buf0 or buf1)
+static int run_fft(imp_ctx* ctx, const std::vector<int>& fac, const cdbl* roots, int N, int64_t B, int dir, cdbl** cur,
+                   cdbl** other) {
+  return run_fft_ops(ctx, fac, roots, N, B, dir, cur, other, fft64::NoOp{}, fft64::NoOp{});
+}
+
 static int minphase_run(imp_ctx* ctx, const double* gain, const double* d_gain, int64_t B, int64_t n, double fs,
-                        double* fir_out, int stage);
+                        double* fir_out, int stage, double* d_fir_out = nullptr);
 
 extern "C" int imp_minphase_fir(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, double* fir_out) {
   return minphase_run(ctx, gain, nullptr, B, n, fs, fir_out, 2);
 }
 
 // the gains are already on the device (curves.hip: the FIR design grid computed from the equalisation curves there;
-// its last column is zero by construction)
-int minphase_fir_from_device_gain(imp_ctx* ctx, const double* d_gain, int64_t B, int64_t n, double fs, double* fir_out_host) {
-  return minphase_run(ctx, nullptr, d_gain, B, n, fs, fir_out_host, 2);
+// its last column is zero by construction).  fir_out_host: the taps come back and the call waits for them;
+// d_fir_out (device, [B][n]): they stay on the device and the call returns without waiting.
+int minphase_fir_from_device_gain(imp_ctx* ctx, const double* d_gain, int64_t B, int64_t n, double fs, double* fir_out_host,
+                                  double* d_fir_out) {
+  return minphase_run(ctx, nullptr, d_gain, B, n, fs, fir_out_host, 2, d_fir_out);
 }
 
 extern "C" int imp_debug_minphase_stage(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, int stage,
@@ -393,8 +533,8 @@ extern "C" int imp_debug_minphase_stage(imp_ctx* ctx, const double* gain, int64_
 
 // stage 0: out[B][2n] = firwin2 taps; stage 1: out[B][2n] = |FFT_2n(taps)|; stage 2: out[B][n] = FIR
 static int minphase_run(imp_ctx* ctx, const double* gain, const double* d_gain, int64_t B, int64_t n, double fs,
-                        double* fir_out, int stage) {
-  if (!ctx || (B && ((!gain && !d_gain) || !fir_out))) return fail(IMP_ERR_INVALID, "imp_minphase_fir: null argument");
+                        double* fir_out, int stage, double* d_fir_out) {
+  if (!ctx || (B && ((!gain && !d_gain) || (!fir_out && !d_fir_out)))) return fail(IMP_ERR_INVALID, "imp_minphase_fir: null argument");
   if (B < 0 || n < 2 || n > (1 << 20)) return fail(IMP_ERR_INVALID, "imp_minphase_fir: bad B or n");
   if (!(fs > 0)) return fail(IMP_ERR_INVALID, "imp_minphase_fir: fs must be positive");
   if (B == 0) return IMP_OK;
@@ -463,9 +603,6 @@ static int minphase_run(imp_ctx* ctx, const double* gain, const double* d_gain, 
                      p->nyq, p->numtaps);
   HIP_TRY(hipGetLastError());
   if ((rc = run_fft(ctx, p->fac_irf, p->roots_irf, p->nirf, B, +1, &cur, &oth))) return rc;
-  hipLaunchKernelGGL(firwin2_window, grid_for(p->numtaps), dim3(256), 0, s, cur, oth, p->nirf, p->numtaps);
-  HIP_TRY(hipGetLastError());
-  std::swap(cur, oth);
   // minimum_phase (homomorphic, half = True)
   const int N = p->numtaps;
   auto dump_real = [&](const cdbl* src) -> int {       // debug stages: real parts of [B][N]
@@ -475,28 +612,79 @@ static int minphase_run(imp_ctx* ctx, const double* gain, const double* d_gain, 
     for (size_t i = 0; i < h.size(); ++i) fir_out[i] = h[i].x;
     return IMP_OK;
   };
-  if (stage == 0) return dump_real(cur);
-  if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, -1, &cur, &oth))) return rc;
-  hipLaunchKernelGGL(magnitude_and_min, dim3((unsigned)((N + 256 * kMagPerThread - 1) / (256 * kMagPerThread)), (unsigned)B),
-                     dim3(256), 0, s, cur, p->minbits, N);
+  // The elementwise steps between the transforms are the LOAD hooks of the transform that follows them (same arithmetic,
+  // same values - one launch and one pass over memory less each); the debug stages and lengths the tile transform does
+  // not take keep them as kernels of their own.
+  const bool fused = stage == 2 && fft64_wanted() && fft64::make_plan(N).ok;
+  if (fused) {
+    if ((rc = run_fft_ops(ctx, p->fac_tap, p->roots_tap, N, B, -1, &cur, &oth, WindowIn{p->nirf, p->numtaps}, fft64::NoOp{}, nullptr,
+                          p->nirf)))
+      return rc;
+    hipLaunchKernelGGL(magnitude_and_min, dim3((unsigned)((N + 256 * kMagPerThread - 1) / (256 * kMagPerThread)), (unsigned)B),
+                       dim3(256), 0, s, cur, p->minbits, N);
+    HIP_TRY(hipGetLastError());
+    if ((rc = run_fft_ops(ctx, p->fac_tap, p->roots_tap, N, B, +1, &cur, &oth, HalfLogIn{p->minbits}, fft64::NoOp{}))) return rc;
+    if ((rc = run_fft_ops(ctx, p->fac_tap, p->roots_tap, N, B, -1, &cur, &oth, CepstralIn{N}, fft64::NoOp{}))) return rc;
+    if ((rc = run_fft_ops(ctx, p->fac_tap, p->roots_tap, N, B, +1, &cur, &oth, ExpIn{}, fft64::NoOp{}))) return rc;
+  } else {
+    hipLaunchKernelGGL(firwin2_window, grid_for(p->numtaps), dim3(256), 0, s, cur, oth, p->nirf, p->numtaps);
+    HIP_TRY(hipGetLastError());
+    std::swap(cur, oth);
+    if (stage == 0) return dump_real(cur);
+    if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, -1, &cur, &oth))) return rc;
+    hipLaunchKernelGGL(magnitude_and_min, dim3((unsigned)((N + 256 * kMagPerThread - 1) / (256 * kMagPerThread)), (unsigned)B),
+                       dim3(256), 0, s, cur, p->minbits, N);
+    HIP_TRY(hipGetLastError());
+    if (stage == 1) return dump_real(cur);
+    hipLaunchKernelGGL(half_log, grid_for(N), dim3(256), 0, s, cur, p->minbits, N);
+    HIP_TRY(hipGetLastError());
+    if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, +1, &cur, &oth))) return rc;
+    hipLaunchKernelGGL(cepstral_window, grid_for(N), dim3(256), 0, s, cur, N);
+    HIP_TRY(hipGetLastError());
+    if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, -1, &cur, &oth))) return rc;
+    hipLaunchKernelGGL(complex_exp, grid_for(N), dim3(256), 0, s, cur, N);
+    HIP_TRY(hipGetLastError());
+    if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, +1, &cur, &oth))) return rc;
+  }
+  hipLaunchKernelGGL(take_real, grid_for(p->n), dim3(256), 0, s, cur, d_fir_out ? d_fir_out : p->out, N, p->n);
   HIP_TRY(hipGetLastError());
-  if (stage == 1) return dump_real(cur);
-  hipLaunchKernelGGL(half_log, grid_for(N), dim3(256), 0, s, cur, p->minbits, N);
-  HIP_TRY(hipGetLastError());
-  if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, +1, &cur, &oth))) return rc;
-  hipLaunchKernelGGL(cepstral_window, grid_for(N), dim3(256), 0, s, cur, N);
-  HIP_TRY(hipGetLastError());
-  if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, -1, &cur, &oth))) return rc;
-  hipLaunchKernelGGL(complex_exp, grid_for(N), dim3(256), 0, s, cur, N);
-  HIP_TRY(hipGetLastError());
-  if ((rc = run_fft(ctx, p->fac_tap, p->roots_tap, N, B, +1, &cur, &oth))) return rc;
-  hipLaunchKernelGGL(take_real, grid_for(p->n), dim3(256), 0, s, cur, p->out, N, p->n);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(fir_out, p->out, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  if (fir_out) {
+    HIP_TRY(hipMemcpyAsync(fir_out, d_fir_out ? d_fir_out : p->out, (size_t)B * n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
   return IMP_OK;
 }
 
+
+// Test hook: the batched fp64 transform the fp64 kernels share (K6, K2, filter spectra), on host data.
+extern "C" int imp_debug_fft64(imp_ctx* ctx, const double* x, int64_t B, int64_t N, int dir, double* y, int* used_tiles) {
+  if (!ctx || !x || !y) return fail(IMP_ERR_INVALID, "imp_debug_fft64: null argument");
+  if (B < 1 || N < 2 || N > (1 << 22) || (dir != 1 && dir != -1)) return fail(IMP_ERR_INVALID, "imp_debug_fft64: bad B, N or dir");
+  const std::vector<int> fac = factorise((int)N);
+  if (fac.empty()) return fail(IMP_ERR_UNSUPPORTED, "imp_debug_fft64: N = %lld is not 2^a 3^b 5^c 11^d", (long long)N);
+  IMP_CTX_LOCK(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  cdbl *a = nullptr, *b = nullptr, *roots = nullptr;
+  const size_t bytes = (size_t)B * N * sizeof(cdbl);
+  hipStream_t s = ctx->stream;
+  auto cleanup = [&](int code) {
+    (void)hipStreamSynchronize(s);
+    (void)ctx_block_put(ctx, a);
+    (void)ctx_block_put(ctx, b);
+    (void)hipFree(roots);
+    return code;
+  };
+  if (ctx_block_get(ctx, bytes, (void**)&a) || ctx_block_get(ctx, bytes, (void**)&b)) return cleanup(IMP_ERR_ALLOC);
+  if ((rc = upload_roots(&roots, (int)N, s))) return cleanup(rc);
+  if (hipMemcpyAsync(a, x, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return cleanup(fail(IMP_ERR_HIP, "imp_debug_fft64: upload failed"));
+  cdbl *cur = a, *oth = b;
+  bool tiles = false;
+  if ((rc = run_fft_ops(ctx, fac, roots, (int)N, B, dir, &cur, &oth, fft64::NoOp{}, fft64::NoOp{}, &tiles))) return cleanup(rc);
+  if (used_tiles) *used_tiles = tiles ? 1 : 0;
+  if (hipMemcpyAsync(y, cur, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) return cleanup(fail(IMP_ERR_HIP, "imp_debug_fft64: download failed"));
+  return cleanup(IMP_OK);
+}
 
 // ------------------------------------------------------------------------------------------------
 // K2: magnitude response of arbitrary-length rows (core/audio_io.py:100-113), fp64 Bluestein
@@ -1004,7 +1192,7 @@ void fft_roots_destroy(imp_ctx* ctx) {
 }
 
 int spectrum_alpha_beta_device(imp_ctx* ctx, const double* filters, int64_t M, int64_t n_filters, int64_t filter_ld,
-                               int64_t Nc, int N1, float4* d_ab) {
+                               int64_t Nc, int N1, float4* d_ab, bool filters_on_device) {
   const std::vector<int> fac = factorise((int)Nc);
   if (fac.empty()) return fail(IMP_ERR_UNSUPPORTED, "spectrum length %lld is not 2^a 3^b 5^c 11^d", (long long)Nc);
   hipStream_t s = ctx->stream;
@@ -1029,27 +1217,38 @@ int spectrum_alpha_beta_device(imp_ctx* ctx, const double* filters, int64_t M, i
     (void)ctx_block_put(ctx, d_h);
     return code;
   };
+  // (filters already on the device are read where they are and nothing below waits: the blocks go back to the pool in
+  // stream order)
+  auto cleanup_async = [&](int code) {
+    (void)ctx_block_put(ctx, a);
+    (void)ctx_block_put(ctx, b);
+    return code;
+  };
   if (ctx_block_get(ctx, (size_t)chunk * Nc * sizeof(cdbl), (void**)&a) ||
       ctx_block_get(ctx, (size_t)chunk * Nc * sizeof(cdbl), (void**)&b) ||
-      ctx_block_get(ctx, (size_t)chunk * M * sizeof(double), (void**)&d_h))
+      (!filters_on_device && ctx_block_get(ctx, (size_t)chunk * M * sizeof(double), (void**)&d_h)))
     return cleanup(fail(IMP_ERR_ALLOC, "device buffers for the filter spectra (%lld filters of %lld points)",
                         (long long)chunk, (long long)Nc));
   for (int64_t f0 = 0; f0 < n_filters; f0 += chunk) {
     const int64_t nf = std::min(chunk, n_filters - f0);
-    if (hipMemcpy2DAsync(d_h, (size_t)M * sizeof(double), filters + f0 * filter_ld, (size_t)filter_ld * sizeof(double),
+    if (!filters_on_device &&
+        hipMemcpy2DAsync(d_h, (size_t)M * sizeof(double), filters + f0 * filter_ld, (size_t)filter_ld * sizeof(double),
                          (size_t)M * sizeof(double), (size_t)nf, hipMemcpyHostToDevice, s) != hipSuccess)
       return cleanup(fail(IMP_ERR_HIP, "filter upload failed"));
     const dim3 grid((unsigned)((Nc + 255) / 256), (unsigned)nf);
-    hipLaunchKernelGGL(pack_filter_kernel, grid, dim3(256), 0, s, d_h, a, (long long)M, (long long)M, (int)Nc);
+    if (filters_on_device)
+      hipLaunchKernelGGL(pack_filter_kernel, grid, dim3(256), 0, s, filters + f0 * filter_ld, a, (long long)M, (long long)filter_ld, (int)Nc);
+    else
+      hipLaunchKernelGGL(pack_filter_kernel, grid, dim3(256), 0, s, (const double*)d_h, a, (long long)M, (long long)M, (int)Nc);
     cdbl *cur = a, *oth = b;
     int rc = run_fft(ctx, fac, roots, (int)Nc, nf, -1, &cur, &oth);
     if (rc) return cleanup(rc);
     hipLaunchKernelGGL(alpha_beta_kernel, grid, dim3(256), 0, s, cur, d_ab + f0 * Nc, (int)Nc, N1);
     if (hipGetLastError() != hipSuccess) return cleanup(fail(IMP_ERR_HIP, "alpha/beta launch failed"));
     // the host rows of this chunk may be reused by the caller after return: drain before the next upload
-    if (hipStreamSynchronize(s) != hipSuccess) return cleanup(fail(IMP_ERR_HIP, "filter spectrum: stream error"));
+    if (!filters_on_device && hipStreamSynchronize(s) != hipSuccess) return cleanup(fail(IMP_ERR_HIP, "filter spectrum: stream error"));
   }
-  return cleanup(IMP_OK);
+  return filters_on_device ? cleanup_async(IMP_OK) : cleanup(IMP_OK);
 }
 
 int spectrum_pair_device(imp_ctx* ctx, const double* filter, int64_t M, int64_t Nc, int N1, cf* d_hs) {

@@ -129,6 +129,10 @@ SIGNATURES = {
     "imp_comm_broadcast": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int]),
     "imp_plan_broadcast_spectrum": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(C.c_size_t)]),
     "imp_plan_set_filters": (C.c_int, [_vp, _pd, _i64]),
+    "imp_plan_set_filters_device": (C.c_int, [_vp, _vp, _i64]),
+    "imp_curves_equalization_fir_device": (C.c_int, [_vp, _pd, _i64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                                     C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, _pd, C.POINTER(_vp), _pi64]),
+    "imp_slice_set_firs_device": (C.c_int, [_vp, _vp, _i64]),
     "imp_plan_set_resident": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
     "imp_plan_resident_status": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong)]),
     "imp_plan_set_timing": (C.c_int, [_vp, C.c_int]),
@@ -157,6 +161,7 @@ SIGNATURES = {
                                               C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, _pd, _pd]),
     "imp_magnitude_db": (C.c_int, [_vp, _pd, _i64, _i64, _pd]),
     "imp_debug_minphase_stage": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, C.c_int, _pd]),
+    "imp_debug_fft64": (C.c_int, [_vp, _pd, _i64, _i64, C.c_int, _pd, C.POINTER(C.c_int)]),
     "imp_peak_index": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
     "imp_peak_index_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, C.c_double, _pi64, _pf]),
     "imp_apply_window": (C.c_int, [_vp, _pf, _pi64, _pi64, _i64, C.POINTER(WindowParams)]),
@@ -490,6 +495,18 @@ class Context:
                                               out.ctypes.data_as(_pd)))
         return out[0] if one else out
 
+    def fft64(self, x, inverse=False):
+        """the library's batched fp64 complex transform on host data [B, N] (test hook): (result, used the LDS tile form)"""
+        a = np.ascontiguousarray(x, dtype=np.complex128)
+        one = a.ndim == 1
+        if one:
+            a = a[None, :]
+        out = np.empty_like(a)
+        tiles = C.c_int(0)
+        _check(self._lib.imp_debug_fft64(self._h, a.ctypes.data_as(_pd), a.shape[0], a.shape[1], 1 if inverse else -1,
+                                         out.ctypes.data_as(_pd), C.byref(tiles)))
+        return (out[0] if one else out), bool(tiles.value)
+
     def minphase_debug_stage(self, gain, fs, stage):
         g = np.ascontiguousarray(gain, dtype=np.float64)
         if g.ndim == 1:
@@ -653,6 +670,10 @@ class Slice:
             raise ValueError(f"FIRs must be [{self.rows}, {self.taps}], got {f.shape}")
         _check(self._lib.imp_slice_set_firs(self._h, f.ctypes.data_as(_pd), self.taps))
 
+    def set_firs_device(self, d_firs, ld=None):
+        """FIRs already on the device (fp64 [rows][ld]): no upload, no wait"""
+        _check(self._lib.imp_slice_set_firs_device(self._h, _vp(int(d_firs)), int(ld or self.taps)))
+
     def execute_device(self, d_rec, rec_stride, M, d_out, out_pitch):
         _check(self._lib.imp_slice_execute_device(self._h, _vp(int(d_rec)), int(rec_stride), int(M), _vp(int(d_out)),
                                                   int(out_pitch)))
@@ -813,6 +834,19 @@ class Curves:
                                                      1 if normalize else 0, eq.ctypes.data_as(_pd), fir.ctypes.data_as(_pd)))
         return (eq[0], fir[0]) if one else (eq, fir)
 
+    def equalization_fir_device(self, error, smoothen_first, max_gain, treble_f_lower, treble_f_upper, treble_max_gain,
+                                treble_gain_k, fs, f_res, normalize, smoothen_kinks=True, want_equalization=False):
+        """error curves -> FIRs LEFT ON THE DEVICE: (equalization [B, n] or None, DeviceFirs)"""
+        a, one = self._rows(error)
+        eq = np.empty_like(a) if want_equalization else None
+        d = _vp()
+        taps = _i64()
+        _check(self._lib.imp_curves_equalization_fir_device(
+            self._h, a.ctypes.data_as(_pd), a.shape[0], 1 if smoothen_first else 0, float(max_gain), float(treble_f_lower),
+            float(treble_f_upper), float(treble_max_gain), float(treble_gain_k), 1 if smoothen_kinks else 0, float(fs), float(f_res),
+            1 if normalize else 0, eq.ctypes.data_as(_pd) if want_equalization else None, C.byref(d), C.byref(taps)))
+        return eq, DeviceFirs(self.ctx, d.value, a.shape[0], taps.value)
+
     def close(self):
         if getattr(self, "_h", None):
             if getattr(self.ctx, "_h", None):
@@ -824,6 +858,68 @@ class Curves:
             self.close()
         except Exception:                                  # noqa: BLE001 - interpreter shutdown
             pass
+
+
+class DeviceFirs:
+    """A batch of FIRs [B, taps] (fp64) that the design left on the device.  Consumers on the same device take the
+    device pointer (ConvPlan.set_filters_device, Slice.set_firs_device); rows() hands out DeviceFir objects that turn
+    into host arrays only when somebody reads them (np.asarray(row) / row.host())."""
+
+    def __init__(self, ctx, dptr, B, taps):
+        self.ctx, self.ptr, self.B, self.taps = ctx, int(dptr), int(B), int(taps)
+        self._host = None
+        self._ready = False
+
+    def ready(self):
+        """wait (once) until the design's stream has produced the taps: consumers on OTHER streams call this first"""
+        if not self._ready:
+            self.ctx.synchronize()
+            self._ready = True
+        return self
+
+    def host(self):
+        if self._host is None:
+            out = np.empty((self.B, self.taps), dtype=np.float64)
+            self.ctx.synchronize()
+            self.ctx.d2h(out, self.ptr)
+            self._host, self._ready = out, True
+        return self._host
+
+    def rows(self):
+        return [DeviceFir(self, i) for i in range(self.B)]
+
+    def close(self):
+        if self.ptr and getattr(self.ctx, "_h", None):
+            self.ctx.free(self.ptr)
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+class DeviceFir:
+    """row i of a DeviceFirs batch: an array-like that becomes a host array when read"""
+    __slots__ = ("batch", "index")
+
+    def __init__(self, batch, index):
+        self.batch, self.index = batch, index
+
+    def host(self):
+        return self.batch.host()[self.index]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.host()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __len__(self):
+        return self.batch.taps
+
+    @property
+    def shape(self):
+        return (self.batch.taps,)
 
 
 class ConvPlan:
@@ -1008,6 +1104,10 @@ class ConvPlan:
         if f.shape != (self.n_filters, self.M):
             raise ValueError(f"plan holds {self.n_filters} filter(s) of {self.M} taps, got {f.shape}")
         _check(self._lib.imp_plan_set_filters(self._h, f.ctypes.data_as(_pd), self.M))
+
+    def set_filters_device(self, d_filt, ld=None):
+        """New filters of the same shape from fp64 device memory [n_filters][ld]: no upload, no wait (stream order)."""
+        _check(self._lib.imp_plan_set_filters_device(self._h, _vp(int(d_filt)), int(ld or self.M)))
 
     def resident_available(self):
         """True if this plan qualifies for the XCD-resident path (one channel's workspace fits an XCD's L2)."""

@@ -153,9 +153,13 @@ def equalization_curves(frequency, errors, smoothen_first=True, max_gain=DEFAULT
 def equalization_firs(frequency, errors, fs, smoothen_first=True, max_gain=DEFAULT_MAX_GAIN,
                       treble_f_lower=DEFAULT_TREBLE_F_LOWER, treble_f_upper=DEFAULT_TREBLE_F_UPPER,
                       treble_max_gain=DEFAULT_TREBLE_MAX_GAIN, treble_gain_k=DEFAULT_TREBLE_GAIN_K, f_res=DEFAULT_F_RES,
-                      normalize=True):
+                      normalize=True, on_device=False):
     """error curves [B, n] -> (equalization [B, n], minimum-phase FIRs [B, taps]); nothing but the inputs and the
-    results crosses the PCIe bus."""
+    results crosses the PCIe bus.  on_device: the FIRs stay on the device - (None, _native.DeviceFirs): their consumer
+    (HRIR.equalize_channels, the resident slice) takes them there, and they visit the host only if somebody reads them."""
+    if on_device:
+        return curves_for(frequency).equalization_fir_device(errors, smoothen_first, max_gain, treble_f_lower, treble_f_upper,
+                                                             treble_max_gain, treble_gain_k, fs, f_res, normalize)
     return curves_for(frequency).equalization_fir(errors, smoothen_first, max_gain, treble_f_lower, treble_f_upper,
                                                   treble_max_gain, treble_gain_k, fs, f_res, normalize)
 

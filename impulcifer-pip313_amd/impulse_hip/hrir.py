@@ -616,7 +616,16 @@ class HRIR(object):
         from .impulse_response import _k5_plans, fir_convolve_full_batch
         keys = [k for k in firs if k[0] in self.irs and k[1] in self.irs[k[0]]]
         dev = self._device_rows([self.irs[sp][sd] for sp, sd in keys])
-        taps = [np.asarray(firs[k], dtype=np.float64) for k in keys]
+        # FIRs the design left on the device (process_equalization_batch(on_device=True)): the rows of ONE batch, in order,
+        # on this device - they go to K5 where they are
+        raw = [firs[k] for k in keys]
+        batch = None
+        if dev is not None and raw and all(isinstance(t, _native.DeviceFir) for t in raw):
+            b0 = raw[0].batch
+            if (all(t.batch is b0 for t in raw) and [t.index for t in raw] == list(range(b0.B))
+                    and b0.ctx.device == _native.default_context().device):
+                batch = b0
+        taps = raw if batch is not None else [np.asarray(t, dtype=np.float64) for t in raw]
         if dev is not None and len({len(t) for t in taps}) == 1 and len(taps[0]) > 0 and dev[0].n > 0:
             from .device_rows import DeviceBlock, Row, uniform
             pitch = uniform(dev)
@@ -624,11 +633,12 @@ class HRIR(object):
                 n, k = dev[0].n, len(taps[0])
                 out_pitch = (n + k - 1 + 63) // 64 * 64
                 block = DeviceBlock(_native.default_context(), len(dev) * out_pitch)
-                out_len = _k5_plans.run_device(dev[0].ptr, len(dev), pitch, n, _rows_matrix(taps), block.ptr, out_pitch)
+                out_len = _k5_plans.run_device(dev[0].ptr, len(dev), pitch, n, batch if batch is not None else _rows_matrix(taps),
+                                               block.ptr, out_pitch)
                 for i, (sp, sd) in enumerate(keys):
                     self.irs[sp][sd]._row = Row(block, i * out_pitch, out_len)
                 return
-        ys = fir_convolve_full_batch([self.irs[sp][sd].data for sp, sd in keys], [firs[k] for k in keys])
+        ys = fir_convolve_full_batch([self.irs[sp][sd].data for sp, sd in keys], [np.asarray(firs[k], dtype=np.float64) for k in keys])
         for (sp, sd), y in zip(keys, ys):
             self.irs[sp][sd].data = y
 

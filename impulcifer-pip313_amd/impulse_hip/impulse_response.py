@@ -42,14 +42,25 @@ class _PlanCache:
 
     def run_device(self, d_in, B, stride_in, n, taps, d_out, stride_out):
         """Device rows in (B rows of n samples, stride_in apart), device rows out (n + taps - 1 samples, stride_out
-        apart); taps: host [B, K].  Asynchronous on the context stream."""
+        apart); taps: host [B, K], or a _native.DeviceFirs batch of B FIRs (no upload then).  Asynchronous on the context
+        stream."""
         ctx = _native.default_context()
-        key = (id(ctx), int(n), taps.shape[1], int(B))
+        on_device = isinstance(taps, _native.DeviceFirs)
+        K = taps.taps if on_device else taps.shape[1]
+        key = (id(ctx), int(n), K, int(B))
         with self.lock:
             plan = self.plans.pop(key, None)
             if plan is not None and not plan._h:
                 plan = None
-            if plan is None:
+            if on_device:
+                if plan is None:
+                    plan = _native.ConvPlan(ctx, None, int(n), "full", ws_channels=int(B), empty_M=K, n_filters=int(B))
+                if not plan.fused and plan.n_filters != B:
+                    raise ValueError("device FIRs: one filter per channel")
+                taps.ready()                                # the design ran on a stream of its own
+                plan.set_filters_device(taps.ptr, K)
+                plan._fir_batch = taps                       # the spectra are formed in stream order: keep the taps alive
+            elif plan is None:
                 plan = _native.ConvPlan(ctx, taps, int(n), "full", ws_channels=int(B))
             else:
                 plan.set_filters(taps)

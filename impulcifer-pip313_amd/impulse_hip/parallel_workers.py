@@ -75,15 +75,20 @@ def process_equalization_worker(args):
 
 
 def process_equalization_batch(tasks, room_frs, hp_left, hp_right, eq_left, eq_right, target, common_freq,
-                               estimator_fs):
+                               estimator_fs, on_device=False):
     """All (speaker, side) FIRs of a measurement in ONE device launch chain - what replaces the reference's process
     pool over channels (core/pipeline.py:668-688): the error matrix goes up, the FIRs come down; smoothing, gain-limited
-    inversion, FIR design grid and the minimum-phase design never leave the device."""
+    inversion, FIR design grid and the minimum-phase design never leave the device.  on_device: neither do the FIRs - the
+    third element of every result is then a _native.DeviceFir (row of one device batch) that HRIR.equalize_channels and
+    the resident slice consume where it is; np.asarray(fir) brings it to the host."""
     from .frequency_response import equalization_firs
     tasks = list(tasks)
     if not tasks:
         return []
     errors = equalization_errors(tasks, room_frs, hp_left, hp_right, eq_left, eq_right, target, common_freq)
     _, firs = equalization_firs(common_freq, errors, estimator_fs, smoothen_first=True, max_gain=40,
-                                treble_f_lower=10000, treble_f_upper=estimator_fs / 2, f_res=5, normalize=False)
+                                treble_f_lower=10000, treble_f_upper=estimator_fs / 2, f_res=5, normalize=False,
+                                on_device=on_device)
+    if on_device:
+        firs = firs.rows()
     return [(sp, sd, fir) for (sp, sd), fir in zip(tasks, firs)]

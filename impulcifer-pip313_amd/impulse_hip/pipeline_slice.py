@@ -31,7 +31,8 @@ def _design_early(tasks, *args):
 
     def work():
         with _native.using_context(_native.aux_context()):
-            return process_equalization_batch(tasks, *args)
+            # the FIRs stay on the device: equalize_channels takes them there (they reach the host only if read)
+            return process_equalization_batch(tasks, *args, on_device=True)
 
     return _designer.submit(work)
 

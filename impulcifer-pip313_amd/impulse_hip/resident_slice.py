@@ -125,7 +125,7 @@ class ResidentSlice:
                                    max_measurements=self.max_measurements)
         self.out_pitch = (self.slice.out_len_max + 63) // 64 * 64
         if self.firs is not None:
-            self.slice.set_firs(self.firs)
+            self.set_firs(self.firs)
 
     def grow_for(self, rows):
         """After a call that flagged IMP_SLICE_KEEP_CAP: size the slice for the crop_tails lengths those rows ask for (the
@@ -142,11 +142,29 @@ class ResidentSlice:
         return True
 
     def set_firs(self, firs):
-        """firs: {(speaker, side): taps} or a [2 * speakers, taps] matrix in layout.tasks order"""
+        """firs: {(speaker, side): taps}, a [2 * speakers, taps] matrix in layout.tasks order, or the _native.DeviceFirs
+        batch a design left on this device (process_equalization_batch(on_device=True): rows in layout.tasks order) - that
+        one is taken where it is: no upload, no wait on the slice's stream beyond the design's completion"""
         if isinstance(firs, dict):
-            firs = np.stack([np.asarray(firs[t], dtype=np.float64) for t in self.layout.tasks])
+            rows = [firs[t] for t in self.layout.tasks]
+            if rows and all(isinstance(r, _native.DeviceFir) for r in rows) and all(r.batch is rows[0].batch for r in rows) \
+                    and [r.index for r in rows] == list(range(rows[0].batch.B)):
+                firs = rows[0].batch
+            else:
+                firs = np.stack([np.asarray(r, dtype=np.float64) for r in rows])
+        if isinstance(firs, _native.DeviceFirs):
+            if (firs.B, firs.taps) != (self.slice.rows, self.taps) or firs.ctx.device != self.ctx.device:
+                raise ValueError(f"device FIRs must be [{self.slice.rows}, {self.taps}] on device {self.ctx.device}")
+            self.firs = firs
+            self.slice.set_firs_device(firs.ready().ptr, firs.taps)
+            return
         self.firs = np.ascontiguousarray(firs, dtype=np.float64)
         self.slice.set_firs(self.firs)
+
+    def firs_by_task(self):
+        """{(speaker, side): taps} on the host (what the staged path takes)"""
+        host = self.firs.host() if isinstance(self.firs, _native.DeviceFirs) else self.firs
+        return {t: host[i] for i, t in enumerate(self.layout.tasks)}
 
     def execute_device(self, d_rec, M, d_out=None):
         """M measurements already on the device (layout.samples apart, first at d_rec).  Asynchronous; returns the output
@@ -215,7 +233,7 @@ class ResidentSlice:
         if self.firs is None:
             raise ValueError("set_firs first")
         results = []
-        firs = {t: self.firs[i] for i, t in enumerate(self.layout.tasks)}
+        firs = None
         for m0 in range(0, len(measurements), self.max_measurements):
             batch = measurements[m0:m0 + self.max_measurements]
             M = len(batch)
@@ -232,7 +250,7 @@ class ResidentSlice:
 
             def staged(m, batch=batch):
                 jobs = [((self.fs, np.asarray(fr)), spec[2], None) for fr, spec in zip(batch[m], self.layout.files)]
-                return run_slice(self.estimator, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=firs)
+                return run_slice(self.estimator, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=self.firs_by_task())
 
             results.extend(self.collect(block, batch, staged))
         return results

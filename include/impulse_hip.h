@@ -170,6 +170,11 @@ int imp_plan_set_overlap(imp_plan* plan, int lanes);
  * drained first), so a caller can keep ONE plan - workspace, tables, buffers - per shape and refill it whenever the
  * FIRs change: HRIR.equalize_channels gets new FIRs for every measurement (core/pipeline.py:690-691). */
 int imp_plan_set_filters(imp_plan* plan, const double* filter, int64_t filter_ld);
+/* the same with the filters ALREADY ON THE DEVICE (fp64, the context's device: what imp_curves_equalization_fir_device
+ * leaves there), for plans with one channel per transform or fused FIR plans, no overlap-add, lanes = 1: nothing is
+ * uploaded, nothing waits - the new planes take effect in stream order.  d_filter must stay valid until the stream has
+ * passed this call (imp_free on the same context's stream is ordered behind it). */
+int imp_plan_set_filters_device(imp_plan* plan, const double* d_filter, int64_t filter_ld);
 
 /* EXPERIMENT, compiled only with -DIMP_XCD_RESIDENT (python build.py --variant xcd IMP_XCD_RESIDENT; measured 163 k against
  * 390 k IR/s): in the default build *available is 0 and enabling it fails with IMP_ERR_UNSUPPORTED.
@@ -282,6 +287,15 @@ int imp_curves_equalization_fir(imp_curves* c, const double* error, int64_t B, i
                                 int smoothen_kinks, double fs, double f_res, int normalize, double* equalization_out,
                                 double* fir_out);
 
+/* the whole worker with the FIRs LEFT ON THE DEVICE (core/pipeline.py:690-691 hands every FIR straight to
+ * ImpulseResponse.equalize: they never need to visit the host): *d_fir_out = fp64 [B][*ntaps_out] in a block of the context's
+ * pool - hand it back with imp_free - ready in the order of the context's stream; the call does not wait for the device
+ * unless equalization_out (host, may be NULL) is asked for. */
+int imp_curves_equalization_fir_device(imp_curves* c, const double* error, int64_t B, int smoothen_first, double max_gain,
+                                       double treble_f_lower, double treble_f_upper, double treble_max_gain, double treble_gain_k,
+                                       int smoothen_kinks, double fs, double f_res, int normalize, double* equalization_out,
+                                       void** d_fir_out, int64_t* ntaps_out);
+
 /* ---- K11: cascaded second-order sections -------------------------------------------------------
  * core/virtual_bass.py:121-176: scipy.signal.sosfilt(sos, x) (zero initial state) over every response.
  * sos: host [n_sections][6] = b0 b1 b2 a0 a1 a2 with a0 = 1 (SciPy's layout);
@@ -329,6 +343,12 @@ int imp_minphase_fir(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, dou
 /* debug: intermediates of the design. stage 0: out[B][2n] = firwin2 taps; stage 1: |FFT_2n(taps)| */
 int imp_debug_minphase_stage(imp_ctx* ctx, const double* gain, int64_t B, int64_t n, double fs, int stage,
                              double* out);
+
+/* test hook: the batched fp64 complex transform K6, K2 and the filter-spectrum preparation share.  x, y: host [B][N]
+ * complex128 (interleaved re, im); dir = -1 forward, +1 inverse, unscaled.  N = 2^a 3^b 5^c 11^d.  Lengths that split into
+ * one or two factors of at most 1024 points run as tile transforms held in LDS (csrc/fft64.hip.h: one or two launches);
+ * *used_tiles (may be NULL) says whether this one did; IMPULSE_HIP_FFT64_GENERIC=1 forces the launch-per-radix-pass form. */
+int imp_debug_fft64(imp_ctx* ctx, const double* x, int64_t B, int64_t N, int dir, double* y, int* used_tiles);
 
 /* ---- K4/K8: in-place gain, fades, decay window (elementwise) ---------------------------------
  * core/hrir.py:530-544 (gain), :591-612 (Hann fade-in), :642-651 (crop + Hann fade-out),
@@ -486,6 +506,8 @@ int imp_slice_info(const imp_slice* slice, int64_t* rows_per_measurement, int64_
 /* the FIRs of a job (host fp64 [2 n_pairs][ld], row r = FIR of row r of every measurement): the curves are per job,
  * core/pipeline.py:668-688 designs them once.  Drains the stream. */
 int imp_slice_set_firs(imp_slice* slice, const double* firs, int64_t ld);
+/* the same from FIRs on the device (imp_curves_equalization_fir_device): no upload, no wait */
+int imp_slice_set_firs_device(imp_slice* slice, const double* d_firs, int64_t ld);
 /* asynchronous on the context's stream; d_out: [M * 2 n_pairs][out_pitch] fp32, out_pitch >= keep_cap + taps - 1; row
  * m * 2 n_pairs + r holds result.out_len valid samples */
 int imp_slice_execute_device(imp_slice* slice, const void* d_rec, int64_t rec_stride, int64_t M, float* d_out,

@@ -2551,3 +2551,28 @@ def test_reflection_levels_golden_from_host_arrays_and_device_rows(gpu_ctx, gold
                     assert abs(v["early_db"] - want[0]) <= 1e-9 and abs(v["late_db"] - want[1]) <= 1e-9, (tag, sp, sd)
     assert all(ir._row is not None for pair in dev.irs.values() for ir in pair.values())      # nothing was pulled to the host
     assert HRIR(Est()).calculate_reflection_levels() == {}
+
+
+@pytest.mark.parametrize("N", [2, 3, 4, 5, 8, 11, 16, 30, 150, 528, 1000, 1024, 1056, 4096, 9600, 19200, 38400, 55296, 65536,
+                               131072, 270336, 524288, 589824, 786432, 1048576])
+def test_fft64_tile_transform_against_numpy(gpu_ctx, N, monkeypatch):
+    """The batched fp64 transform under K6, K2 and the filter-spectrum preparation: lengths up to 1024 points in ONE launch,
+    lengths that split into two factors of at most 1024 points in TWO (tiles held in LDS, decimation in frequency in place,
+    csrc/fft64.hip.h) - forward and inverse against np.fft at 1e-13 of the spectrum's rms scale, over every radix (8, 4, 2,
+    3, 5, 11), the sizes of the FIR design (19 200 / 38 400 / 65 536 / 131 072), of the normalisation's chirp-z transform and
+    of the filter spectra (270 336 = 2^13 x 3 x 11, 589 824, 786 432), ragged batches (tiles of 16 / 8 vectors), and
+    against the launch-per-radix-pass form it replaces."""
+    rng = np.random.default_rng(N)
+    B = 3 if N > 100000 else (21 if N <= 1024 else 5)
+    x = rng.standard_normal((B, N)) + 1j * rng.standard_normal((B, N))
+    for inverse in (False, True):
+        y, tiles = gpu_ctx.fft64(x, inverse=inverse)
+        assert tiles
+        ref = np.fft.ifft(x, axis=1) * N if inverse else np.fft.fft(x, axis=1)
+        assert np.max(np.abs(y - ref)) <= 1e-13 * np.sqrt(N) * np.sqrt(2.0) * max(1.0, np.log2(N))
+    monkeypatch.setenv("IMPULSE_HIP_FFT64_GENERIC", "1")
+    # (the switch is read once per process: the generic form is reached through a length the tiles do not take)
+    if N == 1048576:
+        big = rng.standard_normal((1, 1 << 21)) + 0j
+        yb, tiles = gpu_ctx.fft64(big)
+        assert not tiles and np.max(np.abs(yb - np.fft.fft(big, axis=1))) <= 1e-13 * np.sqrt(1 << 21) * 30

@@ -260,3 +260,56 @@ def test_run_slice_jobs_workers_overlap_and_order():
     for m in range(5):
         assert got[m][0].irs["FL"]["left"]._data is not None and got[m][0].irs["FL"]["left"].data.dtype == np.float64
         assert_same_as_staged(got[m], staged_measurement(e, [(meas[m][0], spk)], firs))
+
+
+def test_firs_left_on_the_device_are_the_same_firs():
+    """process_equalization_batch(on_device=True) leaves the minimum-phase FIRs on the device (core/pipeline.py:690-691 hands
+    every FIR straight to ImpulseResponse.equalize: they never need to visit the host): the rows are the host version's bits,
+    ConvPlan.set_filters_device forms the same spectra as set_filters, HRIR.equalize_channels and the resident slice take
+    the batch where it is - and the slice's results do not change."""
+    from impulse_hip import ConvPlan, _native
+    from impulse_hip.frequency_response import FrequencyResponse
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.parallel_workers import process_equalization_batch
+    from impulse_hip.pipeline_slice import run_slice
+    from impulse_hip.resident_slice import Layout, ResidentSlice
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=fs)
+    spk = ["FL", "FR", "FC"]
+    common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
+    target = FrequencyResponse(name="target", frequency=common.copy(), raw=0)
+    rng = np.random.default_rng(8)
+    room = {sp: {sd: FrequencyResponse("r", frequency=common.copy(), raw=0, error=np.cumsum(rng.standard_normal(len(common))) * 0.2)
+                 for sd in ("left", "right")} for sp in spk}
+    tasks = [(sp, sd) for sp in spk for sd in ("left", "right")]
+    host = process_equalization_batch(tasks, room, None, None, None, None, target, common, fs)
+    dev = process_equalization_batch(tasks, room, None, None, None, None, target, common, fs, on_device=True)
+    assert all(isinstance(f, _native.DeviceFir) for _, _, f in dev)
+    for (sp, sd, fh), (sp2, sd2, fd) in zip(host, dev):
+        assert (sp, sd) == (sp2, sd2) and len(fd) == len(fh) == 9600
+        assert np.array_equal(np.asarray(fd), fh)
+    batch = dev[0][2].batch
+    # the spectra of a plan: from the device batch == from the host matrix
+    ctx = batch.ctx
+    x = rng.standard_normal((6, 30000)).astype(np.float32)
+    p_host = ConvPlan(ctx, np.stack([f for _, _, f in host]), 30000, "full", ws_channels=6)
+    p_dev = ConvPlan(ctx, None, 30000, "full", ws_channels=6, empty_M=9600, n_filters=6)
+    p_dev.set_filters_device(batch.ready().ptr, 9600)
+    assert np.array_equal(p_host.execute(x), p_dev.execute(x))
+    p_host.close()
+    p_dev.close()
+    # the staged path and the resident slice with the device batch == with the host FIRs
+    frames = synth_frames(e, spk, 31337)
+    layout = Layout(e, [(frames.shape[0], 2, spk)])
+    f_host = {(sp, sd): f for sp, sd, f in host}
+    f_dev = {(sp, sd): f for sp, sd, f in dev}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = run_slice(e, [((fs, frames), spk)], firs=f_host)
+        got = run_slice(e, [((fs, frames), spk)], firs=f_dev)
+        assert_same_as_staged(got, want)
+        rs = ResidentSlice(e, layout, max_measurements=1)
+        rs.set_firs(f_dev)
+        assert isinstance(rs.firs, _native.DeviceFirs)
+        assert_same_as_staged(rs.run([[frames]])[0], want)
+        rs.close()
