@@ -1033,6 +1033,49 @@ extern "C" int imp_plan_spectrum(imp_plan* p, void** dptr, size_t* bytes) {
   return IMP_OK;
 }
 
+// The prepared spectrum of `src` into `dst` (a plan of the same geometry, made empty) - the one datum GPUs share: device 0
+// prepares it, the other devices of a single process receive a peer copy (between processes: imp_plan_broadcast_spectrum).
+extern "C" int imp_plan_copy_spectrum(imp_plan* dst, imp_plan* src) {
+  if (!dst || !src) return fail(IMP_ERR_INVALID, "imp_plan_copy_spectrum: null argument");
+  if (dst == src) return IMP_OK;
+  if (dst->paired != src->paired || dst->fused != src->fused || dst->N1 != src->N1 || dst->M != src->M || dst->L != src->L ||
+      dst->mode != src->mode || dst->n_filters != src->n_filters || dst->ola_parts != src->ola_parts)
+    return fail(IMP_ERR_INVALID, "imp_plan_copy_spectrum: the two plans differ in geometry");
+  void *d = nullptr, *s_ = nullptr;
+  size_t nd = 0, ns = 0;
+  int rc;
+  if ((rc = imp_plan_spectrum(src, &s_, &ns)) || (rc = imp_plan_spectrum(dst, &d, &nd))) return rc;
+  if (nd != ns) return fail(IMP_ERR_INVALID, "imp_plan_copy_spectrum: spectrum sizes differ");
+  {
+    IMP_CTX_LOCK(src->ctx);                              // the source must be complete
+    if ((rc = ctx_bind(src->ctx))) return rc;
+    HIP_TRY(hipStreamSynchronize(src->ctx->stream));
+  }
+  IMP_CTX_LOCK(dst->ctx);
+  if ((rc = ctx_bind(dst->ctx))) return rc;
+  if ((rc = plan_sync_lanes(dst))) return rc;
+  HIP_TRY(hipMemcpyPeerAsync(d, dst->ctx->device, s_, src->ctx->device, ns, dst->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(dst->ctx->stream));
+  return IMP_OK;
+}
+
+// bytes from a buffer of one context's device to a buffer of another's (or the same device's): waits for the source
+// context's stream, then copies in the order of the destination context's stream (asynchronous there)
+extern "C" int imp_memcpy_peer(imp_ctx* dst_ctx, void* dst, imp_ctx* src_ctx, const void* src, size_t bytes) {
+  if (!dst_ctx || !src_ctx || (bytes && (!dst || !src))) return fail(IMP_ERR_INVALID, "imp_memcpy_peer: null argument");
+  if (!bytes) return IMP_OK;
+  int rc;
+  {
+    IMP_CTX_LOCK(src_ctx);
+    if ((rc = ctx_bind(src_ctx))) return rc;
+    HIP_TRY(hipStreamSynchronize(src_ctx->stream));
+  }
+  IMP_CTX_LOCK(dst_ctx);
+  if ((rc = ctx_bind(dst_ctx))) return rc;
+  HIP_TRY(hipMemcpyPeerAsync(dst, dst_ctx->device, src, src_ctx->device, bytes, dst_ctx->stream));
+  return IMP_OK;
+}
+
 extern "C" int imp_plan_set_timing(imp_plan* p, int enable) {
   if (!p) return fail(IMP_ERR_INVALID, "null plan");
   IMP_CTX_LOCK(p->ctx);

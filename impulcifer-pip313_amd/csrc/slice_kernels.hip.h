@@ -104,13 +104,11 @@ __device__ inline long long slice_next_fast_len(long long n) {
   return best;
 }
 
-// ---- crop_tails: the common length of a measurement and the tables of the compaction + fade-out launch ----------------
+// ---- crop_tails: the common length of a measurement (the truncation and the fade-out happen in K5's loader) ------------
 // One thread per measurement.
 __global__ __launch_bounds__(64) void slice_keep_kernel(const KneeRow* __restrict__ knee, const int64_t* __restrict__ off2,
                                                         const int64_t* __restrict__ len2, int rows_per_meas, int n_meas,
-                                                        long long fade_out, long long keep_cap, long long pitch_crop,
-                                                        long long taps, int64_t* __restrict__ crop_dst_off,
-                                                        int64_t* __restrict__ crop_len, WindowParams* __restrict__ crop_par,
+                                                        long long fade_out, long long keep_cap, long long taps,
                                                         long long* __restrict__ keep_out, long long* __restrict__ out_len,
                                                         SliceRowOut* __restrict__ rows, SliceMeasOut* __restrict__ meas,
                                                         int* __restrict__ meas_flags) {
@@ -137,21 +135,6 @@ __global__ __launch_bounds__(64) void slice_keep_kernel(const KneeRow* __restric
   if (keep > keep_cap) {
     flags |= SLICE_KEEP_CAP;
     keep = keep_cap;                                     // (the outputs of a flagged measurement are not used)
-  }
-  const long long fo = fade_out > keep ? keep : fade_out;
-  for (int r = 0; r < rows_per_meas; ++r) {
-    const int b = m * rows_per_meas + r;
-    crop_dst_off[b] = (long long)b * pitch_crop;
-    crop_len[b] = keep;
-    WindowParams p;
-    p.gain = 1.0f;
-    p.fade_in = 0;
-    p.fade_out = fo;
-    p.decay_start = 0;
-    p.decay_half = -1;
-    p.decay_knee = 0;
-    p.decay_level_db = 0.f;
-    crop_par[b] = p;
   }
   keep_out[m] = keep;
   out_len[m] = keep > 0 ? keep + taps - 1 : 0;
@@ -207,20 +190,34 @@ __global__ __launch_bounds__(64) void slice_gain_kernel(const double* __restrict
   meas_flags[m] = flags;
 }
 
-// K5's view of the cropped rows: row b belongs to measurement b / rows_per_meas, whose length crop_tails decided on the
-// device; its FIR is filter b % rows_per_meas.  fir_block_kernel reads lengths and the block count through these hooks.
+// K5's view of the rows crop_tails leaves: row b starts at off2[b] of the deconvolved columns (crop_heads put it there),
+// is keep[b / rows_per_meas] samples long (crop_tails decided that on the device) and ends in a Hann fade-out of `fade_out`
+// samples - hann(2 fade_out)[fade_out:], read from a table (a cosine per sample in this kernel would cost it a stack
+// frame), applied as the window kernel of the staged path applies it: (float)((double)x * g).  Its FIR is filter
+// b % rows_per_meas.  No compacted copy of the rows is made: the truncation is the buffer's range, the fade happens on
+// load.  fir_block_kernel reads lengths and the block count through these hooks.
 struct LoadRowsDeviceLen {
   static constexpr bool kDeviceLen = true;
-  const float* __restrict__ base;
-  long long chan_stride;
+  const float* __restrict__ base;           // the deconvolved columns
+  const int64_t* __restrict__ off;          // [rows] first sample of every row
   const long long* __restrict__ len_of;     // [measurements]
   int rows_per_meas;
   long long taps;
+  long long fade_out;
+  const double* __restrict__ win;           // [fade_out]
   __host__ __device__ LoadRowsDeviceLen shifted(long long, long long) const { return *this; }
   struct Row {
     __amdgpu_buffer_rsrc_t r;
-    __device__ __forceinline__ cf finish(cf v, int) const { return v; }
+    int n, fade;
+    const double* __restrict__ win;
     __device__ __forceinline__ cf pair_at(int s) const { return bload_cf<kStreamAux>(r, (unsigned)s * 4u, 0u); }
+    __device__ __forceinline__ cf finish(cf v, int s) const {
+      if (fade > 0 && s + 1 >= n - fade && s < n) {          // only the tail pays for the window
+        if (s >= n - fade) v.x = (float)((double)v.x * win[s - (n - fade)]);
+        if (s + 1 < n) v.y = (float)((double)v.y * win[s + 1 - (n - fade)]);
+      }
+      return v;
+    }
   };
   __device__ __forceinline__ long long row_len(int b) const { return len_of[b / rows_per_meas]; }
   __device__ __forceinline__ long long out_len(int b) const {
@@ -230,7 +227,7 @@ struct LoadRowsDeviceLen {
   __device__ __forceinline__ int filter_of(int b) const { return b % rows_per_meas; }
   __device__ __forceinline__ Row open(int b) const {
     const long long n = row_len(b);
-    return Row{make_rsrc(base + (long long)b * chan_stride, (unsigned)(n > 0 ? n : 0) * 4u)};
+    return Row{make_rsrc(base + off[b], (unsigned)(n > 0 ? n : 0) * 4u), (int)n, (int)(fade_out <= n ? fade_out : 0), win};
   }
 };
 

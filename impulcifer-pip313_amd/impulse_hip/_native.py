@@ -107,6 +107,8 @@ SIGNATURES = {
     "imp_plan_destroy": (None, [_vp]),
     "imp_plan_info": (C.c_int, [_vp, _pi64, _pi64, _pi64, _pi64]),
     "imp_plan_spectrum": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "imp_plan_copy_spectrum": (C.c_int, [_vp, _vp]),
+    "imp_memcpy_peer": (C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t]),
     "imp_conv_execute": (C.c_int, [_vp, _pf, _i64, _i64, _pf, _i64]),
     "imp_conv_execute_interleaved": (C.c_int, [_vp, _pf, _i64, _pf, _i64]),
     "imp_conv_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64]),
@@ -285,6 +287,11 @@ class Context:
 
     def d2d(self, dst, src, nbytes):
         _check(self._lib.imp_memcpy_d2d(self._h, _vp(int(dst)), _vp(int(src)), int(nbytes)))
+
+    def copy_from(self, dst, src_ctx, src, nbytes):
+        """nbytes from `src` on src_ctx's device to `dst` on this context's device (peer copy; waits for src_ctx's stream,
+        asynchronous on this context's)"""
+        _check(self._lib.imp_memcpy_peer(self._h, _vp(int(dst)), src_ctx.handle, _vp(int(src)), int(nbytes)))
 
     def memset(self, dptr, value, nbytes):
         _check(self._lib.imp_memset(self._h, _vp(int(dptr)), int(value), int(nbytes)))
@@ -973,6 +980,10 @@ class ConvPlan:
     def handle(self):
         return self._h
 
+    def copy_spectrum_from(self, src_plan):
+        """the prepared spectrum of a plan of the same geometry on another context / device (peer copy)"""
+        _check(self._lib.imp_plan_copy_spectrum(self._h, src_plan.handle))
+
     def spectrum_buffer(self):
         p, n = _vp(), C.c_size_t()
         _check(self._lib.imp_plan_spectrum(self._h, C.byref(p), C.byref(n)))
@@ -1208,8 +1219,48 @@ _thread_ctx = threading.local()
 
 
 def default_device():
-    """the device index the package's default context lives on (IMPULSE_HIP_DEVICE, default 0)"""
+    """the device index the package's default context lives on: the first entry of IMPULSE_HIP_DEVICES, else
+    IMPULSE_HIP_DEVICE, else 0"""
+    spec = os.environ.get("IMPULSE_HIP_DEVICES", "").strip()
+    if spec:
+        return int(spec.replace(";", ",").split(",")[0])
     return int(os.environ.get("IMPULSE_HIP_DEVICE", "0"))
+
+
+def device_list():
+    """IMPULSE_HIP_DEVICES = "0,1,2,...": the devices the classes shard channel pairs over from this ONE process (one
+    context and one host thread per entry; an index may repeat: two contexts folded on one device).  Unset: the default
+    device alone."""
+    spec = os.environ.get("IMPULSE_HIP_DEVICES", "").strip()
+    if not spec:
+        return [default_device()]
+    return [int(v) for v in spec.replace(";", ",").split(",") if v.strip() != ""]
+
+
+_device_ctxs = None
+_device_spec = None
+
+
+def root_context():
+    """the process-wide default context, whatever the calling thread has installed with using_context"""
+    global _default_ctx
+    with _default_lock:
+        if _default_ctx is None or not _default_ctx._h:
+            _default_ctx = Context(default_device())
+        return _default_ctx
+
+
+def device_contexts():
+    """[root context, one more context per further entry of IMPULSE_HIP_DEVICES]: what estimate_batch and the recording
+    ingest shard over.  Made once per value of the variable."""
+    global _device_ctxs, _device_spec
+    devs = device_list()
+    root = root_context()
+    with _default_lock:
+        if _device_ctxs is None or _device_spec != tuple(devs) or any(not c._h for c in _device_ctxs):
+            _device_ctxs = [root] + [Context(d) for d in devs[1:]]
+            _device_spec = tuple(devs)
+        return list(_device_ctxs)
 
 
 def default_context():
@@ -1218,10 +1269,7 @@ def default_context():
     override = getattr(_thread_ctx, "ctx", None)
     if override is not None:
         return override
-    with _default_lock:
-        if _default_ctx is None:
-            _default_ctx = Context(int(os.environ.get("IMPULSE_HIP_DEVICE", "0")))
-        return _default_ctx
+    return root_context()
 
 
 def aux_context():
@@ -1230,7 +1278,7 @@ def aux_context():
     global _aux_ctx
     with _default_lock:
         if _aux_ctx is None or not _aux_ctx._h:
-            _aux_ctx = Context(int(os.environ.get("IMPULSE_HIP_DEVICE", "0")))
+            _aux_ctx = Context(default_device())
         return _aux_ctx
 
 

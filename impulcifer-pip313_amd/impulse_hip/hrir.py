@@ -186,7 +186,11 @@ def ingest_pcm_frames(estimator, expected_fs, fs, frames, speakers, side=None, s
         # column the reference keeps beside every response (core/hrir.py:336-341), is cut from the PCM block on demand
         pitch = (plan.out_len + 63) // 64 * 64
         block = DeviceBlock(plan.ctx, len(starts) * tracks * pitch)
-        plan.execute_pcm_columns_device(frames, starts, block.ptr, pitch)
+        ctxs = _native.device_contexts() if getattr(_native._thread_ctx, "ctx", None) is None else None
+        if ctxs is not None and len(ctxs) > 1 and len(starts) > 1 and plan.ctx is ctxs[0]:
+            _ingest_columns_sharded(estimator, ctxs, frames, starts, length, plan, block, pitch, side is None and tracks == 2)
+        else:
+            plan.execute_pcm_columns_device(frames, starts, block.ptr, pitch)
         for sp, sd, tr, a, b in group:
             row = Row(block, (starts.index(origin + a) * tracks + tr) * pitch, plan.out_len)
             column = (lambda a=a, b=b, tr=tr: frames[origin + a: origin + b, tr].astype(np.float64) * scale)
@@ -195,6 +199,37 @@ def ingest_pcm_frames(estimator, expected_fs, fs, frames, speakers, side=None, s
     for sp, sd, *_ in jobs:
         ordered.setdefault(sp, {})[sd] = irs[sp][sd]
     return ordered
+
+
+def _ingest_columns_sharded(estimator, ctxs, frames, starts, length, plan, block, pitch, paired):
+    """The columns of a recording over the devices of IMPULSE_HIP_DEVICES: every device uploads the frames of ITS columns
+    (a contiguous stretch of the PCM block), deconvolves them with its own copy of the inverse-sweep spectrum, and the rows
+    are gathered (peer copies) into the root device's block, where the later stages run - same rows, same bits."""
+    from .sharding import device_shards, run_sharded
+    tracks = frames.shape[1]
+    root = ctxs[0]
+
+    def work(ctx, lo, hi):
+        cols = starts[lo:hi]
+        first, last = cols[0], cols[-1] + length
+        sub = frames[first:last]
+        rel = [c - first for c in cols]
+        if ctx is root:
+            plan.execute_pcm_columns_device(sub, rel, block.ptr + lo * tracks * pitch * 4, pitch)
+            return None
+        p = estimator._plan(length, paired=paired)
+        nbytes = len(cols) * tracks * pitch * 4
+        tmp = ctx.malloc(nbytes)
+        p.execute_pcm_columns_device(sub, rel, tmp, pitch)
+        return (ctx, tmp, lo, nbytes)
+
+    shards = device_shards(len(starts), len(ctxs), keep_pairs=False)       # the unit is a column (both ears of a speaker)
+    for res in run_sharded(ctxs, shards, work):
+        if res is not None:
+            ctx, tmp, lo, nbytes = res
+            root.copy_from(block.ptr + lo * tracks * pitch * 4, ctx, tmp, nbytes)
+            root.synchronize()                               # the copy has landed: the source block may go
+            ctx.free(tmp)
 
 
 def _rows_matrix(rows):

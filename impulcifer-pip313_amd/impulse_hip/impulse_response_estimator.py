@@ -129,16 +129,28 @@ class ImpulseResponseEstimator(object):
         error the un-cropped column shows near Nyquist."""
         L = int(L)
         ctx = _native.default_context()
-        key = (L, bool(paired), id(ctx))
         with self._plan_lock:
-            plan = self._plans.get(key)
-            if plan is not None and not plan._h:           # its context was closed
-                plan = None
-            if plan is None:
-                plan = _native.ConvPlan(ctx, np.asarray(self.inverse_filter, dtype=np.float64), L, "same",
-                                        paired="auto" if paired else False)
-                self._plans[key] = plan
-            return plan
+            return self._plan_on(ctx, L, bool(paired))
+
+    def _plan_on(self, ctx, L, paired):
+        """(under the plan lock)  The inverse-sweep spectrum is prepared once, on the process's root context; the plan of
+        any other context - another device of IMPULSE_HIP_DEVICES, a worker's stream - is made empty and receives a copy
+        (hipMemcpyPeer: the one datum the GPUs of a process share)."""
+        key = (L, paired, id(ctx))
+        plan = self._plans.get(key)
+        if plan is not None and not plan._h:               # its context was closed
+            plan = None
+        if plan is None:
+            root = _native.root_context()
+            inv = np.asarray(self.inverse_filter, dtype=np.float64)
+            if ctx is root:
+                plan = _native.ConvPlan(ctx, inv, L, "same", paired="auto" if paired else False)
+            else:
+                src = self._plan_on(root, L, paired)
+                plan = _native.ConvPlan(ctx, None, L, "same", empty_M=len(inv), n_filters=1, paired=src.paired)
+                plan.copy_spectrum_from(src)
+            self._plans[key] = plan
+        return plan
 
     def estimate(self, recording):
         """Impulse response of one recorded channel: convolve(recording, inverse_filter, 'same')."""
@@ -156,7 +168,16 @@ class ImpulseResponseEstimator(object):
             raise ValueError("estimate_batch() takes [B, L]")
         if rec.shape[0] == 0 or rec.shape[1] == 0:
             return np.zeros(rec.shape, dtype=dtype)
-        out = self._plan(rec.shape[1]).execute(rec)
+        ctxs = _native.device_contexts() if getattr(_native._thread_ctx, "ctx", None) is None else None
+        if ctxs is not None and len(ctxs) > 1 and rec.shape[0] > 1:
+            # several devices in this process (IMPULSE_HIP_DEVICES): contiguous channel blocks, pairs kept together, one host
+            # thread per device - the reference's pool over channels (core/parallel_utils.py:97-152) with a GPU per worker
+            from .sharding import device_shards, run_sharded
+            shards = device_shards(rec.shape[0], len(ctxs))
+            parts = run_sharded(ctxs, shards, lambda ctx, lo, hi: self._plan(rec.shape[1]).execute(rec[lo:hi]))
+            out = np.concatenate(parts, axis=0)
+        else:
+            out = self._plan(rec.shape[1]).execute(rec)
         return out if dtype == np.float32 else out.astype(dtype)
 
     def estimate_frames(self, frames, dtype=np.float64):

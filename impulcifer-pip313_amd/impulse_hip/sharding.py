@@ -22,6 +22,36 @@ def shard_channels(n_channels, world_size, rank, keep_pairs=True):
     return lo * unit, hi * unit
 
 
+def device_shards(n_channels, n_devices, keep_pairs=True):
+    """[(device index, lo, hi)] - the non-empty contiguous channel blocks of shard_channels over n_devices, in channel
+    order: what ONE process hands its per-device contexts (impulse_hip._native.device_contexts)."""
+    out = []
+    for r in range(max(1, int(n_devices))):
+        lo, hi = shard_channels(n_channels, max(1, int(n_devices)), r, keep_pairs)
+        if hi > lo:
+            out.append((r, lo, hi))
+    return out
+
+
+def run_sharded(contexts, shards, work):
+    """work(context, lo, hi) for every shard, one host thread per device (the calling thread takes the first shard);
+    results in shard order.  Each thread runs with its context installed as the package default (using_context)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from . import _native
+
+    def call(item):
+        r, lo, hi = item
+        with _native.using_context(contexts[r]):
+            return work(contexts[r], lo, hi)
+
+    if len(shards) <= 1:
+        return [call(s) for s in shards]
+    with ThreadPoolExecutor(max_workers=len(shards) - 1, thread_name_prefix="impulse-dev") as pool:
+        rest = [pool.submit(call, s) for s in shards[1:]]
+        first = call(shards[0])
+        return [first] + [f.result() for f in rest]
+
+
 def broadcast_bytes(buf, dist, src=0):
     """Broadcast a torch uint8 tensor in place from ``src`` (thin wrapper so tests can use gloo)."""
     dist.broadcast(buf, src=src)

@@ -132,6 +132,16 @@ int imp_plan_info(const imp_plan* plan, int64_t* nfft, int64_t* out_len, int64_t
  * datum shared between GPUs: rank 0 builds it, the others receive it with an RCCL broadcast. */
 int imp_plan_spectrum(imp_plan* plan, void** dptr, size_t* bytes);
 
+/* Single process, several GPUs (the reference's fan-out is a pool over channels inside ONE process, core/parallel_utils.py:
+ * 97-152): one context per device, channel pairs sharded over them by the host (impulse_hip/sharding.py), one host thread
+ * per device.  The spectrum is prepared on one device and COPIED to the plans of the others (hipMemcpyPeer: xGMI inside a
+ * node); dst must be an empty plan of the same geometry (imp_conv_plan_create_ex with filter = NULL).  Returns when the
+ * copy has landed. */
+int imp_plan_copy_spectrum(imp_plan* dst, imp_plan* src);
+/* bytes between buffers of two contexts (different devices or the same): waits for src_ctx's stream, then copies in the
+ * order of dst_ctx's stream (asynchronous there) - how deconvolved rows are gathered on the device that runs the later stages */
+int imp_memcpy_peer(imp_ctx* dst_ctx, void* dst, imp_ctx* src_ctx, const void* src, size_t bytes);
+
 /* host in / host out, planar: x[B][ld_in] -> y[B][ld_out] (first out_len samples of each row) */
 int imp_conv_execute(imp_plan* plan, const float* x, int64_t B, int64_t ld_in, float* y, int64_t ld_out);
 /* host in, interleaved frames[L][C] (WAV wire order, core/hrir.py:202-219 columns) -> planar y[C][ld_out] */

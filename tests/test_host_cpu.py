@@ -516,3 +516,46 @@ def test_surface_hygiene_refusals_and_reference_quirks():
     import impulse_hip.impulse_response as ir_mod
     for mod in (hrir_mod, ir_mod):
         assert "plotting" not in open(mod.__file__).read()
+
+
+def test_device_shards_partition_and_result_order():
+    """Single-process multi-device fan-out (IMPULSE_HIP_DEVICES): the partition of channels over per-device contexts -
+    contiguous, pairs kept together, empty shards dropped - and run_sharded's contract: one call per shard with that
+    shard's context installed for the calling thread, results in channel order whatever order the threads finish in."""
+    import threading
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "impulcifer-pip313_amd"))
+    from impulse_hip import _native
+    from impulse_hip.sharding import device_shards, run_sharded
+    assert device_shards(16, 1) == [(0, 0, 16)]
+    assert device_shards(16, 3) == [(0, 0, 6), (1, 6, 12), (2, 12, 16)]            # pairs stay together
+    assert device_shards(5, 2, keep_pairs=False) == [(0, 0, 3), (1, 3, 5)]
+    assert device_shards(2, 4) == [(0, 0, 2)]                                       # one pair: one device
+    assert device_shards(7, 8, keep_pairs=False) == [(r, r, r + 1) for r in range(7)]
+    for n, d in ((1024, 8), (26, 4), (3, 2)):
+        sh = device_shards(n, d)
+        assert sh[0][1] == 0 and sh[-1][2] == n and all(a[2] == b[1] for a, b in zip(sh, sh[1:]))
+    ctxs = [object() for _ in range(4)]
+    seen = {}
+
+    def work(ctx, lo, hi):
+        assert _native.default_context() is ctx                  # the shard's context is the package default in this thread
+        seen[lo] = threading.current_thread().name
+        time.sleep(0.02 * (4 - ctxs.index(ctx)))                 # later shards finish first
+        return list(range(lo, hi))
+
+    parts = run_sharded(ctxs, device_shards(26, 4), work)
+    assert sum(parts, []) == list(range(26))
+    assert len(set(seen.values())) == 4                          # one host thread per device
+    assert getattr(_native._thread_ctx, "ctx", None) is None     # nothing left installed in the calling thread
+    # the device list: IMPULSE_HIP_DEVICES names the devices (the first is the root), else IMPULSE_HIP_DEVICE alone
+    env = dict(os.environ)
+    try:
+        os.environ.pop("IMPULSE_HIP_DEVICES", None)
+        os.environ["IMPULSE_HIP_DEVICE"] = "3"
+        assert _native.device_list() == [3] and _native.default_device() == 3
+        os.environ["IMPULSE_HIP_DEVICES"] = "2, 0,5"
+        assert _native.device_list() == [2, 0, 5] and _native.default_device() == 2
+    finally:
+        os.environ.clear()
+        os.environ.update(env)

@@ -313,3 +313,47 @@ def test_firs_left_on_the_device_are_the_same_firs():
         assert isinstance(rs.firs, _native.DeviceFirs)
         assert_same_as_staged(rs.run([[frames]])[0], want)
         rs.close()
+
+
+def test_single_process_multi_device_fan_out_folded(monkeypatch):
+    """IMPULSE_HIP_DEVICES = "0,0,0": three contexts folded onto the one device of this box - what a process on a multi-GPU
+    node does with "0,1,2".  estimate_batch shards its rows (pairs kept together) and open_recording_frames the columns of
+    the recording over the contexts, one host thread each, every context's plan holding a COPY of the root's inverse-sweep
+    spectrum (imp_plan_copy_spectrum); the deconvolved rows are gathered on the root device.  Results: bit-identical to
+    the single-context run, for the one-channel-per-transform plan (estimate_batch) and the pair plan (recording ingest)."""
+    from impulse_hip import _native
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=fs)
+    spk = ["FL", "FR", "FC", "BL", "BR"]
+    frames = synth_frames(e, spk, 2718)
+    L = len(e) + 2 * fs
+    rows = np.ascontiguousarray(frames[2 * fs: 2 * fs + 3 * L].T.reshape(2, 3, L).transpose(1, 0, 2).reshape(6, L)).astype(np.float32)
+    monkeypatch.delenv("IMPULSE_HIP_DEVICES", raising=False)
+    one = e.estimate_batch(rows, dtype=np.float32)
+    h1 = HRIR(e)
+    h1.open_recording_frames(fs, frames, spk)
+    want = {(sp, sd): h1.irs[sp][sd].peek() for sp in spk for sd in ("left", "right")}
+    monkeypatch.setenv("IMPULSE_HIP_DEVICES", "0,0,0")
+    ctxs = _native.device_contexts()
+    assert len(ctxs) == 3 and len({id(c) for c in ctxs}) == 3 and ctxs[0] is _native.root_context()
+    many = e.estimate_batch(rows, dtype=np.float32)
+    assert np.array_equal(one, many)
+    h3 = HRIR(e)
+    h3.open_recording_frames(fs, frames, spk)
+    assert list(h3.irs) == spk
+    for key, ref in want.items():
+        got = h3.irs[key[0]][key[1]]
+        assert got._row is not None and got._row.block.ctx is ctxs[0]          # gathered on the root device
+        assert np.array_equal(got.peek(), ref), key
+    # the later stages run on the root device as before
+    h3.crop_heads()
+    h1.crop_heads()
+    h3.crop_tails()
+    h1.crop_tails()
+    for sp in spk:
+        assert np.array_equal(h3.irs[sp]["left"].peek(), h1.irs[sp]["left"].peek())
+    # every context holds a plan of its own for this length, with the root's spectrum
+    plans = [p for k, p in e._plans.items() if k[0] == L and p._h]
+    assert len({id(p.ctx) for p in plans}) >= 3
