@@ -330,11 +330,27 @@ class SliceTeam:
                 f"keep_cap {rs.keep_cap}, taps {rs.taps}, normalisation transform {rs.slice.norm_fft_len} points, "
                 f"{'pair' if rs.plan.paired else 'mono'} plan of {rs.plan.n1} rows")
 
-    def step(self):
+    def step(self, design=False):
+        """one call per lane; design: the call's FIRs are designed first (K12 -> K6 on the lane's stream, flat target: the
+        curves belong to a job and a call is a job of M measurements) and handed to the slice on the device"""
         for ln in self.lanes:
+            if design:
+                from impulse_hip._native import using_context
+                from impulse_hip.parallel_workers import process_equalization_batch
+                with using_context(ln["ctx"]):
+                    firs = process_equalization_batch(self.layout.tasks, None, None, None, None, None, self._target(), self._common,
+                                                      self.est.fs, on_device=True)
+                ln["rs"].set_firs({(sp, sd): f for sp, sd, f in firs})
             ln["rs"].slice.execute_device(ln["d_in"][ln["k"] % len(ln["d_in"])], self.layout.samples, self.M, ln["d_out"],
                                           ln["rs"].out_pitch)
             ln["k"] += 1
+
+    def _target(self):
+        from impulse_hip.frequency_response import FrequencyResponse
+        if getattr(self, "_tgt", None) is None:
+            self._common = FrequencyResponse.generate_frequencies(f_min=10, f_max=self.est.fs / 2, f_step=1.01)
+            self._tgt = FrequencyResponse(name="target", frequency=self._common.copy(), raw=0)
+        return self._tgt
 
     def sync(self):
         for ln in self.lanes:
@@ -679,7 +695,7 @@ PMC_KEYS = ("cols_fwd", "rows_kernel", "cols_inv", "peak_search", "fir_block")
 
 def load_profile_traffic(workload):
     """L2<->fabric bytes per launch from the committed rocprofv3 --pmc summary of this command (profiles/), or None."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as fh:
@@ -819,6 +835,23 @@ def slice_resident_block(est, rec, L, workload, no_pmc=False, n_streams=3, M=8, 
         dt = time.perf_counter() - t0
         flags = team.flags()
         rows, meas = team.results(0)
+        # the same with every call designing its FIRs first (a call = a job of M measurements with curves of its own)
+        team._target()
+        for _ in range(2):
+            team.step(design=True)
+        team.sync()
+        calls_d = max(4, calls // 2)
+        t0 = time.perf_counter()
+        for _ in range(calls_d):
+            team.step(design=True)
+        team.sync()
+        dt_design = time.perf_counter() - t0
+        for ln in team.lanes:                              # back to the job FIRs the checks below use
+            ln["rs"].set_firs(team.firs)
+        team.step()
+        team.sync()
+        flags = sorted(set(flags) | set(team.flags()))
+        rows, meas = team.results(0)
         out = team.fetch(0)
         rs = team.lanes[0]["rs"]
         firs = {t: team.firs[i] for i, t in enumerate(team.layout.tasks)}
@@ -839,6 +872,10 @@ def slice_resident_block(est, rec, L, workload, no_pmc=False, n_streams=3, M=8, 
     alg = in_bytes + out_bytes
     block = dict(value=rate, unit="IR/s", timed_region_s=dt, calls=calls * n_streams, measurements_per_call=M, streams=n_streams,
                  ms_per_call_per_stream=dt / calls * 1e3, arrangement=desc,
+                 with_fir_design_per_call=dict(value=calls_d * n_streams * M * rows_per / dt_design, unit="IR/s", calls=calls_d * n_streams,
+                                               note="every call designs its 16 minimum-phase FIRs first (K12 -> K6 on the call's "
+                                                    "stream, left on the device, spectra formed there): a job of M measurements "
+                                                    "with equalisation curves of its own per call"),
                  keep=int(meas["keep"][0]), out_len=n, flags_seen=flags, no_measurement_flagged=flags == [0],
                  bit_identical_to_staged_path=bool(same),
                  algorithmic_bytes_per_ir=alg, path_achieved=rate * alg / 1e9, path_frac=rate * alg / 1e9 / HBM_PEAK_GBS,

@@ -156,7 +156,9 @@ class ResidentSlice:
             if (firs.B, firs.taps) != (self.slice.rows, self.taps) or firs.ctx.device != self.ctx.device:
                 raise ValueError(f"device FIRs must be [{self.slice.rows}, {self.taps}] on device {self.ctx.device}")
             self.firs = firs
-            self.slice.set_firs_device(firs.ready().ptr, firs.taps)
+            if firs.ctx is not self.ctx:
+                firs.ready()                               # designed on another stream: wait for it (once)
+            self.slice.set_firs_device(firs.ptr, firs.taps)     # same context: stream order is enough
             return
         self.firs = np.ascontiguousarray(firs, dtype=np.float64)
         self.slice.set_firs(self.firs)

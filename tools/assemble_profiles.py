@@ -11,13 +11,24 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, HERE)
 import pmc_summary  # noqa: E402
 
-CALLS = {"c2": "one chain call = 32 channels (two 7.1 measurements) at circular length 540672, FIR stage 32640 (*) 9600",
-         "c3": "one chain call = 26 channels at circular length 1179648, FIR stage 65280 (*) 19200"}
+CALLS = {"c2": "one chain call = 32 channels (two 7.1 measurements) at circular length 540672 (one-channel-per-transform plan), FIR stage 32640 (*) 9600",
+         "c3": "one chain call = 26 channels at circular length 1179648 (pair-mode plan, 288 rows), FIR stage 65280 (*) 19200",
+         "c5": "K1 alone, launch groups of 8 channels at circular length 1572864 (pair-mode plan, 384 rows)"}
 
 
-def main(out, tag="r03"):
+def main(out, tag="r04"):
     prof = os.path.join(ROOT, "profiles")
-    for sub, name in (("trace", f"{tag}_kernel_stats.csv"), ("trace_serial", f"{tag}_kernel_stats_serial.csv")):
+    for name, dst in (("slice_rate_serial.txt", f"{tag}_slice_rate_serial.txt"), ("slice_rate.txt", f"{tag}_slice_rate.txt"),
+                      ("eq_fir.txt", f"{tag}_eq_fir.txt"), ("slice_stages.txt", f"{tag}_slice_stages.txt"),
+                      ("column_error.txt", f"{tag}_column_error.txt")):
+        src = os.path.join(out, name)
+        if os.path.exists(src) and os.path.getsize(src):
+            with open(src) as fh:
+                text = "".join(ln for ln in fh if "simple_timer.cpp" not in ln and "UserWarning" not in ln and "warnings.warn" not in ln)
+            open(os.path.join(prof, dst), "w").write(text)
+    for sub, name in (("trace", f"{tag}_kernel_stats.csv"), ("trace_serial", f"{tag}_kernel_stats_serial.csv"),
+                      ("trace_slice_serial", f"{tag}_slice_kernel_stats_serial.csv"), ("trace_slice", f"{tag}_slice_kernel_stats.csv"),
+                      ("trace_eq", f"{tag}_eq_fir_kernel_stats.csv")):
         for root, _, files in os.walk(os.path.join(out, sub)):
             for f in files:
                 if f.endswith("kernel_stats.csv"):
@@ -32,6 +43,8 @@ def main(out, tag="r03"):
         if not os.path.isdir(d):
             continue
         pm = pmc_summary.main(d)
+        if "rows_kernel" not in pm and "rows_single" in pm:
+            pm["rows_kernel"] = pm["rows_single"]              # pair-mode plans: rows_single_kernel is the row pass
         pmc_all[w] = pm
         t = {}
         for k in ("cols_fwd", "rows_kernel", "cols_inv", "peak_search", "fir_block"):
@@ -53,4 +66,4 @@ def main(out, tag="r03"):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r03")
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "r04")
