@@ -896,6 +896,7 @@ static int magnitude_db_core(imp_ctx* ctx, const double* x, const float* d_rows,
 // measurements whose row length n_m is known ONLY ON THE DEVICE (crop_tails decided it there).  Same chirp-z identity as
 // above, but the chirp of each measurement is formed on the device from its n_m and the convolution length is fixed by
 // the slice's capacity (mfft >= 2 n_max - 1), so the launch sequence does not depend on any n_m: nothing is read back.
+// The two ear sums are real: they go through ONE complex transform, z = x_L + i x_R, and are separated afterwards.
 // ------------------------------------------------------------------------------------------------
 struct SliceNorm {
   int n_max = 0, mfft = 0, half_max = 0;
@@ -906,7 +907,7 @@ struct SliceNorm {
   cdbl* chirp = nullptr;     // [m_cap][n_max]
   cdbl* bhat = nullptr;      // [m_cap][mfft]      transform of the conjugate chirp
   cdbl* bwork = nullptr;
-  cdbl *a = nullptr, *b = nullptr;     // [2 m_cap][mfft]
+  cdbl *a = nullptr, *b = nullptr;     // [m_cap][mfft]: the two ears of a measurement share a transform
   double* out = nullptr;     // [2 m_cap][half_max]
 };
 
@@ -954,40 +955,49 @@ __global__ __launch_bounds__(256) void sn_chirp_kernel(const long long* __restri
   bb[(long long)m * mfft + j] = v;
 }
 
+// the two ears of a measurement travel as ONE complex signal z = x_L + i x_R (both real): a[m][j] = z[j] chirp[j]
 __global__ __launch_bounds__(256) void sn_pre_kernel(const double* __restrict__ x, const cdbl* __restrict__ chirp,
                                                      const long long* __restrict__ n_of, cdbl* __restrict__ a, int n_max,
                                                      int mfft) {
-  const int g = blockIdx.y, m = g >> 1;
+  const int m = blockIdx.y;
   long long n = n_of[m];
   n = n < n_max ? n : n_max;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= mfft) return;
   cdbl v = make_double2(0.0, 0.0);
   if (j < n) {
-    const double xv = x[(long long)g * n_max + j];
-    const cdbl c = chirp[(long long)m * n_max + j];
-    v = make_double2(xv * c.x, xv * c.y);
+    const cdbl z = make_double2(x[(long long)(2 * m) * n_max + j], x[(long long)(2 * m + 1) * n_max + j]);
+    v = zmul(z, chirp[(long long)m * n_max + j]);
   }
-  a[(long long)g * mfft + j] = v;
+  a[(long long)m * mfft + j] = v;
 }
 
 __global__ __launch_bounds__(256) void sn_mul_kernel(cdbl* __restrict__ a, const cdbl* __restrict__ bhat, int mfft) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= mfft) return;
   cdbl* p = a + (long long)blockIdx.y * mfft + j;
-  *p = zmul(*p, bhat[(long long)(blockIdx.y >> 1) * mfft + j]);
+  *p = zmul(*p, bhat[(long long)blockIdx.y * mfft + j]);
 }
 
+// Z[k] = chirp[k] conv[k] / mfft is the n-point transform of z; the ears' transforms are its Hermitian parts:
+// X_L[k] = (Z[k] + conj Z[n - k]) / 2, X_R[k] = (Z[k] - conj Z[n - k]) / 2i; out[2 m + ear][k] = 20 log10 |X_ear[k]|, k < ceil(n / 2)
 __global__ __launch_bounds__(256) void sn_post_kernel(const cdbl* __restrict__ conv, const cdbl* __restrict__ chirp,
                                                       const long long* __restrict__ n_of, double* __restrict__ out, int n_max,
                                                       int mfft, int half_max) {
-  const int g = blockIdx.y, m = g >> 1;
+  const int m = blockIdx.y;
   long long n = n_of[m];
   n = n < n_max ? n : n_max;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= (n + 1) / 2) return;
-  const cdbl v = zmul(conv[(long long)g * mfft + k], chirp[(long long)m * n_max + k]);
-  out[(long long)g * half_max + k] = 20.0 * log10(hypot(v.x, v.y) / (double)mfft);
+  const cdbl* cv = conv + (long long)m * mfft;
+  const cdbl* ch = chirp + (long long)m * n_max;
+  const int kk = k == 0 ? 0 : (int)(n - k);
+  const cdbl zk = zmul(cv[k], ch[k]), zn = zmul(cv[kk], ch[kk]);
+  const double s = 0.5 / (double)mfft;
+  const cdbl xl = make_double2((zk.x + zn.x) * s, (zk.y - zn.y) * s);
+  const cdbl xr = make_double2((zk.y + zn.y) * s, (zn.x - zk.x) * s);
+  out[(long long)(2 * m) * half_max + k] = 20.0 * log10(hypot(xl.x, xl.y));
+  out[(long long)(2 * m + 1) * half_max + k] = 20.0 * log10(hypot(xr.x, xr.y));
 }
 
 // np.max of out[g][0 : ceil(n_m / 2)] (NaN if the row holds one; -inf for an empty row)
@@ -1054,8 +1064,8 @@ int slice_norm_create(imp_ctx* ctx, int64_t n_max, int64_t m_cap, SliceNorm** ou
             hipMalloc((void**)&p->chirp, M * (size_t)n_max * sizeof(cdbl)) == hipSuccess &&
             hipMalloc((void**)&p->bhat, M * (size_t)mf * sizeof(cdbl)) == hipSuccess &&
             hipMalloc((void**)&p->bwork, M * (size_t)mf * sizeof(cdbl)) == hipSuccess &&
-            hipMalloc((void**)&p->a, 2 * M * (size_t)mf * sizeof(cdbl)) == hipSuccess &&
-            hipMalloc((void**)&p->b, 2 * M * (size_t)mf * sizeof(cdbl)) == hipSuccess &&
+            hipMalloc((void**)&p->a, M * (size_t)mf * sizeof(cdbl)) == hipSuccess &&
+            hipMalloc((void**)&p->b, M * (size_t)mf * sizeof(cdbl)) == hipSuccess &&
             hipMalloc((void**)&p->out, 2 * M * (size_t)p->half_max * sizeof(double)) == hipSuccess;
   if (!ok) {
     (void)hipGetLastError();
@@ -1086,14 +1096,14 @@ int slice_norm_run(imp_ctx* ctx, SliceNorm* p, const float* d_rows, int64_t pitc
   cdbl *cur = p->bhat, *oth = p->bwork;
   if ((rc = run_fft(ctx, p->fac, p->roots, mf, M, -1, &cur, &oth))) return rc;
   const cdbl* bhat = cur;                                  // (either buffer: both belong to the plan)
-  hipLaunchKernelGGL(sn_pre_kernel, grid(mf, 2 * M), dim3(256), 0, s, p->x, p->chirp, d_n, p->a, nm, mf);
+  hipLaunchKernelGGL(sn_pre_kernel, grid(mf, M), dim3(256), 0, s, p->x, p->chirp, d_n, p->a, nm, mf);
   HIP_TRY(hipGetLastError());
   cdbl *c2 = p->a, *o2 = p->b;
-  if ((rc = run_fft(ctx, p->fac, p->roots, mf, 2 * M, -1, &c2, &o2))) return rc;
-  hipLaunchKernelGGL(sn_mul_kernel, grid(mf, 2 * M), dim3(256), 0, s, c2, bhat, mf);
+  if ((rc = run_fft(ctx, p->fac, p->roots, mf, M, -1, &c2, &o2))) return rc;
+  hipLaunchKernelGGL(sn_mul_kernel, grid(mf, M), dim3(256), 0, s, c2, bhat, mf);
   HIP_TRY(hipGetLastError());
-  if ((rc = run_fft(ctx, p->fac, p->roots, mf, 2 * M, +1, &c2, &o2))) return rc;
-  hipLaunchKernelGGL(sn_post_kernel, grid(p->half_max, 2 * M), dim3(256), 0, s, c2, p->chirp, d_n, p->out, nm, mf, p->half_max);
+  if ((rc = run_fft(ctx, p->fac, p->roots, mf, M, +1, &c2, &o2))) return rc;
+  hipLaunchKernelGGL(sn_post_kernel, grid(p->half_max, M), dim3(256), 0, s, c2, p->chirp, d_n, p->out, nm, mf, p->half_max);
   hipLaunchKernelGGL(sn_rows_max_kernel, dim3((unsigned)(2 * M)), dim3(1024), 0, s, p->out, d_n, nm, p->half_max, d_peak_db);
   HIP_TRY(hipGetLastError());
   return IMP_OK;
