@@ -2042,7 +2042,8 @@ def test_slice_fir_design_on_the_second_stream_changes_nothing(gpu_ctx, golden, 
     """run_slice designs the equalisation FIRs on a worker thread and a context of its own while the recording uploads.
     The same slice with the early design's channel list made wrong on purpose (so that the FIRs are designed where the
     reference's stage order has them, on the default context) must agree bit for bit, stage by stage; the thread-local
-    context override ends with its block; the early design ran on the auxiliary context."""
+    context override ends with its block; the early design ran on the auxiliary context.  (The early design leaves its FIRs
+    on the device - the aux context's - and equalize_channels takes them there; the late one returns host arrays: same bits.)"""
     import slice_input
     from impulse_hip import _native, pipeline_slice
     from impulse_hip.frequency_response import FrequencyResponse
@@ -2062,7 +2063,7 @@ def test_slice_fir_design_on_the_second_stream_changes_nothing(gpu_ctx, golden, 
     seen = []
     real = pipeline_slice.process_equalization_batch
     monkeypatch.setattr(pipeline_slice, "process_equalization_batch",
-                        lambda *a: (seen.append(_native.default_context()), real(*a))[1])
+                        lambda *a, **kw: (seen.append(_native.default_context()), real(*a, **kw))[1])
     st_early, st_late = {}, {}
     h_early, gain_early = pipeline_slice.run_slice(e, [((fs, frames), ["FL", "FR"])], room_frs=room, stages=st_early)
     assert seen == [_native.aux_context()] and _native.default_context() is not _native.aux_context()
