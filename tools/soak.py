@@ -30,6 +30,12 @@ def main():
     gain[:, -1] = 0
     rows = [rng.standard_normal(30000) * np.exp(-np.arange(30000) / 4000.0) for _ in range(4)]
 
+    pk1 = _native.ConvPlan(ctx, h[0], 60000, "same", paired=True)          # K1 of the slices below (kept: a slice borrows it)
+    pcm = (rng.standard_normal((240000, 2)) * 2 ** 20).astype(np.int32)
+    pcm[5000, :] = 2 ** 29
+    pcm[125000, :] = 2 ** 29
+    hfir = rng.standard_normal((4, 9600)) * 0.01
+
     def once():
         p = _native.ConvPlan(ctx, h, 60000, "full")
         y = p.execute(x)
@@ -79,6 +85,18 @@ def main():
         ctx.apply_window_device(base, offs, base, offs, lens, [dict(fade_out=100)] * 4)
         ctx.magnitude_db_sum_peak_device(base, offs, lens, [0, 1, 0, 1], 2, 30000)
         blk.close()
+        # round 4: a resident slice (imp_slice) made, run and destroyed; FIRs left on the device; the fp64 tile transform
+        sl = _native.Slice(pk1, [0, 120000], [48, 48], 2, 32, 48, 200, 9600, 20000, 48000, max_measurements=2)
+        sl.set_firs(hfir)
+        d_rec, d_out = ctx.malloc(pcm.nbytes * 2), ctx.malloc(2 * 4 * sl.out_len_max * 4 + 1024)
+        ctx.h2d(d_rec, pcm)
+        ctx.h2d(d_rec + pcm.nbytes, pcm)
+        sl.execute_device(d_rec, pcm.size, 2, d_out, sl.out_len_max)
+        sl.results()
+        sl.close()
+        ctx.free(d_rec)
+        ctx.free(d_out)
+        ctx.fft64(np.ones((2, 19200), dtype=np.complex128))
         return float(y[0, 0])
 
     for _ in range(10):
