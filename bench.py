@@ -212,7 +212,7 @@ def synth_firs(B, K, seed=0xF1):
     return firs
 
 
-def slice_rate(est, rec, L, reps=24, workers=3):
+def slice_rate(est, rec, L, reps=24, workers=None):
     """SURVEY 8(d) secondary figure: the whole hot-path slice end to end over a job of `reps` measurements (7.1 x 2 ears each,
     one recording file per measurement: interleaved PCM frames in host memory) to float64 responses in host memory:
     ingest K1 -> crop_heads K3/K4 -> crop_tails K7c/K4 -> equalize K5 -> normalize K2, the stage sequence of every
@@ -220,7 +220,7 @@ def slice_rate(est, rec, L, reps=24, workers=3):
     i + 1 overlaps the compute of measurement i; the FIRs are designed once per job (K12 -> K6), inside the timed region."""
     from impulse_hip.frequency_response import FrequencyResponse
     from impulse_hip.parallel_workers import process_equalization_batch
-    from impulse_hip.resident_slice import Layout, SliceRunner
+    from impulse_hip.resident_slice import Layout, SlicePipeline, SliceRunner
     from impulse_hip.pipeline_slice import run_slice
     fs = est.fs
     speakers = SLICE_SPEAKERS["c2"][:rec.shape[0] // 2]
@@ -229,7 +229,8 @@ def slice_rate(est, rec, L, reps=24, workers=3):
     common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
     target = FrequencyResponse(name="target", frequency=common.copy(), raw=0)
 
-    runner = SliceRunner(est, layout, workers=workers)       # lanes (context + slice each) live across jobs
+    # the runner lives across jobs: three stages (upload | compute | download), or `workers` lanes of one measurement each
+    runner = SlicePipeline(est, layout) if workers is None else SliceRunner(est, layout, workers=workers)
 
     def job(n, to_host=True):
         firs = {(sp, sd): fir for sp, sd, fir in process_equalization_batch(layout.tasks, None, None, None, None, None, target, common, fs,
@@ -263,11 +264,14 @@ def slice_rate(est, rec, L, reps=24, workers=3):
     return dict(value=16 / dt, unit="IR/s", ms_per_measurement=dt * 1e3, measurements=reps, workers=workers,
                 ms_per_measurement_of_each_job=jobs_ms,
                 identical_to_staged_path=bool(same), staged_path_ms_per_measurement=staged_ms, lane_ms_per_measurement=lane_ms,
+                runner="pipeline" if workers is None else "lanes", pinned_result_blocks=runner.pool.allocations,
                 pcie_bytes_per_measurement=int(frames.nbytes),
                 note="end to end: PCM frames in host memory -> float64 responses in host memory, incl. PCIe "
-                     f"({frames.nbytes / 1e6:.1f} MB up per measurement) and the once-per-job FIR design; {workers} host threads, a "
-                     "stream and a one-measurement resident slice each: upload i + 1 overlaps compute i; "
-                     "staged_path_ms_per_measurement = the class path with a host readback per stage, one measurement after "
+                     f"({frames.nbytes / 1e6:.1f} MB up per measurement) and the once-per-job FIR design; "
+                     + ("three stages - upload | compute (imp_slice, one measurement per call) | download of the float64 rows into "
+                        "recycled page-locked memory - a host thread and a stream each; " if workers is None else
+                        f"{workers} host threads, a stream and a one-measurement resident slice each: upload i + 1 overlaps compute i; ")
+                     + "staged_path_ms_per_measurement = the class path with a host readback per stage, one measurement after "
                      "the other (FIRs given); not the headline metric")
 
 

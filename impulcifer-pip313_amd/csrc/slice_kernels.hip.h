@@ -231,4 +231,18 @@ struct LoadRowsDeviceLen {
   }
 };
 
+// The finished rows as float64, packed per measurement as a [rows_per_meas][out_len] host array lies (imp_slice_pack_f64).
+// grid (blocks, rows); a measurement the device flagged has out_len as crop_tails left it (possibly 0): its rows are skipped
+// by the caller.
+__global__ void __launch_bounds__(256) slice_pack_f64_kernel(const float* __restrict__ rows, long long pitch,
+                                                             const long long* __restrict__ outlen, int rows_per_meas,
+                                                             double* __restrict__ packed, long long meas_stride) {
+  const int b = blockIdx.y, m = b / rows_per_meas, r = b - m * rows_per_meas;
+  const long long n = outlen[m];
+  if (n <= 0 || (long long)rows_per_meas * n > meas_stride) return;
+  const float* __restrict__ src = rows + (long long)b * pitch;
+  double* __restrict__ dst = packed + (long long)m * meas_stride + (long long)r * n;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dst[i] = (double)src[i];
+}
+
 }  // namespace imp

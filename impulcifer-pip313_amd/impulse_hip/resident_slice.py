@@ -206,6 +206,18 @@ class ResidentSlice:
             out.append((hrir, float(meas["gain_db"][m])))
         return out
 
+    def collect_host(self, host_rows, rows, meas, recordings=None, m=0):
+        """(HRIR, gain dB) of measurement m of the last call from its float64 rows on the host ([R, out_len], the packed
+        layout imp_slice_pack_f64 leaves): the responses are views of host_rows, nothing is copied"""
+        R = self.slice.rows
+        self.stats["measurements"] += 1
+        self._warn_sides(rows[m * R:(m + 1) * R])
+        hrir = HRIR(self.estimator)
+        for q, sp in enumerate(self.layout.speakers):
+            hrir.irs[sp] = {sd: ImpulseResponse(host_rows[2 * q + s], self.fs, self._column(recordings, m, q, s))
+                            for s, sd in enumerate(("left", "right"))}
+        return hrir, float(meas["gain_db"][m])
+
     def _column(self, recordings, m, q, s):
         if recordings is None:
             return None
@@ -257,15 +269,16 @@ class ResidentSlice:
             results.extend(self.collect(block, batch, staged))
         return results
 
-    def upload(self, d_rec, recordings):
+    def upload(self, d_rec, recordings, ctx=None):
         """the files of one measurement to their places in a device block (no host-side packing: every file goes up as it
-        is)"""
+        is); ctx: the context whose stream carries the copies (default: the slice's)"""
+        ctx = ctx or self.ctx
         item = self.layout.dtype.itemsize
         for fr, (n_frames, tracks, _, _, base) in zip(recordings, self.layout.files):
             fr = np.asarray(fr)
             if fr.shape != (n_frames, tracks) or fr.dtype != self.layout.dtype:
                 raise ValueError(f"expected frames {(n_frames, tracks)} of {self.layout.dtype}, got {fr.shape} of {fr.dtype}")
-            self.ctx.h2d(d_rec + base * item, fr)
+            ctx.h2d(d_rec + base * item, fr)
 
     def close(self):
         self.slice.close()
@@ -278,7 +291,7 @@ class SliceRunner:
     for the runner's life: while one measurement's recording crosses PCIe, another's stage sequence runs and a third's
     responses come back - the upload of measurement i + 1 overlaps the compute of measurement i."""
 
-    def __init__(self, estimator, layout, workers=3, head_ms=1, peak_target=-0.1):
+    def __init__(self, estimator, layout, workers=3, head_ms=1, peak_target=-0.1, pinned_mb=None):
         import queue
         import threading
         self.estimator, self.layout = estimator, layout
@@ -286,6 +299,7 @@ class SliceRunner:
         self.lanes = []
         self._job = None
         self._lock = threading.Lock()
+        self.pool = _native.PinnedPool(pinned_mb)
         for k in range(max(1, int(workers))):
             ln = dict(todo=queue.Queue(), done=queue.Queue(), ready=threading.Event(), error=None, times={})
             ln["thread"] = threading.Thread(target=self._worker, args=(ln,), name=f"impulse-slice-{k}", daemon=True)
@@ -328,33 +342,70 @@ class SliceRunner:
                         t0 = time.perf_counter()
                         rs.upload(d_rec, recs)
                         t1 = time.perf_counter()
-                        block = rs.execute_device(d_rec, 1)
+                        host = job["to_host"]
+                        block = self._lane_execute(ln, host)
                         t2 = time.perf_counter()
                         rows, meas = rs.slice.results()
                         t3 = time.perf_counter()
                         if np.any(meas["flags"] & _native.SLICE_KEEP_CAP) and rs.grow_for(rows):
-                            block = rs.execute_device(d_rec, 1)
+                            block = self._lane_execute(ln, host)
+                            rows, meas = rs.slice.results()
 
                         def staged(m, recs=recs):
                             jobs = [((est.fs, np.asarray(fr)), spec[2], None) for fr, spec in zip(recs, layout.files)]
                             return run_slice(est, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=job["firs"])
 
-                        res = rs.collect(block, [recs], staged)[0]
-                        t4 = time.perf_counter()
-                        if job["to_host"]:
+                        if not host:
+                            res = rs.collect(block, [recs], staged)[0]
+                            t4 = t5 = time.perf_counter()
+                        elif int(meas["flags"][0]) & _native.SLICE_REDO:
+                            rs.stats["measurements"] += 1
+                            rs.stats["staged"] += 1
+                            res = staged(0)
+                            t4 = time.perf_counter()
                             res[0].to_host()
+                            t5 = time.perf_counter()
+                        else:
+                            # the packed float64 rows over the link into recycled page-locked memory: one linear copy
+                            R, n = rs.slice.rows, int(meas["out_len"][0])
+                            blk = self.pool.take(ctx, R * n)
+                            flat = np.asarray(blk)[:R * n] if blk is not None else np.empty(R * n)
+                            ctx.d2h(flat, ln["d_packed"])
+                            t4 = time.perf_counter()
+                            res = rs.collect_host(flat.reshape(R, n), rows, meas, [recs])
+                            t5 = time.perf_counter()
                         job["out"][i] = res
-                        t5 = time.perf_counter()
-                        for k, dt in (("upload", t1 - t0), ("launch", t2 - t1), ("wait", t3 - t2), ("collect", t4 - t3),
-                                      ("to_host", t5 - t4), ("measurements", 1)):
+                        for k, dt in (("upload", t1 - t0), ("launch", t2 - t1), ("wait", t3 - t2), ("to_host", t4 - t3),
+                                      ("collect", t5 - t4), ("measurements", 1)):
                             ln["times"][k] = ln["times"].get(k, 0.0) + dt
                     ln["done"].put(None)
                 except BaseException as exc:               # noqa: BLE001 - re-raised in the caller's thread
                     ln["done"].put(exc)
             ctx.free(d_rec)
+            for k in ("d_out", "d_packed"):
+                if ln.get(k):
+                    ctx.free(ln[k])
             rs.close()
             est._forget_context(ctx)
         ctx.close()
+
+    def _lane_execute(self, ln, host):
+        """one measurement through the lane's slice.  host: the rows stay in a block the lane keeps and are packed as float64
+        for the copy-out (returns None); otherwise a device block of their own is returned, as ResidentSlice.execute_device"""
+        rs, ctx = ln["rs"], ln["ctx"]
+        if not host:
+            return rs.execute_device(ln["d_rec"], 1)
+        R, cap = rs.slice.rows, rs.slice.out_len_max
+        if ln.get("cap") != cap:                           # first measurement, or the slice was re-made for longer responses
+            for k in ("d_out", "d_packed"):
+                if ln.get(k):
+                    ctx.free(ln[k])
+            ln["d_out"] = ctx.malloc(R * rs.out_pitch * 4)
+            ln["d_packed"] = ctx.malloc(R * cap * 8)
+            ln["cap"] = cap
+        rs.execute_device(ln["d_rec"], 1, ln["d_out"])
+        rs.slice.pack_f64(ln["d_out"], rs.out_pitch, 1, ln["d_packed"], R * cap)
+        return None
 
     def run(self, measurements, firs, to_host=True):
         """[(HRIR, gain dB)] in the order of `measurements` ([[frames of file 0, ...], ...]).  firs: {(speaker, side):
@@ -387,11 +438,262 @@ class SliceRunner:
         for ln in self.lanes:
             ln["thread"].join()
         self.lanes = []
+        self.pool.close()
 
 
-def run_slice_jobs(estimator, layout, measurements, firs, workers=3, head_ms=1, peak_target=-0.1):
-    """one job through a SliceRunner made for it (responses on the host); callers with several jobs keep a SliceRunner"""
-    runner = SliceRunner(estimator, layout, workers=workers, head_ms=head_ms, peak_target=peak_target)
+class SlicePipeline:
+    """Jobs of many measurements of one layout, end to end from host memory, as a three-stage pipeline.
+
+    upload | compute | download: three host threads with a stream each and rings of device buffers between them.  The
+    upload thread does nothing but push recordings across the link (one synchronous copy after the other: the link is the
+    slowest stage and never waits for a launch or a readback), the compute thread runs imp_slice one measurement per call
+    and packs the rows as float64 on the device, the download thread brings them into recycled page-locked memory
+    (_native.PinnedPool) with one linear copy per measurement and builds the HRIR objects.  Hand-overs are host queues
+    after synchronous copies / imp_slice_results, so no cross-stream event is needed.  Same surface as SliceRunner."""
+
+    def __init__(self, estimator, layout, depth=3, head_ms=1, peak_target=-0.1, pinned_mb=None, keep_cap=None):
+        import queue
+        import threading
+        self.estimator, self.layout = estimator, layout
+        self.head_ms, self.peak_target, self.keep_cap = head_ms, peak_target, keep_cap
+        self.depth = max(2, int(depth))
+        self.pool = _native.PinnedPool(pinned_mb)
+        self._q = queue
+        self.free_rec, self.uploaded, self.free_packed, self.packed = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
+        self.jobs = [queue.Queue() for _ in range(2)]       # compute, upload; the download stage takes its jobs from the items
+        self.done = queue.Queue()
+        self._times = {}
+        self._tlock = threading.Lock()
+        self.state = dict(error=None, ready=threading.Event())
+        self.ctxs = [None, None, None]
+        self.threads = [threading.Thread(target=fn, name=f"impulse-slice-{name}", daemon=True)
+                        for fn, name in ((self._compute, "compute"), (self._upload, "upload"), (self._download, "download"))]
+        self.threads[0].start()                            # makes the slice and the rings, then the others start
+        self.state["ready"].wait()
+        if self.state["error"] is not None:
+            raise self.state["error"]
+        for t in self.threads[1:]:
+            t.start()
+
+    # ---- bookkeeping
+    def _add(self, **kv):
+        with self._tlock:
+            for k, v in kv.items():
+                self._times[k] = self._times.get(k, 0.0) + v
+
+    def times(self, reset=True):
+        """seconds per stage since the last reset: {upload, upload_stall, launch, wait, compute_stall, to_host, collect,
+        download_stall, measurements}; *_stall = the stage waiting for its neighbour"""
+        with self._tlock:
+            out = dict(self._times)
+            if reset:
+                self._times = {}
+        return out
+
+    def _fail(self, job, exc):
+        if job["error"] is None:
+            job["error"] = exc
+
+    # ---- stage 1: the link, upward
+    def _upload(self):
+        ctx = self.ctxs[1] = _native.Context(_native.default_device())
+        item = self.layout.dtype.itemsize
+        with _native.using_context(ctx):
+            while True:
+                job = self.jobs[1].get()
+                if job is None:
+                    break
+                for i, recs in enumerate(job["measurements"]):
+                    t0 = time.perf_counter()
+                    k = self.free_rec.get()
+                    t1 = time.perf_counter()
+                    ok = job["error"] is None
+                    if ok:
+                        try:
+                            self.rs.upload(self.d_rec[k], recs, ctx)
+                        except BaseException as exc:       # noqa: BLE001 - re-raised by run()
+                            self._fail(job, exc)
+                            ok = False
+                    self._add(upload_stall=t1 - t0, upload=time.perf_counter() - t1)
+                    self.uploaded.put((i, k, recs, ok))
+        ctx.close()
+
+    # ---- stage 2: the stage sequence
+    def _rings(self, held=None):
+        """the fp32 row block and the float64 hand-over ring for the slice's present capacity.  held: the ring index the
+        compute stage holds when the slice was re-made for longer responses - the others are collected first (the download
+        stage hands them back as it finishes), so nothing is freed under a copy"""
+        rs, ctx = self.rs, self.ctxs[0]
+        R, cap = rs.slice.rows, rs.slice.out_len_max
+        others = [] if held is None else [self.free_packed.get() for _ in range(self.depth - 1)]
+        for ptr in [getattr(self, "d_out", 0)] + list(getattr(self, "d_packed", [])):
+            if ptr:
+                ctx.free(ptr)
+        self.d_out = ctx.malloc(R * rs.out_pitch * 4)
+        self.d_packed = [ctx.malloc(R * cap * 8) for _ in range(self.depth)]
+        ctx.synchronize()
+        self.cap = cap
+        for j in (range(self.depth) if held is None else others):
+            self.free_packed.put(j)
+
+    def _compute(self):
+        from .pipeline_slice import run_slice
+        est, layout = self.estimator, self.layout
+        try:
+            ctx = self.ctxs[0] = _native.Context(_native.default_device())
+            with _native.using_context(ctx):
+                rs = self.rs = ResidentSlice(est, layout, max_measurements=1, head_ms=self.head_ms, peak_target=self.peak_target,
+                                             keep_cap=self.keep_cap)
+                self.d_rec = [ctx.malloc(layout.samples * layout.dtype.itemsize) for _ in range(self.depth)]
+                for k in range(self.depth):
+                    self.free_rec.put(k)
+                self._rings()
+        except BaseException as exc:                       # noqa: BLE001 - reported to the constructor
+            self.state["error"] = exc
+            self.state["ready"].set()
+            return
+        self.state["ready"].set()
+        with _native.using_context(ctx):
+            while True:
+                job = self.jobs[0].get()
+                if job is None:
+                    break
+                host = job["to_host"]
+                try:
+                    rs.set_firs(job["firs"])
+                except BaseException as exc:               # noqa: BLE001
+                    self._fail(job, exc)
+                for _ in range(len(job["measurements"])):
+                    t0 = time.perf_counter()
+                    i, k, recs, ok = self.uploaded.get()
+                    t1 = time.perf_counter()
+                    j = self.free_packed.get() if host else None
+                    t2 = t3 = t4 = time.perf_counter()
+                    out = None
+                    try:
+                        if not ok or job["error"] is not None:
+                            raise _Skip()
+
+                        def once():
+                            if not host:
+                                return rs.execute_device(self.d_rec[k], 1)
+                            if self.cap != rs.slice.out_len_max:      # grown by a job that left its rows on the device
+                                self._rings(held=j)
+                            rs.execute_device(self.d_rec[k], 1, self.d_out)
+                            rs.slice.pack_f64(self.d_out, rs.out_pitch, 1, self.d_packed[j], rs.slice.rows * self.cap)
+                            return None
+
+                        block = once()
+                        t3 = time.perf_counter()
+                        rows, meas = rs.slice.results()
+                        t4 = time.perf_counter()
+                        if np.any(meas["flags"] & _native.SLICE_KEEP_CAP) and rs.grow_for(rows):
+                            if j is not None:
+                                self._rings(held=j)
+                            block = once()
+                            rows, meas = rs.slice.results()
+                        if int(meas["flags"][0]) & _native.SLICE_REDO:
+                            rs.stats["measurements"] += 1
+                            rs.stats["staged"] += 1
+                            jobs = [((est.fs, np.asarray(fr)), spec[2], None) for fr, spec in zip(recs, layout.files)]
+                            res = run_slice(est, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=job["firs"])
+                            if host:
+                                res[0].to_host()
+                            out = ("result", res)
+                        elif host:
+                            out = ("packed", j, rows, meas, recs)
+                            j = None
+                        else:
+                            out = ("result", rs.collect(block, [recs])[0])
+                    except _Skip:
+                        pass
+                    except BaseException as exc:           # noqa: BLE001
+                        self._fail(job, exc)
+                    self.free_rec.put(k)
+                    if j is not None:
+                        self.free_packed.put(j)
+                    self._add(compute_stall=(t1 - t0) + (t2 - t1), launch=t3 - t2, wait=t4 - t3, measurements=1)
+                    self.packed.put((job, i, out))
+            for ptr in self.d_rec + [getattr(self, "d_out", 0)] + list(getattr(self, "d_packed", [])):
+                if ptr:
+                    ctx.free(ptr)
+            rs.close()
+            est._forget_context(ctx)
+        ctx.close()
+
+    # ---- stage 3: the link, downward
+    def _download(self):
+        ctx = self.ctxs[2] = _native.Context(_native.default_device())
+        with _native.using_context(ctx):
+            while True:
+                t0 = time.perf_counter()
+                item = self.packed.get()
+                if item is None:
+                    break
+                job, i, out = item
+                t1 = t2 = time.perf_counter()
+                try:
+                    if out is None:
+                        pass
+                    elif out[0] == "result":
+                        job["out"][i] = out[1]
+                    else:
+                        _, j, rows, meas, recs = out
+                        try:
+                            R, n = self.rs.slice.rows, int(meas["out_len"][0])
+                            blk = self.pool.take(ctx, R * n)
+                            flat = np.asarray(blk)[:R * n] if blk is not None else np.empty(R * n)
+                            ctx.d2h(flat, self.d_packed[j])
+                        finally:
+                            self.free_packed.put(j)
+                        t2 = time.perf_counter()
+                        job["out"][i] = self.rs.collect_host(flat.reshape(R, n), rows, meas, [recs])
+                except BaseException as exc:               # noqa: BLE001
+                    self._fail(job, exc)
+                self._add(download_stall=t1 - t0, to_host=t2 - t1, collect=time.perf_counter() - t2)
+                job["left"] -= 1
+                if job["left"] == 0:
+                    self.done.put(job)
+        ctx.close()
+
+    def run(self, measurements, firs, to_host=True):
+        """[(HRIR, gain dB)] in the order of `measurements` ([[frames of file 0, ...], ...]); firs and to_host as
+        SliceRunner.run"""
+        if not len(measurements):
+            return []
+        job = dict(measurements=measurements, firs=firs, to_host=to_host, out=[None] * len(measurements), left=len(measurements),
+                   error=None)
+        for q in self.jobs:
+            q.put(job)
+        self.done.get()
+        if job["error"] is not None:
+            raise job["error"]
+        return job["out"]
+
+    def close(self):
+        if not self.threads:
+            return
+        for q in self.jobs:
+            q.put(None)
+        self.threads[0].join()
+        self.threads[1].join()
+        self.packed.put(None)
+        self.threads[2].join()
+        self.threads = []
+        self.pool.close()
+
+
+class _Skip(Exception):
+    """a measurement of a job that has already failed: passed through the stages untouched"""
+
+
+def run_slice_jobs(estimator, layout, measurements, firs, workers=None, head_ms=1, peak_target=-0.1):
+    """one job through a runner made for it (responses on the host): the three-stage SlicePipeline, or with `workers` that
+    many SliceRunner lanes; callers with several jobs keep a runner"""
+    if workers is None:
+        runner = SlicePipeline(estimator, layout, head_ms=head_ms, peak_target=peak_target)
+    else:
+        runner = SliceRunner(estimator, layout, workers=workers, head_ms=head_ms, peak_target=peak_target)
     try:
         return runner.run(measurements, firs, to_host=True)
     finally:

@@ -524,6 +524,17 @@ int imp_slice_execute_device(imp_slice* slice, const void* d_rec, int64_t rec_st
                              int64_t out_pitch);
 /* waits for the last call and copies its scalars: rows_out [M * 2 n_pairs], meas_out [M] (either may be NULL) */
 int imp_slice_results(imp_slice* slice, imp_slice_row_result* rows_out, imp_slice_result* meas_out);
+/* The rows of the last call as float64, packed: measurement m's 2 n_pairs rows at d_packed + m * meas_stride, row r at
+ * + r * out_len(m) with out_len(m) valid samples each (the layout a [2 n_pairs][out_len] float64 host array has, so that one
+ * linear copy of 2 n_pairs * out_len * 8 bytes per measurement brings the responses over as ImpulseResponse.data holds
+ * them, core/impulse_response.py:21-27).  meas_stride >= 2 n_pairs * (keep_cap + taps - 1).  The conversion float32 ->
+ * float64 is exact; asynchronous on the context's stream, after the call that wrote d_out. */
+int imp_slice_pack_f64(imp_slice* slice, const float* d_out, int64_t out_pitch, int64_t M, double* d_packed, int64_t meas_stride);
+
+/* page-locked host memory (results the link writes straight into: imp_memcpy_d2h to it needs no staging and its pages
+ * are mapped once, not per job); imp_host_free takes any pointer imp_host_alloc returned, from any thread */
+int imp_host_alloc(imp_ctx* ctx, size_t bytes, void** out);
+int imp_host_free(void* p);
 
 /* ---- the one collective: RCCL broadcast of the prepared filter spectrum -----------------------------
  * Channels shard across GPUs with no data-path collective; the only shared datum is the inverse-sweep spectrum rank 0

@@ -262,6 +262,58 @@ def test_run_slice_jobs_workers_overlap_and_order():
         assert_same_as_staged(got[m], staged_measurement(e, [(meas[m][0], spk)], firs))
 
 
+def test_slice_pipeline_order_regrowth_recycling_and_errors():
+    """The three-stage runner (upload | compute | download, a thread and a stream each).  A job of six measurements, one of
+    them with responses longer than the slice was first sized for (the slice and the float64 hand-over ring are re-made
+    in mid-job): results in job order, float64 on the host, each identical to the staged path.  A second job after the
+    first one's results were dropped pins no new memory (the blocks are recycled); a job whose third recording has the
+    wrong shape raises and leaves the runner usable; responses left on the device (to_host=False) are the same samples."""
+    import gc
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.resident_slice import Layout, SlicePipeline, _fir_taps
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=fs)
+    spk = ["FL", "FR"]
+    rt = [0.18, 0.2, 0.22, 0.75, 0.24, 0.19]
+    meas = [[synth_frames(e, spk, 700 + m, rt60=rt[m], noise_db=-100.0 if rt[m] > 0.5 else -85.0)] for m in range(6)]
+    layout = Layout(e, [(meas[0][0].shape[0], 2, spk)])
+    firs = synth_firs(layout.tasks, _fir_taps(fs), 5)
+    runner = SlicePipeline(e, layout, keep_cap=4000)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = runner.run(meas, firs)
+            want = [staged_measurement(e, [(meas[m][0], spk)], firs) for m in range(6)]
+            assert len(got) == 6
+            for m in range(6):
+                ir = got[m][0].irs["FL"]["left"]
+                assert ir._data is not None and ir.data.dtype == np.float64 and ir.data.flags["C_CONTIGUOUS"]
+                assert_same_as_staged(got[m], want[m])
+            lens = {len(got[m][0].irs["FL"]["left"].data) for m in range(6)}
+            assert len(lens) > 1 and runner.rs.stats["regrown"] >= 1, (lens, runner.rs.stats)
+            pinned = runner.pool.allocations
+            assert pinned >= 1
+            keep = got[3][0].irs["FR"]["right"].data           # a view outliving the other results keeps ITS block only
+            snapshot = keep.copy()
+            del got, ir
+            gc.collect()
+            again = runner.run(meas, firs)
+            assert runner.pool.allocations <= pinned + 1, (runner.pool.allocations, pinned)
+            assert np.array_equal(keep, snapshot)
+            for m in range(6):
+                assert_same_as_staged(again[m], want[m])
+            bad = [list(x) for x in meas]
+            bad[2] = [meas[2][0][:-1]]
+            with pytest.raises(ValueError):
+                runner.run(bad, firs)
+            on_dev = runner.run(meas[:3], firs, to_host=False)
+            for m in range(3):
+                assert on_dev[m][0].irs["FL"]["left"]._data is None
+                assert_same_as_staged(on_dev[m], want[m])
+    finally:
+        runner.close()
+
+
 def test_firs_left_on_the_device_are_the_same_firs():
     """process_equalization_batch(on_device=True) leaves the minimum-phase FIRs on the device (core/pipeline.py:690-691 hands
     every FIR straight to ImpulseResponse.equalize: they never need to visit the host): the rows are the host version's bits,
