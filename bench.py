@@ -860,6 +860,22 @@ def slice_resident_block(est, rec, L, workload, no_pmc=False, n_streams=3, M=8, 
         dt_design = time.perf_counter() - t0
         for ln in team.lanes:                              # back to the job FIRs the checks below use
             ln["rs"].set_firs(team.firs)
+        # the same with the optional stage between equalize and normalize: every row's decay pulled to a 0.3 s RT60
+        for ln in team.lanes:
+            ln["rs"].set_decay(0.3)
+        for _ in range(2):
+            team.step()
+        team.sync()
+        t0 = time.perf_counter()
+        for _ in range(calls_d):
+            team.step()
+        team.sync()
+        dt_decay = time.perf_counter() - t0
+        d_rows, d_meas = team.results(0)
+        decay_states = {int(k): int(v) for k, v in zip(*np.unique(d_rows["decay_state"], return_counts=True))}
+        decay_flags = sorted({int(f) for f in d_meas["flags"]})
+        for ln in team.lanes:
+            ln["rs"].set_decay(None)
         team.step()
         team.sync()
         flags = sorted(set(flags) | set(team.flags()))
@@ -888,6 +904,11 @@ def slice_resident_block(est, rec, L, workload, no_pmc=False, n_streams=3, M=8, 
                                                note="every call designs its 16 minimum-phase FIRs first (K12 -> K6 on the call's "
                                                     "stream, left on the device, spectra formed there): a job of M measurements "
                                                     "with equalisation curves of its own per call"),
+                 with_decay_adjustment=dict(value=calls_d * n_streams * M * rows_per / dt_decay, unit="IR/s", calls=calls_d * n_streams,
+                                            target_rt60_s=0.3, row_states_of_one_call=decay_states, flags_seen=decay_flags,
+                                            note="the optional stage of core/pipeline.py:694-716 between equalize and normalize, on "
+                                                 "every row: decay_params (K3 + K7c) and decay_times (K7b) of the equalized rows, the "
+                                                 "window (K8) in place; row states 1 = adjusted, 2 = already faster, 3 = left to the host"),
                  keep=int(meas["keep"][0]), out_len=n, flags_seen=flags, no_measurement_flagged=flags == [0],
                  bit_identical_to_staged_path=bool(same),
                  algorithmic_bytes_per_ir=alg, path_achieved=rate * alg / 1e9, path_frac=rate * alg / 1e9 / HBM_PEAK_GBS,

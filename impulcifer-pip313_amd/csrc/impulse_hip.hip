@@ -2285,7 +2285,40 @@ extern "C" int imp_decay_times(imp_ctx* ctx, const double* x, const int64_t* off
   imp::DecayJob* d_jobs = (imp::DecayJob*)(d_out + 4 * B);
   if (total) HIP_TRY(hipMemcpyAsync(d_x, x, (size_t)total * sizeof(double), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), (size_t)B * sizeof(imp::DecayJob), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(imp::decay_times_kernel, dim3((unsigned)B), dim3(256), 0, s, d_x, d_jobs, d_scr, fs, d_out);
+  hipLaunchKernelGGL(imp::decay_times_kernel<double>, dim3((unsigned)B), dim3(256), 0, s, (const double*)d_x, (const imp::DecayJob*)d_jobs, d_scr, fs, d_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)(4 * B) * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return IMP_OK;
+}
+
+extern "C" int imp_decay_times_device(imp_ctx* ctx, const float* d_x, const int64_t* off, const int64_t* len, int64_t B,
+                                      const int64_t* peak, const int64_t* knee, const double* noise_floor,
+                                      const int64_t* window, double fs, double* out) {
+  if (!ctx || (B && (!d_x || !off || !len || !peak || !knee || !noise_floor || !window || !out)))
+    return fail(IMP_ERR_INVALID, "imp_decay_times_device: null argument");
+  IMP_CTX_LOCK(ctx);
+  if (B < 0 || !(fs > 0)) return fail(IMP_ERR_INVALID, "imp_decay_times_device: bad B or fs");
+  if (B == 0) return IMP_OK;
+  std::vector<imp::DecayJob> jobs((size_t)B);
+  int64_t scr = 0;
+  for (int64_t b = 0; b < B; ++b) {
+    if (off[b] < 0 || len[b] < 0) return fail(IMP_ERR_INVALID, "negative offset/length in response %lld", (long long)b);
+    if (window[b] < 1) return fail(IMP_ERR_INVALID, "response %lld: window_size must be >= 1", (long long)b);
+    jobs[(size_t)b] = imp::DecayJob{off[b], len[b], peak[b], knee[b] - peak[b], window[b], noise_floor[b], scr};
+    scr += 2 * (len[b] + 2);
+  }
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  const size_t bytes = (size_t)(scr + 4 * B) * sizeof(double) + (size_t)B * sizeof(imp::DecayJob);
+  void* buf = nullptr;
+  if ((rc = ctx_scratch(ctx, bytes, &buf))) return rc;
+  double* d_scr = (double*)buf;
+  double* d_out = d_scr + scr;
+  imp::DecayJob* d_jobs = (imp::DecayJob*)(d_out + 4 * B);
+  HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), (size_t)B * sizeof(imp::DecayJob), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(imp::decay_times_kernel<float>, dim3((unsigned)B), dim3(256), 0, s, d_x, (const imp::DecayJob*)d_jobs, d_scr, fs, d_out);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)(4 * B) * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));

@@ -854,19 +854,26 @@ __device__ inline void block_scan(F f, long long len, double* out, double* red) 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void decay_times_kernel(const double* __restrict__ x, const DecayJob* __restrict__ jobs,
+// Sample = double (host responses, uploaded) or float (device-resident rows: converted exactly on load, so a row gives the
+// bits its float64 copy would).  A job with window < 1 (a row without a knee search behind it) is left undefined.
+template <class Sample>
+__global__ __launch_bounds__(256) void decay_times_kernel(const Sample* __restrict__ x, const DecayJob* __restrict__ jobs,
                                                           double* __restrict__ scratch, double fs,
                                                           double* __restrict__ out) {
   __shared__ double red[256];
   __shared__ long long redl[256];
   const DecayJob jb = jobs[blockIdx.x];
-  const double* ir = x + jb.off;
+  struct View {
+    const Sample* __restrict__ p;
+    __device__ __forceinline__ double operator[](long long i) const { return (double)p[i]; }
+  };
+  const View ir{x + jb.off};
   const long long n = jb.n, peak = jb.peak, K = jb.K;
   const int t = threadIdx.x;
   double* res = out + 4 * (long long)blockIdx.x;
   const double nan = __longlong_as_double(0x7ff8000000000000ll);
   if (t < 4) res[t] = nan;
-  if (K < 1 || peak < 0 || peak + K >= n + 1 || n < 2) return;          // nothing to integrate: all undefined
+  if (K < 1 || peak < 0 || peak + K >= n + 1 || n < 2 || jb.window < 1) return;          // nothing to integrate: all undefined
   double* sch = scratch + jb.scratch;            // K + 1 values
   double* smo = sch + (n + 2);                   // prefix sums, then the smoothed level
 

@@ -20,6 +20,8 @@ enum {
   SLICE_GAIN_GUARD = 16,     // 10^(gain / 20) is within the guard band of an fp32 rounding boundary
   SLICE_GAIN_NONFINITE = 32, // all-zero or NaN spectra
   SLICE_SHORT = 64,          // a row shorter than the head fade (the reference skips the fade for that pair)
+  SLICE_DECAY_GUARD = 128,   // decay adjustment: a knee search in its guard band, no decay time defined (the reference raises
+                             // TypeError), or a knee before the window's start (ValueError): the host flow decides / raises
 };
 
 struct SliceRowOut {         // per row, returned to the host at the end (imp_slice_row_result)
@@ -29,6 +31,12 @@ struct SliceRowOut {         // per row, returned to the host at the end (imp_sl
   long long knee;            // decay_params()[1] of the cropped row
   int knee_flags;            // KNEE_*
   int knee_why;              // diagnostic: KneeRow::why
+  long long decay_peak;      // decay adjustment (rows with a target): decay_params()[0:2] of the equalized row ...
+  long long decay_knee;
+  double decay_slope;        // ... the measured slope in dB/s (from the longest decay time that is defined; NaN: none) ...
+  double decay_level_db;     // ... and the window's level at the knee, as applied (fp32)
+  int decay_state;           // 0 no target, 1 adjusted, 2 already faster than the target (left alone), 3 flagged
+  int decay_flags;           // KNEE_* of that search
 };
 
 struct SliceMeasOut {        // per measurement (imp_slice_result)
@@ -230,6 +238,108 @@ struct LoadRowsDeviceLen {
     return Row{make_rsrc(base + off[b], (unsigned)(n > 0 ? n : 0) * 4u), (int)n, (int)(fade_out <= n ? fade_out : 0), win};
   }
 };
+
+// ---- adjust decay (core/pipeline.py:694-716 -> core/parallel_workers.py:24-39 -> core/decay.py:355-403) ------------------
+// on the equalized rows, for the rows that have a target RT60: decay_params (K3 + K7c, the launches of crop_tails once
+// more on the new rows), decay_times (K7b), the window's parameters here, K8 in place.
+// tables of the equalized rows: row b starts at b * out_pitch and is out_len[b / R] long; one thread per row
+__global__ __launch_bounds__(64) void slice_decay_rows_kernel(const long long* __restrict__ out_len, int rows_per_meas, int n_rows,
+                                                              long long out_pitch, int64_t* __restrict__ off3, int64_t* __restrict__ len3) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_rows) return;
+  off3[b] = (long long)b * out_pitch;
+  len3[b] = out_len[b / rows_per_meas];
+}
+
+// decay_times' jobs from the knee search's results; rows without a target get window 0 (their job returns at once)
+__global__ __launch_bounds__(64) void slice_decay_jobs_kernel(const KneeRow* __restrict__ knee, const double* __restrict__ target, int rows_per_meas,
+                                                              int n_rows, long long scratch_per_row, DecayJob* __restrict__ jobs) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_rows) return;
+  const KneeRow k = knee[b];
+  const double tg = target[b % rows_per_meas];
+  DecayJob j;
+  j.off = k.src_off;
+  j.n = k.n;
+  j.peak = k.peak;
+  j.K = k.knee - k.peak;
+  j.window = (tg == tg && k.done && !k.flags) ? k.window : 0;
+  j.noise_floor = k.floor;
+  j.scratch = (long long)b * scratch_per_row;
+  jobs[b] = j;
+}
+
+// decay_adjustment_params (core/decay.py:355-380) for every row with a target, one thread per measurement: the slope from the
+// longest defined decay time, no window when the response already decays faster than the target, else
+// (start, half, knee, level) as WindowParams of an in-place K8 launch (rows left alone get length 0 in that launch).
+__global__ __launch_bounds__(64) void slice_decay_params_kernel(const KneeRow* __restrict__ knee, const double* __restrict__ rt /*[rows][4]*/,
+                                                                const double* __restrict__ target, const int64_t* __restrict__ len3,
+                                                                int rows_per_meas, int n_meas, double fs,
+                                                                int64_t* __restrict__ d_len, WindowParams* __restrict__ par,
+                                                                SliceRowOut* __restrict__ rows, int* __restrict__ meas_flags) {
+#pragma clang fp contract(off)          // wanted * knee_s - measured * knee_s rounds as Python's three operations do
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_meas) return;
+  int flags = meas_flags[m];
+  const double spans[4] = {-10.0, -20.0, -30.0, -60.0};
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  for (int r = 0; r < rows_per_meas; ++r) {
+    const int b = m * rows_per_meas + r;
+    const double tg = target[r];
+    WindowParams p;
+    p.gain = 1.f;
+    p.fade_in = p.fade_out = 0;
+    p.decay_start = 0;
+    p.decay_half = -1;
+    p.decay_knee = 0;
+    p.decay_level_db = 0.f;
+    d_len[b] = 0;
+    SliceRowOut& o = rows[b];
+    o.decay_peak = o.decay_knee = 0;
+    o.decay_slope = nan;
+    o.decay_level_db = 0.0;
+    o.decay_state = 0;
+    o.decay_flags = 0;
+    if (tg == tg) {
+      const KneeRow k = knee[b];
+      const int kf = k.done ? k.flags : (k.flags ? k.flags : (int)KNEE_GUARD);
+      o.decay_peak = k.peak;
+      o.decay_knee = k.knee;
+      o.decay_flags = kf;
+      double measured = nan;
+      for (int q = 0; q < 4; ++q) {
+        const double t = rt[4 * b + q];
+        if (!(t == t) || t == 0.0) break;                  // `if not rt_time: break` (None or 0.0)
+        measured = spans[q] / t;
+      }
+      o.decay_slope = measured;
+      const double wanted = -60.0 / tg;
+      const long long start = k.peak + 2 * (long long)floor(fs / 1000.0);
+      const long long half = k.knee - start;
+      if (kf || !(measured == measured)) {
+        o.decay_state = 3;
+        flags |= SLICE_DECAY_GUARD;
+      } else if (wanted > measured) {
+        o.decay_state = 2;                                 // not adjusting decay and noise floor up
+      } else if (half < 0 || k.knee > len3[b]) {
+        o.decay_state = 3;                                 // the window does not tile the response: the reference raises
+        flags |= SLICE_DECAY_GUARD;
+      } else {
+        const double knee_s = (double)k.knee / fs;
+        const double level = wanted * knee_s - measured * knee_s;
+        p.decay_start = start;
+        p.decay_half = half;
+        p.decay_knee = k.knee;
+        p.decay_level_db = (float)level;
+        o.decay_level_db = (double)p.decay_level_db;
+        o.decay_state = 1;
+        d_len[b] = len3[b];
+      }
+    }
+    par[b] = p;
+  }
+  meas_flags[m] = flags;
+}
 
 // The finished rows as float64, packed per measurement as a [rows_per_meas][out_len] host array lies (imp_slice_pack_f64).
 // grid (blocks, rows); a measurement the device flagged has out_len as crop_tails left it (possibly 0): its rows are skipped

@@ -63,7 +63,8 @@ class SliceGeometry(C.Structure):
 
 class SliceRowResult(C.Structure):
     _fields_ = [("peak", C.c_int64), ("cut", C.c_int64), ("len", C.c_int64), ("knee", C.c_int64),
-                ("knee_flags", C.c_int32), ("knee_why", C.c_int32)]
+                ("knee_flags", C.c_int32), ("knee_why", C.c_int32), ("decay_peak", C.c_int64), ("decay_knee", C.c_int64),
+                ("decay_slope", C.c_double), ("decay_level_db", C.c_double), ("decay_state", C.c_int32), ("decay_flags", C.c_int32)]
 
 
 class SliceResult(C.Structure):
@@ -71,9 +72,10 @@ class SliceResult(C.Structure):
                 ("gain", C.c_float), ("flags", C.c_int32)]
 
 
-SLICE_KNEE_GUARD, SLICE_KNEE_RANGE, SLICE_KEEP_CAP, SLICE_FADE, SLICE_GAIN_GUARD, SLICE_GAIN_NONFINITE, SLICE_SHORT = (
-    1, 2, 4, 8, 16, 32, 64)
-SLICE_REDO = SLICE_KNEE_GUARD | SLICE_KNEE_RANGE | SLICE_KEEP_CAP | SLICE_FADE | SLICE_GAIN_GUARD | SLICE_GAIN_NONFINITE
+SLICE_KNEE_GUARD, SLICE_KNEE_RANGE, SLICE_KEEP_CAP, SLICE_FADE, SLICE_GAIN_GUARD, SLICE_GAIN_NONFINITE, SLICE_SHORT, SLICE_DECAY_GUARD = (
+    1, 2, 4, 8, 16, 32, 64, 128)
+SLICE_REDO = (SLICE_KNEE_GUARD | SLICE_KNEE_RANGE | SLICE_KEEP_CAP | SLICE_FADE | SLICE_GAIN_GUARD | SLICE_GAIN_NONFINITE
+              | SLICE_DECAY_GUARD)
 
 _vp = C.c_void_p
 _i64 = C.c_int64
@@ -123,6 +125,7 @@ SIGNATURES = {
     "imp_slice_set_firs": (C.c_int, [_vp, _pd, _i64]),
     "imp_slice_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64]),
     "imp_slice_results": (C.c_int, [_vp, C.POINTER(SliceRowResult), C.POINTER(SliceResult)]),
+    "imp_slice_set_decay": (C.c_int, [_vp, _pd]),
     "imp_slice_pack_f64": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64]),
     "imp_host_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "imp_host_free": (C.c_int, [_vp]),
@@ -151,6 +154,7 @@ SIGNATURES = {
     "imp_segset_range_means": (C.c_int, [_vp, _pi64, _pi64, _pi64, _i64, _pd]),
     "imp_segset_destroy": (None, [_vp]),
     "imp_decay_times": (C.c_int, [_vp, _pd, _pi64, _pi64, _i64, _pi64, _pi64, _pd, _pi64, C.c_double, _pd]),
+    "imp_decay_times_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _i64, _pi64, _pi64, _pd, _pi64, C.c_double, _pd]),
     "imp_sosfilt": (C.c_int, [_vp, _pd, _i64, _pd, _pi64, _pi64, _i64, _pd]),
     "imp_xcorr_argmax": (C.c_int, [_vp, _pd, _pi64, _pi64, _pd, _pi64, _pi64, _i64, _pi64, _pd]),
     "imp_minphase_fir": (C.c_int, [_vp, _pd, _i64, _i64, C.c_double, _pd]),
@@ -440,6 +444,22 @@ class Context:
                                          float(fs), out.ctypes.data_as(_pd)))
         return out
 
+    def decay_times_device(self, dptr, offs, lens, peaks, knees, noise_floors, windows, fs):
+        """decay_times for fp32 rows that are on the device: [B, 4] = EDT, RT20, RT30, RT60 (NaN = undefined), the bits the
+        rows' float64 copies give through decay_times()"""
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int64)
+        B = len(offs)
+        out = np.full((B, 4), np.nan)
+        if B:
+            pk = np.ascontiguousarray(peaks, dtype=np.int64)
+            kn = np.ascontiguousarray(knees, dtype=np.int64)
+            nf = np.ascontiguousarray(noise_floors, dtype=np.float64)
+            ws = np.ascontiguousarray(windows, dtype=np.int64)
+            _check(self._lib.imp_decay_times_device(self._h, _vp(int(dptr)), _ptr_i64(offs), _ptr_i64(lens), B, _ptr_i64(pk), _ptr_i64(kn),
+                                                    nf.ctypes.data_as(_pd), _ptr_i64(ws), float(fs), out.ctypes.data_as(_pd)))
+        return out
+
     def sosfilt(self, sos, rows):
         """scipy.signal.sosfilt(sos, row) for every row (fp64 on the device, bit-identical). Returns a list."""
         sos = np.ascontiguousarray(sos, dtype=np.float64).reshape(-1, 6)
@@ -698,6 +718,16 @@ class Slice:
         r = np.ctypeslib.as_array(rows)[:M * self.rows].copy() if M else np.zeros(0)
         m = np.ctypeslib.as_array(meas)[:M].copy() if M else np.zeros(0)
         return r, m
+
+    def set_decay(self, targets):
+        """target RT60 in seconds per row of a measurement (NaN: leave the row alone); None switches the stage off"""
+        if targets is None:
+            _check(self._lib.imp_slice_set_decay(self._h, None))
+            return
+        t = np.ascontiguousarray(targets, dtype=np.float64)
+        if t.shape != (self.rows,):
+            raise ValueError(f"one decay target per row of a measurement ({self.rows}), got {t.shape}")
+        _check(self._lib.imp_slice_set_decay(self._h, t.ctypes.data_as(_pd)))
 
     def pack_f64(self, d_out, out_pitch, M, d_packed, meas_stride):
         """the last call's rows as float64, every measurement packed as a [rows][out_len] array (asynchronous)"""

@@ -303,8 +303,13 @@ def decay_adjustment_params(data, fs, target):
     """(window_start, half_window, knee_point_index, window_level) or None when the measured
     decay is already faster than ``target`` seconds per 60 dB."""
     peak, knee, _, _ = decay_params(data, fs)
+    return _adjustment(peak, knee, decay_times(data, fs), fs, target)
+
+
+def _adjustment(peak, knee, times, fs, target):
+    """decay_adjustment_params from decay_params' and decay_times' results (core/decay.py:359-380)"""
     measured = None
-    for rt, span in zip(decay_times(data, fs), (-10, -20, -30, -60)):
+    for rt, span in zip(times, (-10, -20, -30, -60)):
         if not rt:
             break
         measured = span / rt                     # dB/s from the longest defined decay time
@@ -314,6 +319,47 @@ def decay_adjustment_params(data, fs, target):
     knee_s = knee / fs
     start = peak + 2 * (fs // 1000)
     return start, knee - start, knee, wanted * knee_s - measured * knee_s
+
+
+def adjust_decay_rows(rows, fs, targets, stats=None):
+    """process_decay_worker (core/parallel_workers.py:24-39) for responses that are on the device (device_rows.Row), in
+    place and without bringing a sample to the host: decay_params by the device knee search (K3 + K7c; rows with a
+    decision inside a guard band are searched again by the host flow, as in knee_indices_rows), decay_times from the
+    rows where they are (K7b), the window by K8 in place.  targets: one RT60 in seconds per row.  Raises what the
+    reference raises (TypeError when no decay time is defined, ValueError when the window does not tile the response)."""
+    from .device_rows import span
+    if not rows:
+        return
+    ctx = _native.default_context()
+    base, offs, lens = span(rows)
+    peaks, knees, floors, wins, flags = ctx.decay_knees_device(base, offs, lens, fs)
+    redo = [k for k in range(len(rows)) if flags[k]]
+    if stats is not None:
+        stats["host_rows"] = stats.get("host_rows", 0) + len(redo)
+        stats["rows"] = stats.get("rows", 0) + len(rows)
+    if redo:
+        def segset_for(idx, starts, seg_lens):
+            return _native.SegSet.from_device(ctx, base, [offs[redo[k]] + a for k, a in zip(idx, starts)], seg_lens, want_max=False)
+
+        host = _knee_searches(ctx, [int(lens[k]) for k in redo], [int(peaks[k]) for k in redo], segset_for, fs)
+        for k, (pk, kn, fl, w) in zip(redo, host):
+            peaks[k], knees[k], floors[k], wins[k] = pk, kn, fl, w
+    times = ctx.decay_times_device(base, offs, lens, peaks, knees, floors, wins, fs)
+    todo, params = [], []
+    for k, row in enumerate(rows):
+        vals = tuple(None if np.isnan(v) else float(v) for v in times[k])
+        p = _adjustment(int(peaks[k]), int(knees[k]), vals, fs, targets[k])
+        if p is None:
+            continue
+        start, half, knee, level = p
+        if start + half != knee or knee > row.n or start < 0 or half < 0:
+            raise ValueError("operands could not be broadcast together: decay window does not tile the data")
+        todo.append(k)
+        params.append(dict(gain=1.0, decay_start=start, decay_half=half, decay_knee=knee, decay_level_db=level))
+    if todo:
+        ctx.apply_window_device(base, offs[todo], base, offs[todo], lens[todo], params)
+        for k in todo:
+            rows[k].block.touch()
 
 
 def apply_decay_window(data, params):

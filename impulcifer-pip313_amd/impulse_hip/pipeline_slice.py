@@ -14,6 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 from . import _native
 from .frequency_response import FrequencyResponse
 from .hrir import HRIR
+from .decay import adjust_decay_rows
 from .parallel_workers import process_decay_worker, process_equalization_batch
 
 _designer = None
@@ -99,9 +100,14 @@ def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, deca
     snap("equalize")
 
     if decay is not None:
-        for sp, pair in hrir.irs.items():
-            for sd, ir in pair.items():
-                _, _, ir.data = process_decay_worker((sp, sd, ir.data, fs, decay[sp] if isinstance(decay, dict) else decay))
+        # core/pipeline.py:702-716: the speakers named in `decay` (a number: every speaker)
+        todo = [(sp, sd, ir, decay[sp] if isinstance(decay, dict) else decay) for sp, pair in hrir.irs.items()
+                if not isinstance(decay, dict) or sp in decay for sd, ir in pair.items()]
+        if todo and all(ir._data is None and ir._row is not None for _, _, ir, _ in todo):
+            adjust_decay_rows([ir._row for _, _, ir, _ in todo], fs, [tg for _, _, _, tg in todo])      # where the rows are
+        else:
+            for sp, sd, ir, tg in todo:
+                _, _, ir.data = process_decay_worker((sp, sd, ir.data, fs, tg))
         snap("decay")
 
     gain = hrir.normalize(peak_target=peak_target)

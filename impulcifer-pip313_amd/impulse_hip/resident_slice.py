@@ -105,6 +105,7 @@ class ResidentSlice:
         self.delays = [int(np.round(SPEAKER_DELAYS[sp] * fs)) + self.head for sp in layout.speakers]
         self.bits = {np.dtype(np.int16): 16, np.dtype(np.int32): 32, np.dtype(np.float32): 0}[layout.dtype]
         self.firs = None
+        self.decay = None
         self.slice = None
         self.stats = dict(measurements=0, staged=0, regrown=0)
         self._make(self._cap_for(int(1.1 * fs)) if keep_cap is None else int(keep_cap))
@@ -126,6 +127,21 @@ class ResidentSlice:
         self.out_pitch = (self.slice.out_len_max + 63) // 64 * 64
         if self.firs is not None:
             self.set_firs(self.firs)
+        if self.decay is not None:
+            self.set_decay(self.decay)
+
+    def set_decay(self, decay):
+        """the optional stage between equalize and normalize (core/pipeline.py:694-716): decay = None (off), a target RT60
+        in seconds for every speaker, or {speaker: seconds} for the speakers to adjust"""
+        self.decay = decay
+        if decay is None:
+            self.slice.set_decay(None)
+            return
+        if isinstance(decay, dict):
+            per_row = [float(decay[sp]) if sp in decay else np.nan for sp, _ in self.layout.tasks]
+        else:
+            per_row = [float(decay)] * len(self.layout.tasks)
+        self.slice.set_decay(per_row)
 
     def grow_for(self, rows):
         """After a call that flagged IMP_SLICE_KEEP_CAP: size the slice for the crop_tails lengths those rows ask for (the
@@ -264,7 +280,8 @@ class ResidentSlice:
 
             def staged(m, batch=batch):
                 jobs = [((self.fs, np.asarray(fr)), spec[2], None) for fr, spec in zip(batch[m], self.layout.files)]
-                return run_slice(self.estimator, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=self.firs_by_task())
+                return run_slice(self.estimator, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=self.firs_by_task(),
+                                 decay=self.decay)
 
             results.extend(self.collect(block, batch, staged))
         return results
@@ -332,6 +349,7 @@ class SliceRunner:
                     break
                 try:
                     rs.set_firs(job["firs"])
+                    rs.set_decay(job["decay"])
                     while True:
                         with self._lock:
                             i = job["next"]
@@ -353,7 +371,8 @@ class SliceRunner:
 
                         def staged(m, recs=recs):
                             jobs = [((est.fs, np.asarray(fr)), spec[2], None) for fr, spec in zip(recs, layout.files)]
-                            return run_slice(est, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=job["firs"])
+                            return run_slice(est, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=job["firs"],
+                                             decay=job["decay"])
 
                         if not host:
                             res = rs.collect(block, [recs], staged)[0]
@@ -407,12 +426,12 @@ class SliceRunner:
         rs.slice.pack_f64(ln["d_out"], rs.out_pitch, 1, ln["d_packed"], R * cap)
         return None
 
-    def run(self, measurements, firs, to_host=True):
+    def run(self, measurements, firs, to_host=True, decay=None):
         """[(HRIR, gain dB)] in the order of `measurements` ([[frames of file 0, ...], ...]).  firs: {(speaker, side):
         taps}, designed once per job (the curves belong to the job, core/pipeline.py:668-688).  to_host: True = the
         responses as float64 host arrays (as the reference's classes hold them), converted inside the workers;
-        False = left on the device."""
-        job = dict(measurements=measurements, firs=firs, to_host=to_host, next=0, out=[None] * len(measurements))
+        False = left on the device.  decay: as ResidentSlice.set_decay."""
+        job = dict(measurements=measurements, firs=firs, to_host=to_host, decay=decay, next=0, out=[None] * len(measurements))
         lanes = self.lanes[:max(1, min(len(self.lanes), len(measurements)))]
         for ln in lanes:
             ln["todo"].put(job)
@@ -561,6 +580,7 @@ class SlicePipeline:
                 host = job["to_host"]
                 try:
                     rs.set_firs(job["firs"])
+                    rs.set_decay(job["decay"])
                 except BaseException as exc:               # noqa: BLE001
                     self._fail(job, exc)
                 for _ in range(len(job["measurements"])):
@@ -596,7 +616,8 @@ class SlicePipeline:
                             rs.stats["measurements"] += 1
                             rs.stats["staged"] += 1
                             jobs = [((est.fs, np.asarray(fr)), spec[2], None) for fr, spec in zip(recs, layout.files)]
-                            res = run_slice(est, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=job["firs"])
+                            res = run_slice(est, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=job["firs"],
+                                            decay=job["decay"])
                             if host:
                                 res[0].to_host()
                             out = ("result", res)
@@ -656,12 +677,12 @@ class SlicePipeline:
                     self.done.put(job)
         ctx.close()
 
-    def run(self, measurements, firs, to_host=True):
-        """[(HRIR, gain dB)] in the order of `measurements` ([[frames of file 0, ...], ...]); firs and to_host as
+    def run(self, measurements, firs, to_host=True, decay=None):
+        """[(HRIR, gain dB)] in the order of `measurements` ([[frames of file 0, ...], ...]); firs, to_host and decay as
         SliceRunner.run"""
         if not len(measurements):
             return []
-        job = dict(measurements=measurements, firs=firs, to_host=to_host, out=[None] * len(measurements), left=len(measurements),
+        job = dict(measurements=measurements, firs=firs, to_host=to_host, decay=decay, out=[None] * len(measurements), left=len(measurements),
                    error=None)
         for q in self.jobs:
             q.put(job)
@@ -687,7 +708,7 @@ class _Skip(Exception):
     """a measurement of a job that has already failed: passed through the stages untouched"""
 
 
-def run_slice_jobs(estimator, layout, measurements, firs, workers=None, head_ms=1, peak_target=-0.1):
+def run_slice_jobs(estimator, layout, measurements, firs, workers=None, head_ms=1, peak_target=-0.1, decay=None):
     """one job through a runner made for it (responses on the host): the three-stage SlicePipeline, or with `workers` that
     many SliceRunner lanes; callers with several jobs keep a runner"""
     if workers is None:
@@ -695,7 +716,7 @@ def run_slice_jobs(estimator, layout, measurements, firs, workers=None, head_ms=
     else:
         runner = SliceRunner(estimator, layout, workers=workers, head_ms=head_ms, peak_target=peak_target)
     try:
-        return runner.run(measurements, firs, to_host=True)
+        return runner.run(measurements, firs, to_host=True, decay=decay)
     finally:
         runner.close()
 

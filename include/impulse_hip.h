@@ -259,6 +259,11 @@ void imp_segset_destroy(imp_segset* s);
 int imp_decay_times(imp_ctx* ctx, const double* x, const int64_t* off, const int64_t* len, int64_t B,
                     const int64_t* peak, const int64_t* knee, const double* noise_floor, const int64_t* window,
                     double fs, double* out);
+/* the same for fp32 rows that are on the device (response b at d_x + off[b]; converted exactly on load, so the result has
+ * the bits imp_decay_times gives for the rows' float64 copies); the tables and out are host memory */
+int imp_decay_times_device(imp_ctx* ctx, const float* d_x, const int64_t* off, const int64_t* len, int64_t B,
+                           const int64_t* peak, const int64_t* knee, const double* noise_floor, const int64_t* window,
+                           double fs, double* out);
 
 /* ---- K12: equalisation-curve conditioning ----------------------------------------------------
  * The EQ worker's front half (core/parallel_workers.py:69-131 -> autoeq/frequency_response.py) for all speaker-ear
@@ -476,6 +481,8 @@ void imp_chain_destroy(imp_chain* chain);
 #define IMP_SLICE_GAIN_GUARD 16
 #define IMP_SLICE_GAIN_NONFINITE 32
 #define IMP_SLICE_SHORT 64          /* informational: a pair shorter than the head fade kept its head un-faded */
+#define IMP_SLICE_DECAY_GUARD 128   /* decay adjustment: a knee search in its guard band, no decay time defined, or a knee
+                                     * before the window's start (the reference raises): the host flow decides */
 typedef struct imp_slice imp_slice;
 typedef struct imp_slice_geometry {
   int64_t n_pairs;               /* ear pairs per measurement */
@@ -499,6 +506,12 @@ typedef struct imp_slice_row_result {
   int64_t knee;                  /* decay_params()[1] of the cropped row */
   int32_t knee_flags;            /* flags_out of imp_decay_knees_device */
   int32_t knee_why;              /* diagnostic: which decision of the search fell into its guard band first (0: none) */
+  int64_t decay_peak;            /* rows with a decay target (imp_slice_set_decay): decay_params()[0] of the equalized row */
+  int64_t decay_knee;            /* ... and [1] */
+  double decay_slope;            /* measured slope in dB/s from the longest defined decay time (NaN: none defined) */
+  double decay_level_db;         /* the window's level at the knee as applied (core/decay.py:375) */
+  int32_t decay_state;           /* 0 no target, 1 adjusted, 2 already faster than the target, 3 left to the host flow */
+  int32_t decay_flags;           /* flags_out of imp_decay_knees_device for that search */
 } imp_slice_row_result;
 typedef struct imp_slice_result {
   int64_t keep;                  /* crop_tails' return value */
@@ -518,6 +531,16 @@ int imp_slice_info(const imp_slice* slice, int64_t* rows_per_measurement, int64_
 int imp_slice_set_firs(imp_slice* slice, const double* firs, int64_t ld);
 /* the same from FIRs on the device (imp_curves_equalization_fir_device): no upload, no wait */
 int imp_slice_set_firs_device(imp_slice* slice, const double* d_firs, int64_t ld);
+/* The optional stage between equalize and normalize (core/pipeline.py:694-716 -> core/parallel_workers.py:24-39 ->
+ * core/decay.py:355-403): target_rt60[2 n_pairs], the target 60 dB decay time in seconds of row r of every measurement, NaN
+ * for rows to leave alone (the reference's `decay` dict is per speaker); NULL or all NaN switches the stage off.  Per row
+ * with a target, on the equalized row and on the device: decay_params (K3 + K7c), decay_times (K7b), the slope of the
+ * longest defined decay time, no change if the response already decays faster than the target, else the window
+ * ones | falling Hann from peak + 2 ms to the knee | zeros, scaled to the level difference at the knee, applied in place
+ * (K8).  Where the reference raises (no decay time defined: TypeError; knee before the window's start: ValueError) or the
+ * knee search has a decision inside its guard band, the measurement is flagged IMP_SLICE_DECAY_GUARD.  Bit-identical to
+ * imp_decay_knees_device -> imp_decay_times_device -> imp_apply_window_device on the same rows.  Drains the stream. */
+int imp_slice_set_decay(imp_slice* slice, const double* target_rt60);
 /* asynchronous on the context's stream; d_out: [M * 2 n_pairs][out_pitch] fp32, out_pitch >= keep_cap + taps - 1; row
  * m * 2 n_pairs + r holds result.out_len valid samples */
 int imp_slice_execute_device(imp_slice* slice, const void* d_rec, int64_t rec_stride, int64_t M, float* d_out,

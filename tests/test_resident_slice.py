@@ -55,16 +55,17 @@ def synth_firs(tasks, taps, seed):
     return {t: firs[i] for i, t in enumerate(tasks)}
 
 
-def staged_measurement(e, files, firs):
+def staged_measurement(e, files, firs, decay=None):
     """the staged class path of one measurement (one host readback per stage)"""
     from impulse_hip.pipeline_slice import run_slice
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return run_slice(e, [((e.fs, fr), sp) for fr, sp in files], firs=firs)
+        return run_slice(e, [((e.fs, fr), sp) for fr, sp in files], firs=firs, decay=decay)
 
 
-def oracle_measurement(oe, files, firs, fs):
-    """the oracle composition: estimate -> crop_heads -> crop_tails -> FIR 'full' -> normalize (fp64)"""
+def oracle_measurement(oe, files, firs, fs, decay=None):
+    """the oracle composition: estimate -> crop_heads -> crop_tails -> FIR 'full' -> [adjust decay] -> normalize (fp64)"""
+    from oracle import decay as odecay
     from oracle import hrir as ohrir
     from oracle.scipy_restated import fft_convolve
     N = len(oe)
@@ -78,6 +79,13 @@ def oracle_measurement(oe, files, firs, fs):
     for sp in irs:
         for sd in irs[sp]:
             irs[sp][sd] = fft_convolve(irs[sp][sd], firs[(sp, sd)], "full")
+    if decay is not None:
+        for sp in irs:
+            if sp in decay:
+                for sd in irs[sp]:
+                    x = np.array(irs[sp][sd], dtype=np.float64)
+                    odecay.apply_decay_window(x, odecay.decay_adjustment_params(x, fs, decay[sp]))
+                    irs[sp][sd] = x
     g = ohrir.normalization_gain_db(irs, fs, peak_target=-0.1)
     return tail_ind, g, {sp: {sd: irs[sp][sd] * 10 ** (g / 20) for sd in irs[sp]} for sp in irs}
 
@@ -239,6 +247,98 @@ def test_resident_slice_full_size(config):
         for sd in o_irs[sp]:
             assert rel(got[0][0].irs[sp][sd].peek(), o_irs[sp][sd]) <= 2 * TIME_TOL, (sp, sd)
     rs.close()
+
+
+def test_resident_slice_decay_stage():
+    """The optional stage between equalize and normalize (core/pipeline.py:694-716): per-speaker target RT60s.  The
+    resident sequence runs decay_params + decay_times + the window on the equalized rows on the device; the staged path
+    does the same through adjust_decay_rows (the rows never visit the host); the reference's worker on host arrays
+    (process_decay_worker) is the third form.  FL gets a target faster than its decay (the synthetic rooms' RT60 reads
+    1.0 - 1.6 s: adjusted), FR one slower (left alone), FC none (not in the dict).  Resident = staged bit for bit; both agree with the oracle composition to the
+    fp32 tolerance of the path and with the host-array form of the stage."""
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.resident_slice import Layout, ResidentSlice, _fir_taps
+    from impulse_hip.pipeline_slice import run_slice
+    from oracle import estimator as oest
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=fs)
+    oe = oest.Estimator(min_duration=1.0, fs=fs)
+    spk = ["FL", "FR", "FC"]
+    decay = {"FL": 0.5, "FR": 5.0}
+    meas = [[synth_frames(e, spk, 900 + m, rt60=0.22 + 0.03 * m)] for m in range(3)]
+    layout = Layout(e, [(meas[0][0].shape[0], 2, spk)])
+    firs = synth_firs(layout.tasks, _fir_taps(fs), 9)
+    rs = ResidentSlice(e, layout, max_measurements=3)
+    rs.set_firs(firs)
+    rs.set_decay(decay)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = rs.run(meas)
+    rows, res = rs.slice.results()
+    assert rs.stats["staged"] == 0, (res["flags"], rows["decay_flags"])
+    R = rs.slice.rows
+    for m in range(3):
+        st = rows["decay_state"][m * R:(m + 1) * R]
+        assert list(st) == [1, 1, 2, 2, 0, 0], st
+        assert np.all(rows["decay_level_db"][m * R:m * R + 2] < -1.0)            # a real adjustment, not a no-op
+        want = staged_measurement(e, [(meas[m][0], spk)], firs, decay=decay)
+        assert_same_as_staged(got[m], want)
+        # without the stage the adjusted speaker differs, the others change only through the common gain
+        plain = staged_measurement(e, [(meas[m][0], spk)], firs)
+        tail_a, tail_b = got[m][0].irs["FL"]["left"].peek()[-2000:], plain[0].irs["FL"]["left"].peek()[-2000:]
+        assert np.max(np.abs(tail_a)) < 1e-3 * np.max(np.abs(tail_b))           # the late tail is pulled down, by a lot
+        tail_ind, g, o_irs = oracle_measurement(oe, [(meas[m][0], spk)], firs, fs, decay=decay)
+        assert int(res["keep"][m]) == tail_ind
+        assert got[m][1] == pytest.approx(g, abs=1e-5)
+        for sp in o_irs:
+            for sd in o_irs[sp]:
+                assert rel(got[m][0].irs[sp][sd].peek(), o_irs[sp][sd]) <= 2 * TIME_TOL, (sp, sd)
+    # the host-array form of the stage (the reference's worker as the classes run it when a response is on the host)
+    hrir, _ = run_slice(e, [((fs, meas[0][0]), spk)], firs=firs, decay=None, peak_target=-0.1)
+    from impulse_hip.parallel_workers import process_decay_worker
+    from impulse_hip.decay import adjust_decay_rows
+    ir = hrir.irs["FL"]["left"]
+    gain_free = ir.peek()
+    _, _, host_form = process_decay_worker(("FL", "left", gain_free.copy(), fs, 0.5))
+    adjust_decay_rows([ir._row], fs, [0.5])
+    assert np.array_equal(ir.peek(), host_form)
+    # a target, then none: the stage is off again and the results are those of the plain sequence
+    rs.set_decay(None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        again = rs.run(meas[:1])
+    assert_same_as_staged(again[0], staged_measurement(e, [(meas[0][0], spk)], firs))
+    assert np.all(rs.slice.results()[0]["decay_state"] == 0)
+    rs.close()
+
+
+def test_decay_times_of_device_rows_have_the_bits_of_their_float64_copies():
+    from impulse_hip import _native
+    from impulse_hip.decay import decay_params, decay_times
+    ctx = _native.default_context()
+    fs = 48000
+    rng = np.random.default_rng(77)
+    rows = []
+    for k in range(4):
+        n = 30000 + 5000 * k
+        t = np.arange(n) / fs
+        x = rng.standard_normal(n) * 10 ** (-3.0 * t / (0.15 + 0.05 * k)) + rng.standard_normal(n) * 1e-4
+        x[:200] = 0
+        x[200] = 2.0
+        rows.append(x.astype(np.float32))
+    lens = np.array([len(r) for r in rows], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    flat = np.concatenate(rows)
+    d = ctx.malloc(flat.nbytes)
+    ctx.h2d(d, flat)
+    par = [decay_params(r.astype(np.float64), fs) for r in rows]
+    got = ctx.decay_times_device(d, offs, lens, [p[0] for p in par], [p[1] for p in par], [p[2] for p in par], [p[3] for p in par], fs)
+    ctx.free(d)
+    for k, r in enumerate(rows):
+        want = decay_times(r.astype(np.float64), fs, *par[k])
+        assert any(w is not None for w in want)
+        for a, b in zip(got[k], want):
+            assert (np.isnan(a) and b is None) or a == b, (k, got[k], want)
 
 
 def test_run_slice_jobs_workers_overlap_and_order():
