@@ -2285,7 +2285,7 @@ extern "C" int imp_decay_times(imp_ctx* ctx, const double* x, const int64_t* off
   imp::DecayJob* d_jobs = (imp::DecayJob*)(d_out + 4 * B);
   if (total) HIP_TRY(hipMemcpyAsync(d_x, x, (size_t)total * sizeof(double), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), (size_t)B * sizeof(imp::DecayJob), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(imp::decay_times_kernel<double>, dim3((unsigned)B), dim3(256), 0, s, (const double*)d_x, (const imp::DecayJob*)d_jobs, d_scr, fs, d_out);
+  hipLaunchKernelGGL(imp::decay_times_kernel<double>, dim3((unsigned)B), dim3(imp::kDecayThreads), 0, s, (const double*)d_x, (const imp::DecayJob*)d_jobs, d_scr, fs, d_out);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)(4 * B) * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -2318,7 +2318,7 @@ extern "C" int imp_decay_times_device(imp_ctx* ctx, const float* d_x, const int6
   double* d_out = d_scr + scr;
   imp::DecayJob* d_jobs = (imp::DecayJob*)(d_out + 4 * B);
   HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), (size_t)B * sizeof(imp::DecayJob), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(imp::decay_times_kernel<float>, dim3((unsigned)B), dim3(256), 0, s, d_x, (const imp::DecayJob*)d_jobs, d_scr, fs, d_out);
+  hipLaunchKernelGGL(imp::decay_times_kernel<float>, dim3((unsigned)B), dim3(imp::kDecayThreads), 0, s, d_x, (const imp::DecayJob*)d_jobs, d_scr, fs, d_out);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)(4 * B) * sizeof(double), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));

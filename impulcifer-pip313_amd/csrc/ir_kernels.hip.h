@@ -793,12 +793,14 @@ struct DecayJob {
   long long scratch;   // offset of this job's 2 (n + 2) doubles in the scratch buffer
 };
 
+constexpr int kDecayThreads = 1024;     // one workgroup per response: its threads share the scans and the line fits
+
 __device__ inline double block_sum(double v, double* red) {
   const int t = threadIdx.x;
   __syncthreads();
   red[t] = v;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = kDecayThreads / 2; s > 0; s >>= 1) {
     if (t < s) red[t] += red[t + s];
     __syncthreads();
   }
@@ -809,7 +811,7 @@ __device__ inline double block_max(double v, double* red) {
   __syncthreads();
   red[t] = v;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = kDecayThreads / 2; s > 0; s >>= 1) {
     if (t < s) red[t] = fmax(red[t], red[t + s]);
     __syncthreads();
   }
@@ -820,26 +822,30 @@ __device__ inline long long block_min_ll(long long v, long long* red) {
   __syncthreads();
   red[t] = v;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = kDecayThreads / 2; s > 0; s >>= 1) {
     if (t < s && red[t + s] < red[t]) red[t] = red[t + s];
     __syncthreads();
   }
   return red[0];
 }
-// inclusive scan of f(0..len) into out[0..len): per-thread contiguous chunks + scan of the 256 chunk totals
+// inclusive scan of f(0..len) into out[0..len): per-thread contiguous chunks + scan of the chunk totals
 template <class F>
 __device__ inline void block_scan(F f, long long len, double* out, double* red) {
   const int t = threadIdx.x;
-  const long long chunk = (len + 255) / 256;
+  const long long chunk = (len + kDecayThreads - 1) / kDecayThreads;
   const long long lo = (long long)t * chunk, hi = (lo + chunk < len) ? lo + chunk : len;
   double acc = 0.0;
-  for (long long i = lo; i < hi; ++i) acc += f(i);
+  for (long long i = lo; i < hi; ++i) {          // f once per element: the terms wait in out[] for the second sweep
+    const double v = f(i);
+    out[i] = v;
+    acc += v;
+  }
   __syncthreads();
   red[t] = acc;
   __syncthreads();
   if (t == 0) {
     double run = 0.0;
-    for (int k = 0; k < 256; ++k) {
+    for (int k = 0; k < kDecayThreads; ++k) {
       const double v = red[k];
       red[k] = run;
       run += v;
@@ -848,7 +854,7 @@ __device__ inline void block_scan(F f, long long len, double* out, double* red) 
   __syncthreads();
   acc = red[t];
   for (long long i = lo; i < hi; ++i) {
-    acc += f(i);
+    acc += out[i];
     out[i] = acc;
   }
   __syncthreads();
@@ -857,11 +863,11 @@ __device__ inline void block_scan(F f, long long len, double* out, double* red) 
 // Sample = double (host responses, uploaded) or float (device-resident rows: converted exactly on load, so a row gives the
 // bits its float64 copy would).  A job with window < 1 (a row without a knee search behind it) is left undefined.
 template <class Sample>
-__global__ __launch_bounds__(256) void decay_times_kernel(const Sample* __restrict__ x, const DecayJob* __restrict__ jobs,
+__global__ __launch_bounds__(kDecayThreads) void decay_times_kernel(const Sample* __restrict__ x, const DecayJob* __restrict__ jobs,
                                                           double* __restrict__ scratch, double fs,
                                                           double* __restrict__ out) {
-  __shared__ double red[256];
-  __shared__ long long redl[256];
+  __shared__ double red[kDecayThreads];
+  __shared__ long long redl[kDecayThreads];
   const DecayJob jb = jobs[blockIdx.x];
   struct View {
     const Sample* __restrict__ p;
@@ -879,21 +885,21 @@ __global__ __launch_bounds__(256) void decay_times_kernel(const Sample* __restri
 
   // ---- Schroeder backward integral
   double m = 0.0;
-  for (long long i = peak + t; i < n; i += 256) m = fmax(m, fabs(ir[i]));
+  for (long long i = peak + t; i < n; i += kDecayThreads) m = fmax(m, fabs(ir[i]));
   const double m1 = block_max(m, red);
   auto e = [&](long long i) {                    // i relative to the peak
     const double v = fabs(ir[peak + i] / m1);
     return v * v;
   };
   double part_sum = 0.0;
-  for (long long i = t; i < K; i += 256) part_sum += e(i);
+  for (long long i = t; i < K; i += kDecayThreads) part_sum += e(i);
   const double S = block_sum(part_sum, red);
   const long long last = (peak + K < n) ? K : K - 1;                     // analytical[K] exists unless the knee is the end
   // tmp[j] = sum_{m = last - j .. last} e[m] / S  (reversed order), stored so that sch[i] = tmp over m >= i
   block_scan([&](long long j) { return e(last - j) / S; }, last + 1, smo, red);
   // cumsum(...)[:0:-1] drops the first partial sum: len(schroeder) = last
   const long long Ks = last;
-  for (long long i = t; i < Ks; i += 256) sch[i] = 10.0 * log10(smo[last - i]);
+  for (long long i = t; i < Ks; i += kDecayThreads) sch[i] = 10.0 * log10(smo[last - i]);
   __syncthreads();
 
   // ---- moving average of the squared response around the same stretch
@@ -905,7 +911,7 @@ __global__ __launch_bounds__(256) void decay_times_kernel(const Sample* __restri
   const long long skew = half - lead;
   const long long p0 = peak - lead, P = lead + K + trail, N = jb.window;
   m = 0.0;
-  for (long long i = t; i < P; i += 256) m = fmax(m, fabs(ir[p0 + i]));
+  for (long long i = t; i < P; i += kDecayThreads) m = fmax(m, fabs(ir[p0 + i]));
   const double m2 = block_max(m, red);
   const long long Ls = (N >= 1 && P >= N) ? P - N + 1 : 0;               // len(running_mean)
   double offset = nan;
@@ -916,7 +922,7 @@ __global__ __launch_bounds__(256) void decay_times_kernel(const Sample* __restri
     // c[i + 1] = c[i] + p2[i]; smo[] holds c[1..P]
     block_scan([&](long long i) { const double v = ir[p0 + i] / m2; return v * v; }, P, smo, red);
     double acc = 0.0;
-    for (long long i = a + t; i < b; i += 256) {
+    for (long long i = a + t; i < b; i += kDecayThreads) {
       const long long r = i - skew;                                      // index into the running mean
       const double hi = smo[r + N - 1], lo = r > 0 ? smo[r - 1] : 0.0;
       acc += sch[i] - 10.0 * log10((hi - lo) / (double)N + 1e-18);
@@ -931,7 +937,7 @@ __global__ __launch_bounds__(256) void decay_times_kernel(const Sample* __restri
   for (int k = 0; k < 4; ++k) {
     if (bots[k] < jb.noise_floor + offset + 10.0) continue;              // < 10 dB above the floor (a NaN offset passes, as in the reference)
     long long it = 0x7fffffffffffffffll, ib = 0x7fffffffffffffffll;
-    for (long long i = t; i < Ks; i += 256) {
+    for (long long i = t; i < Ks; i += kDecayThreads) {
       if (sch[i] <= tops[k] && i < it) it = i;
       if (sch[i] <= bots[k] && i < ib) ib = i;
     }
@@ -940,14 +946,14 @@ __global__ __launch_bounds__(256) void decay_times_kernel(const Sample* __restri
     if (it == 0x7fffffffffffffffll || ib == 0x7fffffffffffffffll || ib - it < 2) continue;
     const double cnt = (double)(ib - it);
     double sx = 0.0, sy = 0.0;
-    for (long long i = it + t; i < ib; i += 256) {
+    for (long long i = it + t; i < ib; i += kDecayThreads) {
       sx += tt(i);
       sy += sch[i];
     }
     const double xm = block_sum(sx, red) / cnt;
     const double ym = block_sum(sy, red) / cnt;
     double sxy = 0.0, sxx = 0.0;
-    for (long long i = it + t; i < ib; i += 256) {
+    for (long long i = it + t; i < ib; i += kDecayThreads) {
       const double dx = tt(i) - xm;
       sxy += dx * (sch[i] - ym);
       sxx += dx * dx;

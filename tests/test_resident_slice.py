@@ -246,6 +246,15 @@ def test_resident_slice_full_size(config):
     for sp in o_irs:
         for sd in o_irs[sp]:
             assert rel(got[0][0].irs[sp][sd].peek(), o_irs[sp][sd]) <= 2 * TIME_TOL, (sp, sd)
+    # the same layout with the decay stage on every row: still the staged path's bits
+    rs.set_decay(0.3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = rs.run(meas[:2])
+    rows, res = rs.slice.results()
+    assert set(rows["decay_state"]) <= {1, 2, 3} and np.count_nonzero(rows["decay_state"] == 1) >= 4      # adjusted / already faster
+    for m in range(2):
+        assert_same_as_staged(got[m], staged_measurement(e, [(meas[m][0], spk)], firs, decay=0.3))
     rs.close()
 
 
@@ -254,8 +263,8 @@ def test_resident_slice_decay_stage():
     resident sequence runs decay_params + decay_times + the window on the equalized rows on the device; the staged path
     does the same through adjust_decay_rows (the rows never visit the host); the reference's worker on host arrays
     (process_decay_worker) is the third form.  FL gets a target faster than its decay (the synthetic rooms' RT60 reads
-    1.0 - 1.6 s: adjusted), FR one slower (left alone), FC none (not in the dict).  Resident = staged bit for bit; both agree with the oracle composition to the
-    fp32 tolerance of the path and with the host-array form of the stage."""
+    1.0 - 1.6 s: adjusted), FR one slower (left alone), FC none (not in the dict).  Resident = staged bit for bit; both
+    agree with the oracle composition to the fp32 tolerance of the path and with the host-array form of the stage."""
     from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
     from impulse_hip.resident_slice import Layout, ResidentSlice, _fir_taps
     from impulse_hip.pipeline_slice import run_slice

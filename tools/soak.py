@@ -93,9 +93,21 @@ def main():
         ctx.h2d(d_rec + pcm.nbytes, pcm)
         sl.execute_device(d_rec, pcm.size, 2, d_out, sl.out_len_max)
         sl.results()
+        # the decay stage's tables, the float64 pack and a page-locked result block: made, used and released per iteration
+        sl.set_decay([0.3, np.nan, 0.3, 0.3])
+        sl.execute_device(d_rec, pcm.size, 2, d_out, sl.out_len_max)
+        d_packed = ctx.malloc(2 * 4 * sl.out_len_max * 8)
+        sl.pack_f64(d_out, sl.out_len_max, 2, d_packed, 4 * sl.out_len_max)
+        _, meas = sl.results()
+        pool = _native.PinnedPool(64)
+        blk = pool.take(ctx, 4 * sl.out_len_max)
+        ctx.d2h(np.asarray(blk)[:4 * max(int(meas["out_len"][0]), 1)], d_packed)
+        del blk
+        pool.close()
         sl.close()
         ctx.free(d_rec)
         ctx.free(d_out)
+        ctx.free(d_packed)
         ctx.fft64(np.ones((2, 19200), dtype=np.complex128))
         return float(y[0, 0])
 
