@@ -20,7 +20,8 @@ def main(out, tag="r04"):
     prof = os.path.join(ROOT, "profiles")
     for name, dst in (("slice_rate_serial.txt", f"{tag}_slice_rate_serial.txt"), ("slice_rate.txt", f"{tag}_slice_rate.txt"),
                       ("eq_fir.txt", f"{tag}_eq_fir.txt"), ("slice_stages.txt", f"{tag}_slice_stages.txt"),
-                      ("column_error.txt", f"{tag}_column_error.txt")):
+                      ("column_error.txt", f"{tag}_column_error.txt"), ("slice_rate_decay_serial.txt", f"{tag}_slice_rate_decay_serial.txt"),
+                      ("slice_e2e.txt", f"{tag}_slice_e2e.txt"), ("link_probe.txt", f"{tag}_link_probe.txt")):
         src = os.path.join(out, name)
         if os.path.exists(src) and os.path.getsize(src):
             with open(src) as fh:
@@ -28,7 +29,7 @@ def main(out, tag="r04"):
             open(os.path.join(prof, dst), "w").write(text)
     for sub, name in (("trace", f"{tag}_kernel_stats.csv"), ("trace_serial", f"{tag}_kernel_stats_serial.csv"),
                       ("trace_slice_serial", f"{tag}_slice_kernel_stats_serial.csv"), ("trace_slice", f"{tag}_slice_kernel_stats.csv"),
-                      ("trace_eq", f"{tag}_eq_fir_kernel_stats.csv")):
+                      ("trace_slice_decay", f"{tag}_slice_decay_kernel_stats_serial.csv"), ("trace_eq", f"{tag}_eq_fir_kernel_stats.csv")):
         for root, _, files in os.walk(os.path.join(out, sub)):
             for f in files:
                 if f.endswith("kernel_stats.csv"):

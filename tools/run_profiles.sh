@@ -18,6 +18,7 @@ echo "serial trace done"
 # the resident slice: one stream (serial kernels) and three
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_slice_serial -o s -- python3 $R/tools/slice_resident_rate.py c2 1 8 20 3 > $OUT/slice_rate_serial.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_slice -o s -- python3 $R/tools/slice_resident_rate.py c2 3 8 40 3 > $OUT/slice_rate.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_slice_decay -o s -- python3 $R/tools/slice_resident_rate.py c2 1 8 20 3 0.3 > $OUT/slice_rate_decay_serial.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_eq -o s -- python3 $R/tools/eq_fir_profile.py 48000 20 flat > $OUT/eq_fir.txt 2>&1
 echo "slice traces done"
 for W in c2 c3 c5; do
@@ -33,6 +34,9 @@ python3 bench.py --workload c3 > $OUT/bench_c3.json 2> $OUT/bench_c3.err
 echo "c3 done"
 python3 bench.py --workload c5 --steps 8 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
 echo "c5 done"
+python3 tools/slice_e2e_rate.py 0 48 > $OUT/slice_e2e.txt 2>&1
+python3 tools/slice_e2e_rate.py 3 48 >> $OUT/slice_e2e.txt 2>&1
+python3 tools/probes/link_probe.py > $OUT/link_probe.txt 2>&1
 python3 tools/slice_stages.py 20 > $OUT/slice_stages.txt 2>&1
 python3 tools/knee_stats.py 512 >> $OUT/slice_stages.txt 2>&1
 for W in c2 c3 c5; do python3 tools/column_error.py $W pair; python3 tools/column_error.py $W; done > $OUT/column_error.txt 2>&1
