@@ -252,6 +252,20 @@ def slice_rate(est, rec, L, reps=24, workers=None):
                 dt, res, firs = d_, r_, f_
                 lane_ms = {k: v / reps * 1e3 for k, v in runner.times().items() if k != "measurements"}
             del r_
+        # the same job with the recordings in page-locked buffers the runner handed out (a reader that fills frame_buffers()
+        # instead of its own array): no staging copy before the link
+        pinned_ms = None
+        if workers is None:
+            bufs = [runner.frame_buffers() for _ in range(4)]
+            for b in bufs:
+                b[0][...] = frames
+            for _ in range(2):
+                t0 = time.perf_counter()
+                r_ = runner.run([bufs[i % 4] for i in range(reps)], firs)
+                d_ = (time.perf_counter() - t0) / reps * 1e3
+                pinned_ms = d_ if pinned_ms is None else min(pinned_ms, d_)
+                del r_
+            del bufs
         # the same measurement through the staged class path (one host readback per stage): identical samples
         hrir, gain = run_slice(est, [((fs, frames), speakers)], firs=firs)
         same = all(np.array_equal(res[k][0].irs[sp][sd].data, hrir.irs[sp][sd].data) for k in (0, reps - 1) for sp in speakers
@@ -265,6 +279,10 @@ def slice_rate(est, rec, L, reps=24, workers=None):
                 ms_per_measurement_of_each_job=jobs_ms,
                 identical_to_staged_path=bool(same), staged_path_ms_per_measurement=staged_ms, lane_ms_per_measurement=lane_ms,
                 runner="pipeline" if workers is None else "lanes", pinned_result_blocks=runner.pool.allocations,
+                recordings_in_page_locked_buffers=None if pinned_ms is None else dict(
+                    value=16 / pinned_ms * 1e3, unit="IR/s", ms_per_measurement=pinned_ms,
+                    note="the same job with every recording in a buffer from SlicePipeline.frame_buffers() (what a WAV reader "
+                         "would fill): the upload needs no staging copy; FIRs reused from the job above"),
                 pcie_bytes_per_measurement=int(frames.nbytes),
                 note="end to end: PCM frames in host memory -> float64 responses in host memory, incl. PCIe "
                      f"({frames.nbytes / 1e6:.1f} MB up per measurement) and the once-per-job FIR design; "

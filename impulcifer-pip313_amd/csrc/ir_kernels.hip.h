@@ -828,34 +828,33 @@ __device__ inline long long block_min_ll(long long v, long long* red) {
   }
   return red[0];
 }
-// inclusive scan of f(0..len) into out[0..len): per-thread contiguous chunks + scan of the chunk totals
+// inclusive scan of f(0..len) into out[0..len): tiles of kDecayThreads consecutive elements (coalesced loads and stores,
+// f once per element), a shuffle scan inside every wave, the waves' totals and the running carry through LDS
 template <class F>
 __device__ inline void block_scan(F f, long long len, double* out, double* red) {
-  const int t = threadIdx.x;
-  const long long chunk = (len + kDecayThreads - 1) / kDecayThreads;
-  const long long lo = (long long)t * chunk, hi = (lo + chunk < len) ? lo + chunk : len;
-  double acc = 0.0;
-  for (long long i = lo; i < hi; ++i) {          // f once per element: the terms wait in out[] for the second sweep
-    const double v = f(i);
-    out[i] = v;
-    acc += v;
-  }
-  __syncthreads();
-  red[t] = acc;
-  __syncthreads();
-  if (t == 0) {
-    double run = 0.0;
-    for (int k = 0; k < kDecayThreads; ++k) {
-      const double v = red[k];
-      red[k] = run;
-      run += v;
+  constexpr int kWaves = kDecayThreads / 64;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  double carry = 0.0;
+  for (long long base = 0; base < len; base += kDecayThreads) {
+    const long long i = base + t;
+    double v = i < len ? f(i) : 0.0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double u = __shfl_up(v, d, 64);
+      if (lane >= d) v += u;
     }
-  }
-  __syncthreads();
-  acc = red[t];
-  for (long long i = lo; i < hi; ++i) {
-    acc += out[i];
-    out[i] = acc;
+    __syncthreads();
+    if (lane == 63) red[w] = v;
+    __syncthreads();
+    double before = carry, total = 0.0;
+#pragma unroll
+    for (int k = 0; k < kWaves; ++k) {
+      const double r = red[k];
+      if (k < w) before += r;
+      total += r;
+    }
+    if (i < len) out[i] = v + before;
+    carry += total;
   }
   __syncthreads();
 }

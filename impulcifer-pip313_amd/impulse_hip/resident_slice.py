@@ -494,6 +494,20 @@ class SlicePipeline:
         for t in self.threads[1:]:
             t.start()
 
+    def frame_buffers(self):
+        """One measurement's recording buffers in page-locked memory: [frames[n_frames, tracks] of the layout's sample
+        type, one per file], for a reader to fill (a WAV data chunk read straight into them): their upload needs no
+        staging copy on the way to the link.  They go back to the runner's pool when the caller drops them."""
+        out = []
+        for n_frames, tracks, _, _, _ in self.layout.files:
+            nbytes = n_frames * tracks * self.layout.dtype.itemsize
+            blk = self.pool.take(self.ctxs[0], -(-nbytes // 8))
+            if blk is None:
+                out.append(np.empty((n_frames, tracks), dtype=self.layout.dtype))
+            else:
+                out.append(np.asarray(blk).view(self.layout.dtype)[:n_frames * tracks].reshape(n_frames, tracks))
+        return out
+
     # ---- bookkeeping
     def _add(self, **kv):
         with self._tlock:
