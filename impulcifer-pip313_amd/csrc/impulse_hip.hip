@@ -2406,8 +2406,8 @@ extern "C" int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_
   HIP_TRY(hipMemcpyAsync(d_meta + B, a_len, meta, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_meta + 2 * B, b_off, meta, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_meta + 3 * B, b_len, meta, hipMemcpyHostToDevice, s));
-  if ((rc = ctx_kernel_lds(ctx, reinterpret_cast<const void*>(imp::xcorr_argmax_kernel), 16384 * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(imp::xcorr_argmax_kernel, dim3((unsigned)B), dim3(256), (size_t)lds * sizeof(double), s, d_a, d_meta,
+  if ((rc = ctx_kernel_lds(ctx, reinterpret_cast<const void*>(imp::xcorr_argmax_kernel<double>), 16384 * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(imp::xcorr_argmax_kernel<double>, dim3((unsigned)B), dim3(256), (size_t)lds * sizeof(double), s, (const double*)d_a, (const int64_t*)d_meta,
                      d_meta + B, d_b, d_meta + 2 * B, d_meta + 3 * B, d_arg, d_val);
   HIP_TRY(hipGetLastError());
   std::vector<long long> h_arg((size_t)B);
@@ -2419,6 +2419,82 @@ extern "C" int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_
     arg_out[p] = (int64_t)h_arg[(size_t)p];
     if (val_out) val_out[p] = h_val[(size_t)p];
   }
+  return IMP_OK;
+}
+
+extern "C" int imp_xcorr_argmax_device(imp_ctx* ctx, const float* d_x, const int64_t* a_off, const int64_t* a_len,
+                                       const int64_t* b_off, const int64_t* b_len, int64_t B, int64_t* arg_out, double* val_out) {
+  if (!ctx || (B && (!d_x || !a_off || !a_len || !b_off || !b_len || !arg_out)))
+    return fail(IMP_ERR_INVALID, "imp_xcorr_argmax_device: null argument");
+  if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
+  if (B == 0) return IMP_OK;
+  int64_t lds = 0;
+  for (int64_t p = 0; p < B; ++p) {
+    if (a_len[p] < 1 || b_len[p] < 1 || a_off[p] < 0 || b_off[p] < 0)
+      return fail(IMP_ERR_INVALID, "pair %lld: empty segment or negative offset", (long long)p);
+    if (a_len[p] + b_len[p] > 16384)
+      return fail(IMP_ERR_UNSUPPORTED, "pair %lld: %lld + %lld samples exceed the 16384 the lag search holds in LDS",
+                  (long long)p, (long long)a_len[p], (long long)b_len[p]);
+    lds = std::max(lds, a_len[p] + b_len[p]);
+  }
+  IMP_CTX_LOCK(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  const size_t meta = (size_t)B * sizeof(int64_t);
+  void* scr = nullptr;
+  if ((rc = ctx_scratch(ctx, 6 * meta, &scr))) return rc;
+  int64_t* d_meta = (int64_t*)scr;
+  long long* d_arg = (long long*)(d_meta + 4 * B);
+  double* d_val = (double*)(d_arg + B);
+  HIP_TRY(hipMemcpyAsync(d_meta, a_off, meta, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_meta + B, a_len, meta, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_meta + 2 * B, b_off, meta, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_meta + 3 * B, b_len, meta, hipMemcpyHostToDevice, s));
+  if ((rc = ctx_kernel_lds(ctx, reinterpret_cast<const void*>(imp::xcorr_argmax_kernel<float>), 16384 * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(imp::xcorr_argmax_kernel<float>, dim3((unsigned)B), dim3(256), (size_t)lds * sizeof(double), s, d_x, (const int64_t*)d_meta,
+                     (const int64_t*)(d_meta + B), d_x, (const int64_t*)(d_meta + 2 * B), (const int64_t*)(d_meta + 3 * B), d_arg, d_val);
+  HIP_TRY(hipGetLastError());
+  std::vector<long long> h_arg((size_t)B);
+  std::vector<double> h_val((size_t)B);
+  HIP_TRY(hipMemcpyAsync(h_arg.data(), d_arg, (size_t)B * sizeof(long long), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_val.data(), d_val, (size_t)B * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int64_t p = 0; p < B; ++p) {
+    arg_out[p] = (int64_t)h_arg[(size_t)p];
+    if (val_out) val_out[p] = h_val[(size_t)p];
+  }
+  return IMP_OK;
+}
+
+extern "C" int imp_shift_rows_device(imp_ctx* ctx, const float* d_src, const int64_t* src_off, const int64_t* len,
+                                     const int64_t* shift, int64_t B, float* d_dst, const int64_t* dst_off) {
+  if (!ctx || (B && (!d_src || !src_off || !len || !shift || !d_dst || !dst_off)))
+    return fail(IMP_ERR_INVALID, "imp_shift_rows_device: null argument");
+  if (B < 0) return fail(IMP_ERR_INVALID, "B < 0");
+  if (B == 0) return IMP_OK;
+  int64_t longest = 0;
+  for (int64_t b = 0; b < B; ++b) {
+    if (src_off[b] < 0 || dst_off[b] < 0 || len[b] < 0) return fail(IMP_ERR_INVALID, "negative offset/length in row %lld", (long long)b);
+    longest = std::max(longest, len[b]);
+  }
+  if (longest == 0) return IMP_OK;
+  IMP_CTX_LOCK(ctx);
+  int rc = ctx_bind(ctx);
+  if (rc) return rc;
+  void *h = nullptr, *d = nullptr;
+  const size_t meta = (size_t)B * sizeof(int64_t);
+  if ((rc = ctx_stage(ctx, 4 * meta, &h, &d))) return rc;
+  int64_t* hm = (int64_t*)h;
+  std::memcpy(hm, src_off, meta);
+  std::memcpy(hm + B, len, meta);
+  std::memcpy(hm + 2 * B, shift, meta);
+  std::memcpy(hm + 3 * B, dst_off, meta);
+  if ((rc = ctx_stage_push(ctx, h, d, 4 * meta))) return rc;
+  const int64_t* dm = (const int64_t*)d;
+  hipLaunchKernelGGL(imp::shift_rows_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (longest + 1023) / 1024)), (unsigned)B), dim3(256), 0,
+                     ctx->stream, d_src, dm, dm + B, (const long long*)nullptr, (const long long*)(dm + 2 * B), d_dst, dm + 3 * B);
+  HIP_TRY(hipGetLastError());
   return IMP_OK;
 }
 

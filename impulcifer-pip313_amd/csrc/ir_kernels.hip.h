@@ -555,9 +555,11 @@ __global__ __launch_bounds__(256) void seg_from_float_kernel(const float* __rest
 // scipy.signal.correlate(a, b, "full") then np.argmax).  corr[k] = sum_l a[l + k - (nb - 1)] b[l],
 // k = 0 .. na + nb - 2, summed in fp64 in index order.  One workgroup per pair, both segments in LDS,
 // a thread owns lags k = tid, tid + 256, ...; the first maximum wins, as in np.argmax.
-__global__ __launch_bounds__(256) void xcorr_argmax_kernel(const double* __restrict__ a, const int64_t* __restrict__ a_off,
+// Sample = double (host segments, uploaded) or float (device-resident rows, converted exactly on load)
+template <class Sample>
+__global__ __launch_bounds__(256) void xcorr_argmax_kernel(const Sample* __restrict__ a, const int64_t* __restrict__ a_off,
                                                            const int64_t* __restrict__ a_len,
-                                                           const double* __restrict__ b, const int64_t* __restrict__ b_off,
+                                                           const Sample* __restrict__ b, const int64_t* __restrict__ b_off,
                                                            const int64_t* __restrict__ b_len,
                                                            long long* __restrict__ arg_out, double* __restrict__ val_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -565,8 +567,8 @@ __global__ __launch_bounds__(256) void xcorr_argmax_kernel(const double* __restr
   const int p = blockIdx.x;
   const int na = (int)a_len[p], nb = (int)b_len[p];
   double* sb = sa + na;
-  for (int i = threadIdx.x; i < na; i += blockDim.x) sa[i] = a[a_off[p] + i];
-  for (int i = threadIdx.x; i < nb; i += blockDim.x) sb[i] = b[b_off[p] + i];
+  for (int i = threadIdx.x; i < na; i += blockDim.x) sa[i] = (double)a[a_off[p] + i];
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) sb[i] = (double)b[b_off[p] + i];
   __syncthreads();
   double best = -__builtin_huge_val();
   int best_k = 0x7fffffff;

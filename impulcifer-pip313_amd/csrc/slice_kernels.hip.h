@@ -22,6 +22,8 @@ enum {
   SLICE_SHORT = 64,          // a row shorter than the head fade (the reference skips the fade for that pair)
   SLICE_DECAY_GUARD = 128,   // decay adjustment: a knee search in its guard band, no decay time defined (the reference raises
                              // TypeError), or a knee before the window's start (ValueError): the host flow decides / raises
+  SLICE_ALIGN_GUARD = 256,   // alignment: a row shorter than the correlation segment, an all-zero row, or a delayed row whose
+                             // first sample is not zero (the host flow decides on the materialised rows)
 };
 
 struct SliceRowOut {         // per row, returned to the host at the end (imp_slice_row_result)
@@ -37,6 +39,8 @@ struct SliceRowOut {         // per row, returned to the host at the end (imp_sl
   double decay_level_db;     // ... and the window's level at the knee, as applied (fp32)
   int decay_state;           // 0 no target, 1 adjusted, 2 already faster than the target (left alone), 3 flagged
   int decay_flags;           // KNEE_* of that search
+  long long shift_ipsilateral;   // alignment (imp_slice_set_alignment): samples align_ipsilateral_all delayed the row by (>= 0) ...
+  long long shift_onset;         // ... and the signed shift align_onset_groups_peak_leftref gave it afterwards
 };
 
 struct SliceMeasOut {        // per measurement (imp_slice_result)
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(64) void slice_crop_heads_kernel(const RowPeak* __r
     p.decay_knee = 0;
     p.decay_level_db = 0.f;
     fade_par[b] = p;
-    SliceRowOut r;
+    SliceRowOut r = {};
     r.peak = pk[s];
     r.cut = cut;
     r.len = n;
@@ -238,6 +242,128 @@ struct LoadRowsDeviceLen {
     return Row{make_rsrc(base + off[b], (unsigned)(n > 0 ? n : 0) * 4u), (int)n, (int)(fade_out <= n ? fade_out : 0), win};
   }
 };
+
+// ---- alignment between crop_heads and crop_tails (core/pipeline.py:593-597 -> core/hrir.py:921-1001) -----------------------
+// align_ipsilateral_all: per ipsilateral speaker pair (s1, s2) the lag of the full cross-correlation of the first
+// `segment` samples of s1's left ear and s2's right ear (K10); lag > 0 delays s2 (both ears; s1 == s2: the right ear only),
+// lag < 0 delays s1 (the left ear only when s1 == s2).  The pairs of IPSILATERAL_PAIRS share no speaker, so all searches of
+// a measurement read the rows as crop_heads left them.  align_onset_groups_peak_leftref: every group's rows are shifted by
+// -(peak of its leader's left ear - peak of FL's left ear), peaks taken AFTER the first alignment.
+// ImpulseResponse.shift (core/impulse_response.py:92-108) keeps the length: a delay prepends zeros and drops the tail, an
+// advance drops the head and pads zeros.
+//
+// tables of the lag searches: job j = (measurement m, ipsilateral pair p); one thread per job
+__global__ __launch_bounds__(64) void slice_align_jobs_kernel(const int64_t* __restrict__ off2, const int64_t* __restrict__ len2,
+                                                              const int* __restrict__ ipsi_a, const int* __restrict__ ipsi_b, int n_ipsi,
+                                                              int rows_per_meas, int n_jobs, long long segment,
+                                                              int64_t* __restrict__ a_off, int64_t* __restrict__ a_len,
+                                                              int64_t* __restrict__ b_off, int64_t* __restrict__ b_len,
+                                                              int* __restrict__ meas_flags) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_jobs) return;
+  const int m = j / n_ipsi, p = j - m * n_ipsi;
+  const int ra = m * rows_per_meas + 2 * ipsi_a[p], rb = m * rows_per_meas + 2 * ipsi_b[p] + 1;
+  const long long na = len2[ra] < segment ? len2[ra] : segment, nb = len2[rb] < segment ? len2[rb] : segment;
+  // scipy raises on an empty segment, and lags[argmax] is indexed with len(a) only: unequal segments go to the host flow
+  if (na < 1 || nb < 1 || na != nb) atomicOr(&meas_flags[m], SLICE_ALIGN_GUARD);
+  a_off[j] = off2[ra];
+  a_len[j] = na < 1 ? 1 : na;
+  b_off[j] = off2[rb];
+  b_len[j] = nb < 1 ? 1 : nb;
+}
+
+// the delays of align_ipsilateral_all per row, and the rows' lengths without the samples a delay pushes out (the peak
+// search of the onset alignment runs on those: peak_index(zeros(d) ++ x[:n - d]) = d + peak_index(x[:n - d]) as long as
+// x[0] cannot become a peak by gaining a left neighbour - checked in slice_align_onset_kernel); one thread per measurement
+__global__ __launch_bounds__(64) void slice_align_delays_kernel(const long long* __restrict__ arg, const int64_t* __restrict__ a_len,
+                                                                const int* __restrict__ ipsi_a, const int* __restrict__ ipsi_b, int n_ipsi,
+                                                                int rows_per_meas, int n_meas, const int64_t* __restrict__ len2,
+                                                                long long* __restrict__ d1, int64_t* __restrict__ len1) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_meas) return;
+  const int r0 = m * rows_per_meas;
+  for (int r = 0; r < rows_per_meas; ++r) d1[r0 + r] = 0;
+  for (int p = 0; p < n_ipsi; ++p) {
+    const int j = m * n_ipsi + p;
+    const long long lag = arg[j] - (a_len[j] - 1);             // lags = arange(-len(a) + 1, len(a)); lag = lags[argmax]
+    const int qa = ipsi_a[p], qb = ipsi_b[p];
+    if (qa == qb) {
+      if (lag > 0) d1[r0 + 2 * qa + 1] = lag;
+      else if (lag < 0) d1[r0 + 2 * qa] = -lag;
+    } else if (lag > 0) {
+      d1[r0 + 2 * qb] = lag;
+      d1[r0 + 2 * qb + 1] = lag;
+    } else if (lag < 0) {
+      d1[r0 + 2 * qa] = -lag;
+      d1[r0 + 2 * qa + 1] = -lag;
+    }
+  }
+  for (int r = 0; r < rows_per_meas; ++r) {
+    const long long n = len2[r0 + r] - d1[r0 + r];
+    len1[r0 + r] = n > 0 ? n : 0;
+  }
+}
+
+// the onset shifts: s2 of the rows of pair q = -(P(leader[q]) - P(ref)), P(q) = d1 + peak of q's left row after the first
+// alignment; leader[q] < 0: no shift (the reference group, speakers outside the groups, groups whose leader is absent).
+// One thread per measurement.
+__global__ __launch_bounds__(64) void slice_align_onset_kernel(const RowPeak* __restrict__ res1, const long long* __restrict__ d1,
+                                                               const int64_t* __restrict__ len1, const float* __restrict__ x,
+                                                               const int64_t* __restrict__ off2, const int* __restrict__ leader, int ref_pair,
+                                                               int rows_per_meas, int n_meas, long long* __restrict__ s2,
+                                                               SliceRowOut* __restrict__ rows, int* __restrict__ meas_flags) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n_meas) return;
+  const int r0 = m * rows_per_meas;
+  int flags = meas_flags[m];
+  auto peak_after = [&](int q) {
+    const int b = r0 + 2 * q;
+    const RowPeak rp = res1[b];
+    long long pk;
+    if (len1[b] == 0 || !(__uint_as_float(rp.maxabs_bits) >= 1e-20f)) {
+      pk = 0;
+      if (d1[b] > 0) flags |= SLICE_ALIGN_GUARD;            // an all-zero row: its peak index does not move with the zeros
+    } else {
+      pk = (long long)(rp.first_peak != ~0ull ? rp.first_peak : rp.first_max);
+    }
+    if (d1[b] > 0 && len1[b] > 0 && x[off2[b]] != 0.f) flags |= SLICE_ALIGN_GUARD;   // x[0] gains a zero neighbour: it could become the first peak
+    return d1[b] + pk;
+  };
+  const long long ref = peak_after(ref_pair);
+  for (int q = 0; q < rows_per_meas / 2; ++q) {
+    long long sh = 0;
+    if (leader[q] >= 0) sh = -(peak_after(leader[q]) - ref);
+    for (int e = 0; e < 2; ++e) {
+      const int b = r0 + 2 * q + e;
+      s2[b] = sh;
+      rows[b].shift_ipsilateral = d1[b];
+      rows[b].shift_onset = sh;
+    }
+  }
+  meas_flags[m] = flags;
+}
+
+// ImpulseResponse.shift twice, materialised: y = shift(shift(x, d1), s2), each step keeping the length n (a delay drops the
+// tail, an advance pads zeros).  grid (blocks, rows); dst row b at b * dst_pitch; d1 may be NULL (one shift: s2).
+__global__ __launch_bounds__(256) void shift_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ src_off,
+                                                         const int64_t* __restrict__ len, const long long* __restrict__ d1,
+                                                         const long long* __restrict__ s2, float* __restrict__ dst,
+                                                         const int64_t* __restrict__ dst_off) {
+  const int b = blockIdx.y;
+  const long long n = len[b];
+  const long long a = d1 ? d1[b] : 0, s = s2[b];
+  const float* __restrict__ in = src + src_off[b];
+  float* __restrict__ out = dst + dst_off[b];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long k = i - s;                   // index into the once-shifted row (s > 0: delayed, s < 0: advanced)
+    float v = 0.f;
+    if (k >= 0 && k < n) {
+      const long long j = k - a;                 // index into the source row
+      if (j >= 0 && j < n) v = in[j];
+    }
+    out[i] = v;
+  }
+}
 
 // ---- adjust decay (core/pipeline.py:694-716 -> core/parallel_workers.py:24-39 -> core/decay.py:355-403) ------------------
 // on the equalized rows, for the rows that have a target RT60: decay_params (K3 + K7c, the launches of crop_tails once

@@ -64,7 +64,8 @@ class SliceGeometry(C.Structure):
 class SliceRowResult(C.Structure):
     _fields_ = [("peak", C.c_int64), ("cut", C.c_int64), ("len", C.c_int64), ("knee", C.c_int64),
                 ("knee_flags", C.c_int32), ("knee_why", C.c_int32), ("decay_peak", C.c_int64), ("decay_knee", C.c_int64),
-                ("decay_slope", C.c_double), ("decay_level_db", C.c_double), ("decay_state", C.c_int32), ("decay_flags", C.c_int32)]
+                ("decay_slope", C.c_double), ("decay_level_db", C.c_double), ("decay_state", C.c_int32), ("decay_flags", C.c_int32),
+                ("shift_ipsilateral", C.c_int64), ("shift_onset", C.c_int64)]
 
 
 class SliceResult(C.Structure):
@@ -72,10 +73,10 @@ class SliceResult(C.Structure):
                 ("gain", C.c_float), ("flags", C.c_int32)]
 
 
-SLICE_KNEE_GUARD, SLICE_KNEE_RANGE, SLICE_KEEP_CAP, SLICE_FADE, SLICE_GAIN_GUARD, SLICE_GAIN_NONFINITE, SLICE_SHORT, SLICE_DECAY_GUARD = (
-    1, 2, 4, 8, 16, 32, 64, 128)
+(SLICE_KNEE_GUARD, SLICE_KNEE_RANGE, SLICE_KEEP_CAP, SLICE_FADE, SLICE_GAIN_GUARD, SLICE_GAIN_NONFINITE, SLICE_SHORT, SLICE_DECAY_GUARD,
+ SLICE_ALIGN_GUARD) = (1, 2, 4, 8, 16, 32, 64, 128, 256)
 SLICE_REDO = (SLICE_KNEE_GUARD | SLICE_KNEE_RANGE | SLICE_KEEP_CAP | SLICE_FADE | SLICE_GAIN_GUARD | SLICE_GAIN_NONFINITE
-              | SLICE_DECAY_GUARD)
+              | SLICE_DECAY_GUARD | SLICE_ALIGN_GUARD)
 
 _vp = C.c_void_p
 _i64 = C.c_int64
@@ -126,6 +127,9 @@ SIGNATURES = {
     "imp_slice_execute_device": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64]),
     "imp_slice_results": (C.c_int, [_vp, C.POINTER(SliceRowResult), C.POINTER(SliceResult)]),
     "imp_slice_set_decay": (C.c_int, [_vp, _pd]),
+    "imp_slice_set_alignment": (C.c_int, [_vp, _i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, _i64]),
+    "imp_xcorr_argmax_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _pi64, _pi64, _i64, _pi64, _pd]),
+    "imp_shift_rows_device": (C.c_int, [_vp, _vp, _pi64, _pi64, _pi64, _i64, _vp, _pi64]),
     "imp_slice_pack_f64": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64]),
     "imp_host_alloc": (C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "imp_host_free": (C.c_int, [_vp]),
@@ -444,6 +448,24 @@ class Context:
                                          float(fs), out.ctypes.data_as(_pd)))
         return out
 
+    def xcorr_argmax_device(self, dptr, a_off, a_len, b_off, b_len):
+        """argmax of the full cross-correlation of segment pairs of fp32 device rows (K10): index into correlate(a, b, 'full')"""
+        a_off, a_len, b_off, b_len = (np.ascontiguousarray(v, dtype=np.int64) for v in (a_off, a_len, b_off, b_len))
+        B = len(a_off)
+        arg = np.zeros(B, dtype=np.int64)
+        val = np.zeros(B, dtype=np.float64)
+        if B:
+            _check(self._lib.imp_xcorr_argmax_device(self._h, _vp(int(dptr)), _ptr_i64(a_off), _ptr_i64(a_len), _ptr_i64(b_off), _ptr_i64(b_len),
+                                                     B, _ptr_i64(arg), val.ctypes.data_as(_pd)))
+        return arg, val
+
+    def shift_rows_device(self, d_src, src_off, lens, shifts, d_dst, dst_off):
+        """ImpulseResponse.shift of fp32 device rows into other rows (asynchronous)"""
+        src_off, lens, shifts, dst_off = (np.ascontiguousarray(v, dtype=np.int64) for v in (src_off, lens, shifts, dst_off))
+        if len(lens):
+            _check(self._lib.imp_shift_rows_device(self._h, _vp(int(d_src)), _ptr_i64(src_off), _ptr_i64(lens), _ptr_i64(shifts), len(lens),
+                                                   _vp(int(d_dst)), _ptr_i64(dst_off)))
+
     def decay_times_device(self, dptr, offs, lens, peaks, knees, noise_floors, windows, fs):
         """decay_times for fp32 rows that are on the device: [B, 4] = EDT, RT20, RT30, RT60 (NaN = undefined), the bits the
         rows' float64 copies give through decay_times()"""
@@ -718,6 +740,22 @@ class Slice:
         r = np.ctypeslib.as_array(rows)[:M * self.rows].copy() if M else np.zeros(0)
         m = np.ctypeslib.as_array(meas)[:M].copy() if M else np.zeros(0)
         return r, m
+
+    def set_alignment(self, ipsi_pairs, leader_of_pair, ref_pair, segment):
+        """ipsi_pairs: [(first ear pair, second ear pair)]; leader_of_pair: per ear pair the pair whose left ear leads its
+        onset group (-1: no onset shift); ref_pair: FL's ear pair; segment: samples of the lag search.  None switches the
+        stage off."""
+        p32 = C.POINTER(C.c_int32)
+        if ipsi_pairs is None:
+            _check(self._lib.imp_slice_set_alignment(self._h, 0, None, None, None, 0, 0))
+            return
+        a = np.ascontiguousarray([p[0] for p in ipsi_pairs], dtype=np.int32)
+        b = np.ascontiguousarray([p[1] for p in ipsi_pairs], dtype=np.int32)
+        ld = np.ascontiguousarray(leader_of_pair, dtype=np.int32)
+        if ld.shape != (self.rows // 2,):
+            raise ValueError(f"one onset leader per ear pair ({self.rows // 2}), got {ld.shape}")
+        _check(self._lib.imp_slice_set_alignment(self._h, len(a), a.ctypes.data_as(p32), b.ctypes.data_as(p32), ld.ctypes.data_as(p32),
+                                                 int(ref_pair), int(segment)))
 
     def set_decay(self, targets):
         """target RT60 in seconds per row of a measurement (NaN: leave the row alone); None switches the stage off"""

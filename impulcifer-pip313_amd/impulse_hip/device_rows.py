@@ -79,3 +79,17 @@ def uniform(rows):
     if pitch < rows[0].n or any(rows[i].off - rows[0].off != i * pitch for i in range(len(rows))):
         return None
     return pitch
+
+
+def shift_rows(rows, shifts):
+    """ImpulseResponse.shift (core/impulse_response.py:92-108) for device rows: rows[k] delayed by shifts[k] > 0 or advanced
+    by -shifts[k], length kept.  One new block and one launch for the batch; returns the new rows (the old ones untouched)."""
+    if not rows:
+        return []
+    ctx = rows[0].block.ctx
+    base, offs, lens = span(rows)
+    pitch = [(int(n) + 63) // 64 * 64 for n in lens]
+    dst_off = np.concatenate([[0], np.cumsum(pitch)[:-1]]).astype(np.int64)
+    block = DeviceBlock(ctx, int(sum(pitch)))
+    ctx.shift_rows_device(base, offs, lens, np.asarray(shifts, dtype=np.int64), block.ptr, dst_off)
+    return [Row(block, int(o), int(n)) for o, n in zip(dst_off, lens)]

@@ -703,37 +703,72 @@ class HRIR(object):
                 batch.append(pairs[i])
                 touched |= {pairs[i][0], pairs[i][1]}
                 i += 1
-            a = [self.irs[one]["left"].data[:seg] for one, _ in batch]
-            b = [self.irs[two]["right"].data[:seg] for _, two in batch]
-            arg, _ = ctx.xcorr_argmax(a, b)
-            for (one, two), k, xa in zip(batch, arg, a):
-                lags = np.arange(-len(xa) + 1, len(xa))        # the reference indexes this with the argmax
+            ears_a = [self.irs[one]["left"] for one, _ in batch]
+            ears_b = [self.irs[two]["right"] for _, two in batch]
+            resident = all(ir._data is None and ir._row is not None for ir in ears_a + ears_b)
+            if resident:
+                # the segments where the rows are: nothing comes to the host but the lags
+                from .device_rows import span
+                base, offs, lens = span([ir._row for ir in ears_a + ears_b])
+                nb = len(batch)
+                a_len = [min(seg, int(n)) for n in lens[:nb]]
+                arg, _ = ctx.xcorr_argmax_device(base, offs[:nb], a_len, offs[nb:], [min(seg, int(n)) for n in lens[nb:]])
+            else:
+                a = [ir.data[:seg] for ir in ears_a]
+                arg, _ = ctx.xcorr_argmax(a, [ir.data[:seg] for ir in ears_b])
+                a_len = [len(x) for x in a]
+            todo = []
+            for (one, two), k, la in zip(batch, arg, a_len):
+                lags = np.arange(-la + 1, la)                  # the reference indexes this with the argmax
                 lag = int(lags[int(k)])
                 if one == two:
                     if lag > 0:
-                        self.irs[one]["right"].shift(lag)
+                        todo.append((self.irs[one]["right"], lag))
                     elif lag < 0:
-                        self.irs[one]["left"].shift(-lag)
+                        todo.append((self.irs[one]["left"], -lag))
                     continue
                 target, amount = (two, lag) if lag > 0 else (one, -lag)
                 if lag != 0:
-                    for sd in ("left", "right"):
-                        self.irs[target][sd].shift(amount)
+                    todo.extend((self.irs[target][sd], amount) for sd in ("left", "right"))
+            self._shift_all(todo)
+
+    @staticmethod
+    def _shift_all(todo):
+        """[(ImpulseResponse, samples)]: device-resident responses of the list are shifted with one launch"""
+        from .device_rows import shift_rows
+        dev = [(ir, n) for ir, n in todo if ir._data is None and ir._row is not None and n != 0]
+        if dev:
+            for (ir, _), row in zip(dev, shift_rows([ir._row for ir, _ in dev], [n for _, n in dev])):
+                ir._row = row
+        for ir, n in todo:
+            if not (ir._data is None and ir._row is not None):
+                ir.shift(n)
 
     def align_onset_groups_peak_leftref(self, groups=None):
         if groups is None:
             groups = [("FL", "FR"), ("SL", "SR"), ("BL", "BR"), ("WL", "WR"), ("TFL", "TFR"),
                       ("TSL", "TSR"), ("TBL", "TBR"), ("FC",)]
 
+        leaders = [g[0] for g in [("FL", "FR")] + [g for g in groups if g != ("FL", "FR")]
+                   if g[0] in self.irs and "left" in self.irs[g[0]]]
+        peaks = {}
+        on_dev = [sp for sp in leaders if self.irs[sp]["left"]._data is None and self.irs[sp]["left"]._row is not None]
+        if on_dev:                                             # the leaders' peaks in one device call (K3)
+            from .device_rows import span
+            base, offs, lens = span([self.irs[sp]["left"]._row for sp in on_dev])
+            idx, _ = _native.default_context().peak_index_device(base, offs, lens)
+            peaks = {sp: int(k) for sp, k in zip(on_dev, idx)}
+
         def lead_peak(group):
             sp = group[0]
             if sp not in self.irs or "left" not in self.irs[sp]:
                 return None
-            return self.irs[sp]["left"].peak_index()
+            return peaks[sp] if sp in peaks else self.irs[sp]["left"].peak_index()
 
         ref = lead_peak(("FL", "FR"))
         if ref is None:
             raise RuntimeError("Cannot find FL left channel reference for onset alignment.")
+        todo = []
         for group in groups:
             if group == ("FL", "FR"):
                 continue
@@ -742,5 +777,5 @@ class HRIR(object):
                 continue
             for sp in group:
                 if sp in self.irs:
-                    for sd in ("left", "right"):
-                        self.irs[sp][sd].shift(-(pk - ref))
+                    todo.extend((self.irs[sp][sd], -(pk - ref)) for sd in ("left", "right"))
+        self._shift_all(todo)

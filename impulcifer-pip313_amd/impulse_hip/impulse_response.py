@@ -183,7 +183,13 @@ class ImpulseResponse(object):
         self.data = self.data[max(first, 0):]
 
     def shift(self, samples):
-        """Delay (samples > 0) or advance (samples < 0) keeping the length."""
+        """Delay (samples > 0) or advance (samples < 0) keeping the length.  A response that is on the device stays there
+        (the shifted copy is a new device row)."""
+        if self._data is None and self._row is not None:
+            if samples != 0:
+                from .device_rows import shift_rows
+                self._row = shift_rows([self._row], [int(samples)])[0]
+            return
         n = len(self.data)
         if samples > 0:
             self.data = np.concatenate((np.zeros(samples), self.data))[:n]

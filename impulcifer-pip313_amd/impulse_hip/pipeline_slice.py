@@ -12,6 +12,7 @@ import threading
 from concurrent.futures import ThreadPoolExecutor
 
 from . import _native
+from .constants import IPSILATERAL_PAIRS
 from .frequency_response import FrequencyResponse
 from .hrir import HRIR
 from .decay import adjust_decay_rows
@@ -52,7 +53,7 @@ def _expected_tasks(recordings):
 
 
 def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, decay=None, peak_target=-0.1,
-              hp_left=None, hp_right=None, eq_left=None, eq_right=None, stages=None, firs=None):
+              hp_left=None, hp_right=None, eq_left=None, eq_right=None, stages=None, firs=None, align=False):
     """recordings: list of (path_or_(fs, array), speakers[, side]) measurement files.
     Returns the HRIR after: ingest (batched GPU deconvolution) -> crop_heads -> crop_tails ->
     per-channel minimum-phase FIR (batched GPU design) + equalize -> optional decay adjustment ->
@@ -61,7 +62,10 @@ def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, deca
     context (stream) of its own, and collected where the reference's stage order needs it: same FIRs, same stage
     results, the design's 0.46 ms hidden behind the upload of the recording.
     ``firs`` ({(speaker, side): taps}): FIRs already designed for the job (the curves are per job, not per measurement);
-    no design runs then."""
+    no design runs then.
+    ``align``: run the two alignments `_stage_crop_and_align` has between crop_heads and crop_tails (core/pipeline.py:593-597:
+    align_ipsilateral_all over IPSILATERAL_PAIRS with 30 ms segments, align_onset_groups_peak_leftref); responses that are
+    on the device stay there."""
     hrir = HRIR(estimator)
     fs = estimator.fs
     common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
@@ -88,6 +92,10 @@ def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, deca
     snap("ingest")
     hrir.crop_heads(head_ms=head_ms)
     snap("crop_heads")
+    if align:
+        hrir.align_ipsilateral_all(speaker_pairs=list(IPSILATERAL_PAIRS), segment_ms=30)
+        hrir.align_onset_groups_peak_leftref()
+        snap("align")
     hrir.crop_tails()
     snap("crop_tails")
 

@@ -18,7 +18,7 @@ import warnings
 import numpy as np
 
 from . import _native
-from .constants import SPEAKER_DELAYS, speaker_side
+from .constants import IPSILATERAL_PAIRS, SPEAKER_DELAYS, speaker_side
 from .device_rows import DeviceBlock, Row
 from .hrir import HRIR, next_fast_len, split_recording
 from .impulse_response import ImpulseResponse
@@ -106,6 +106,7 @@ class ResidentSlice:
         self.bits = {np.dtype(np.int16): 16, np.dtype(np.int32): 32, np.dtype(np.float32): 0}[layout.dtype]
         self.firs = None
         self.decay = None
+        self.align = False
         self.slice = None
         self.stats = dict(measurements=0, staged=0, regrown=0)
         self._make(self._cap_for(int(1.1 * fs)) if keep_cap is None else int(keep_cap))
@@ -129,6 +130,31 @@ class ResidentSlice:
             self.set_firs(self.firs)
         if self.decay is not None:
             self.set_decay(self.decay)
+        if self.align:
+            self.set_alignment(True)
+
+    ONSET_GROUPS = [("FL", "FR"), ("SL", "SR"), ("BL", "BR"), ("WL", "WR"), ("TFL", "TFR"), ("TSL", "TSR"), ("TBL", "TBR"), ("FC",)]
+
+    def set_alignment(self, on=True):
+        """the alignments `_stage_crop_and_align` runs between crop_heads and crop_tails (core/pipeline.py:593-597):
+        align_ipsilateral_all over IPSILATERAL_PAIRS with 30 ms segments, then align_onset_groups_peak_leftref - lag searches,
+        leader peaks and the shifted rows all on the device"""
+        self.align = bool(on)
+        if not on:
+            self.slice.set_alignment(None, None, 0, 0)
+            return
+        idx = {sp: q for q, sp in enumerate(self.layout.speakers)}
+        if "FL" not in idx:
+            raise RuntimeError("Cannot find FL left channel reference for onset alignment.")
+        ipsi = [(idx[a], idx[b]) for a, b in IPSILATERAL_PAIRS if a in idx and b in idx]
+        leader = [-1] * len(self.layout.speakers)
+        for group in self.ONSET_GROUPS:
+            if group == ("FL", "FR") or group[0] not in idx:
+                continue
+            for sp in group:
+                if sp in idx:
+                    leader[idx[sp]] = idx[group[0]]
+        self.slice.set_alignment(ipsi, leader, idx["FL"], int(self.fs * 30 / 1000))
 
     def set_decay(self, decay):
         """the optional stage between equalize and normalize (core/pipeline.py:694-716): decay = None (off), a target RT60
@@ -281,7 +307,7 @@ class ResidentSlice:
             def staged(m, batch=batch):
                 jobs = [((self.fs, np.asarray(fr)), spec[2], None) for fr, spec in zip(batch[m], self.layout.files)]
                 return run_slice(self.estimator, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=self.firs_by_task(),
-                                 decay=self.decay)
+                                 decay=self.decay, align=self.align)
 
             results.extend(self.collect(block, batch, staged))
         return results
@@ -350,6 +376,7 @@ class SliceRunner:
                 try:
                     rs.set_firs(job["firs"])
                     rs.set_decay(job["decay"])
+                    rs.set_alignment(job["align"])
                     while True:
                         with self._lock:
                             i = job["next"]
@@ -372,7 +399,7 @@ class SliceRunner:
                         def staged(m, recs=recs):
                             jobs = [((est.fs, np.asarray(fr)), spec[2], None) for fr, spec in zip(recs, layout.files)]
                             return run_slice(est, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=job["firs"],
-                                             decay=job["decay"])
+                                             decay=job["decay"], align=job["align"])
 
                         if not host:
                             res = rs.collect(block, [recs], staged)[0]
@@ -426,12 +453,12 @@ class SliceRunner:
         rs.slice.pack_f64(ln["d_out"], rs.out_pitch, 1, ln["d_packed"], R * cap)
         return None
 
-    def run(self, measurements, firs, to_host=True, decay=None):
+    def run(self, measurements, firs, to_host=True, decay=None, align=False):
         """[(HRIR, gain dB)] in the order of `measurements` ([[frames of file 0, ...], ...]).  firs: {(speaker, side):
         taps}, designed once per job (the curves belong to the job, core/pipeline.py:668-688).  to_host: True = the
         responses as float64 host arrays (as the reference's classes hold them), converted inside the workers;
-        False = left on the device.  decay: as ResidentSlice.set_decay."""
-        job = dict(measurements=measurements, firs=firs, to_host=to_host, decay=decay, next=0, out=[None] * len(measurements))
+        False = left on the device.  decay: as ResidentSlice.set_decay; align: as ResidentSlice.set_alignment."""
+        job = dict(measurements=measurements, firs=firs, to_host=to_host, decay=decay, align=align, next=0, out=[None] * len(measurements))
         lanes = self.lanes[:max(1, min(len(self.lanes), len(measurements)))]
         for ln in lanes:
             ln["todo"].put(job)
@@ -595,6 +622,7 @@ class SlicePipeline:
                 try:
                     rs.set_firs(job["firs"])
                     rs.set_decay(job["decay"])
+                    rs.set_alignment(job["align"])
                 except BaseException as exc:               # noqa: BLE001
                     self._fail(job, exc)
                 for _ in range(len(job["measurements"])):
@@ -631,7 +659,7 @@ class SlicePipeline:
                             rs.stats["staged"] += 1
                             jobs = [((est.fs, np.asarray(fr)), spec[2], None) for fr, spec in zip(recs, layout.files)]
                             res = run_slice(est, jobs, head_ms=self.head_ms, peak_target=self.peak_target, firs=job["firs"],
-                                            decay=job["decay"])
+                                            decay=job["decay"], align=job["align"])
                             if host:
                                 res[0].to_host()
                             out = ("result", res)
@@ -691,12 +719,12 @@ class SlicePipeline:
                     self.done.put(job)
         ctx.close()
 
-    def run(self, measurements, firs, to_host=True, decay=None):
-        """[(HRIR, gain dB)] in the order of `measurements` ([[frames of file 0, ...], ...]); firs, to_host and decay as
-        SliceRunner.run"""
+    def run(self, measurements, firs, to_host=True, decay=None, align=False):
+        """[(HRIR, gain dB)] in the order of `measurements` ([[frames of file 0, ...], ...]); firs, to_host, decay and align
+        as SliceRunner.run"""
         if not len(measurements):
             return []
-        job = dict(measurements=measurements, firs=firs, to_host=to_host, decay=decay, out=[None] * len(measurements), left=len(measurements),
+        job = dict(measurements=measurements, firs=firs, to_host=to_host, decay=decay, align=align, out=[None] * len(measurements), left=len(measurements),
                    error=None)
         for q in self.jobs:
             q.put(job)
@@ -722,7 +750,7 @@ class _Skip(Exception):
     """a measurement of a job that has already failed: passed through the stages untouched"""
 
 
-def run_slice_jobs(estimator, layout, measurements, firs, workers=None, head_ms=1, peak_target=-0.1, decay=None):
+def run_slice_jobs(estimator, layout, measurements, firs, workers=None, head_ms=1, peak_target=-0.1, decay=None, align=False):
     """one job through a runner made for it (responses on the host): the three-stage SlicePipeline, or with `workers` that
     many SliceRunner lanes; callers with several jobs keep a runner"""
     if workers is None:
@@ -730,7 +758,7 @@ def run_slice_jobs(estimator, layout, measurements, firs, workers=None, head_ms=
     else:
         runner = SliceRunner(estimator, layout, workers=workers, head_ms=head_ms, peak_target=peak_target)
     try:
-        return runner.run(measurements, firs, to_host=True, decay=decay)
+        return runner.run(measurements, firs, to_host=True, decay=decay, align=align)
     finally:
         runner.close()
 

@@ -331,6 +331,15 @@ int imp_sosfilt(imp_ctx* ctx, const double* sos, int64_t n_sections, const doubl
  */
 int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_off, const int64_t* a_len, const double* b,
                      const int64_t* b_off, const int64_t* b_len, int64_t B, int64_t* arg_out, double* val_out);
+/* the same for segments of fp32 rows that are on the device (both of a pair at d_x + offset; converted exactly on load, so
+ * the sums have the bits imp_xcorr_argmax forms from the rows' float64 copies); tables and results are host memory */
+int imp_xcorr_argmax_device(imp_ctx* ctx, const float* d_x, const int64_t* a_off, const int64_t* a_len, const int64_t* b_off,
+                            const int64_t* b_len, int64_t B, int64_t* arg_out, double* val_out);
+/* ImpulseResponse.shift (core/impulse_response.py:92-108) for fp32 device rows: row b (len[b] samples at d_src +
+ * src_off[b]) delayed by shift[b] > 0 (zeros in front, the tail dropped) or advanced by -shift[b] (the head dropped, zeros
+ * behind), length kept, written to d_dst + dst_off[b] (not the source rows).  Asynchronous on the context's stream. */
+int imp_shift_rows_device(imp_ctx* ctx, const float* d_src, const int64_t* src_off, const int64_t* len, const int64_t* shift,
+                          int64_t B, float* d_dst, const int64_t* dst_off);
 
 /* ---- K3: first significant peak ---------------------------------------------------------------
  * core/impulse_response.py:32-70 ImpulseResponse.peak_index (twin core/decay.py:12-41):
@@ -481,6 +490,8 @@ void imp_chain_destroy(imp_chain* chain);
 #define IMP_SLICE_GAIN_GUARD 16
 #define IMP_SLICE_GAIN_NONFINITE 32
 #define IMP_SLICE_SHORT 64          /* informational: a pair shorter than the head fade kept its head un-faded */
+#define IMP_SLICE_ALIGN_GUARD 256   /* alignment: a row shorter than the correlation segment, an all-zero row, or a delayed row
+                                     * whose first sample is not zero: the host flow decides on the materialised rows */
 #define IMP_SLICE_DECAY_GUARD 128   /* decay adjustment: a knee search in its guard band, no decay time defined, or a knee
                                      * before the window's start (the reference raises): the host flow decides */
 typedef struct imp_slice imp_slice;
@@ -512,6 +523,8 @@ typedef struct imp_slice_row_result {
   double decay_level_db;         /* the window's level at the knee as applied (core/decay.py:375) */
   int32_t decay_state;           /* 0 no target, 1 adjusted, 2 already faster than the target, 3 left to the host flow */
   int32_t decay_flags;           /* flags_out of imp_decay_knees_device for that search */
+  int64_t shift_ipsilateral;     /* alignment (imp_slice_set_alignment): samples align_ipsilateral_all delayed the row by */
+  int64_t shift_onset;           /* ... and the signed shift align_onset_groups_peak_leftref gave it afterwards */
 } imp_slice_row_result;
 typedef struct imp_slice_result {
   int64_t keep;                  /* crop_tails' return value */
@@ -531,6 +544,23 @@ int imp_slice_info(const imp_slice* slice, int64_t* rows_per_measurement, int64_
 int imp_slice_set_firs(imp_slice* slice, const double* firs, int64_t ld);
 /* the same from FIRs on the device (imp_curves_equalization_fir_device): no upload, no wait */
 int imp_slice_set_firs_device(imp_slice* slice, const double* d_firs, int64_t ld);
+/* The alignment between crop_heads and crop_tails (core/pipeline.py:593-597 -> core/hrir.py:921-1001), on the device:
+ *   align_ipsilateral_all            per ipsilateral pair p = (ear pair ipsi_first[p], ear pair ipsi_second[p]) the lag of the
+ *                                    full cross-correlation of the first `segment` samples of the first's left ear and the
+ *                                    second's right ear (K10); lag > 0 delays the second (both ears; first == second: its
+ *                                    right ear only), lag < 0 the first.  No ear pair may appear in two entries (the
+ *                                    reference's IPSILATERAL_PAIRS share no speaker): the searches of a measurement then
+ *                                    all read the rows as crop_heads left them.
+ *   align_onset_groups_peak_leftref  the rows of ear pair q are shifted by -(peak of leader_of_pair[q]'s left ear - peak of
+ *                                    ref_pair's left ear), peaks taken after the first alignment; leader_of_pair[q] < 0:
+ *                                    no shift (the reference group, speakers outside the groups, groups whose first
+ *                                    speaker is absent)
+ * Both shifts keep a row's length (ImpulseResponse.shift); the aligned rows are materialised once and the later stages read
+ * them.  n_ipsi = 0 with leader_of_pair = NULL switches the stage off.  A measurement the device cannot promise to align as
+ * the host flow would is flagged IMP_SLICE_ALIGN_GUARD.  Bit-identical to imp_xcorr_argmax_device -> imp_shift_rows_device
+ * -> imp_peak_index_device -> imp_shift_rows_device.  Drains the stream. */
+int imp_slice_set_alignment(imp_slice* slice, int64_t n_ipsi, const int32_t* ipsi_first, const int32_t* ipsi_second,
+                            const int32_t* leader_of_pair, int32_t ref_pair, int64_t segment);
 /* The optional stage between equalize and normalize (core/pipeline.py:694-716 -> core/parallel_workers.py:24-39 ->
  * core/decay.py:355-403): target_rt60[2 n_pairs], the target 60 dB decay time in seconds of row r of every measurement, NaN
  * for rows to leave alone (the reference's `decay` dict is per speaker); NULL or all NaN switches the stage off.  Per row

@@ -141,6 +141,43 @@ def align_ipsilateral_all(irs, fs, speaker_pairs, segment_ms=30):
     return out
 
 
+def align_onset_groups_peak_leftref(irs, groups=None):
+    """core/hrir.py:960-1001 on a dict {speaker: {side: fp64 array}}; returns the shifted copies: every group is shifted
+    by -(peak_index of its first speaker's left ear - peak_index of FL's left ear); a group whose first speaker is absent
+    is left alone; a missing FL raises."""
+    from .impulse_response import peak_index
+
+    def shift(d, s):                                       # core/impulse_response.py:92-108
+        n = len(d)
+        if s > 0:
+            return np.concatenate((np.zeros(s), d))[:n]
+        if s < 0:
+            t = d[-s:]
+            return np.pad(t, (0, n - len(t))) if len(t) < n else t
+        return d
+    if groups is None:
+        groups = [("FL", "FR"), ("SL", "SR"), ("BL", "BR"), ("WL", "WR"), ("TFL", "TFR"), ("TSL", "TSR"), ("TBL", "TBR"), ("FC",)]
+    out = {sp: {sd: np.array(x, dtype=np.float64) for sd, x in pair.items()} for sp, pair in irs.items()}
+
+    def lead(group):
+        sp = group[0]
+        return peak_index(out[sp]["left"]) if sp in out and "left" in out[sp] else None
+    ref = lead(("FL", "FR"))
+    if ref is None:
+        raise RuntimeError("Cannot find FL left channel reference for onset alignment.")
+    for group in groups:
+        if group == ("FL", "FR"):
+            continue
+        pk = lead(group)
+        if pk is None:
+            continue
+        for sp in group:
+            if sp in out:
+                for sd in ("left", "right"):
+                    out[sp][sd] = shift(out[sp][sd], -(pk - ref))
+    return out
+
+
 # core/constants.py:95-104
 HESUVI_TRACK_ORDER = ['FL-left', 'FL-right', 'SL-left', 'SL-right', 'BL-left', 'BL-right', 'FC-left', 'FR-right',
                       'FR-left', 'SR-right', 'SR-left', 'BR-right', 'BR-left', 'FC-right', 'WL-left', 'WL-right',

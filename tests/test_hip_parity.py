@@ -998,6 +998,26 @@ def test_alignment_matches_reference_run(gpu_ctx, golden):
                 assert int(np.argmax(np.abs(d))) == int(g[f"{name}_{sp}_{sd}_peak"]), (name, sp, sd)
                 np.testing.assert_array_equal(d[:96], g[f"{name}_{sp}_{sd}_head"])
                 np.testing.assert_array_equal(d[-96:], g[f"{name}_{sp}_{sd}_tail"])
+        # the same with the responses as rows of a device block (fp32: the inputs rounded first, so the comparison is with
+        # the host-array form on the SAME rounded inputs - lags and peaks are integers, the shifted samples exact copies)
+        from impulse_hip.device_rows import DeviceBlock, Row
+        names = [(sp, sd) for sp in irs for sd in ("left", "right")]
+        rounded = {k: irs[k[0]][k[1]].astype(np.float32) for k in names}
+        pitch = max(len(x) for x in rounded.values()) + 64
+        block = DeviceBlock(gpu_ctx, pitch * len(names))
+        flat = np.zeros(pitch * len(names), dtype=np.float32)
+        for i, k in enumerate(names):
+            flat[i * pitch:i * pitch + len(rounded[k])] = rounded[k]
+        gpu_ctx.h2d(block.ptr, flat)
+        dev, host = HRIR(Est()), HRIR(Est())
+        for i, (sp, sd) in enumerate(names):
+            dev.irs.setdefault(sp, {})[sd] = ImpulseResponse.on_device(Row(block, i * pitch, len(rounded[(sp, sd)])), 48000)
+            host.irs.setdefault(sp, {})[sd] = ImpulseResponse(rounded[(sp, sd)].astype(np.float64), 48000)
+        call(dev)
+        call(host)
+        for sp, sd in names:
+            assert dev.irs[sp][sd]._data is None and dev.irs[sp][sd]._row is not None, (name, sp, sd)
+            np.testing.assert_array_equal(dev.irs[sp][sd].peek(), host.irs[sp][sd].data)
 
 
 @pytest.mark.parametrize("method", ["mids", "trend", "left", "right", "avg", "min", "-1.5"])

@@ -346,6 +346,15 @@ def test_ipsilateral_alignment(golden):
     a[60] = 1.0
     b[67] = 1.0
     assert abs(ohrir.ipsilateral_lag(a, b, 1440)) == 7
+    # align_onset_groups_peak_leftref (core/hrir.py:960-1001) against the same reference run
+    out = ohrir.align_onset_groups_peak_leftref(irs)
+    for sp in irs:
+        for sd in ("left", "right"):
+            d = out[sp][sd]
+            assert int(np.argmax(np.abs(d))) == int(g[f"onset_{sp}_{sd}_peak"])
+            np.testing.assert_array_equal(d[:96], g[f"onset_{sp}_{sd}_head"])
+            np.testing.assert_array_equal(d[-96:], g[f"onset_{sp}_{sd}_tail"])
+            assert float(np.sum(d)) == float(g[f"onset_{sp}_{sd}_sum"])
 
 
 def test_sosfilt_restatement(golden):

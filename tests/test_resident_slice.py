@@ -55,15 +55,15 @@ def synth_firs(tasks, taps, seed):
     return {t: firs[i] for i, t in enumerate(tasks)}
 
 
-def staged_measurement(e, files, firs, decay=None):
+def staged_measurement(e, files, firs, decay=None, align=False):
     """the staged class path of one measurement (one host readback per stage)"""
     from impulse_hip.pipeline_slice import run_slice
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return run_slice(e, [((e.fs, fr), sp) for fr, sp in files], firs=firs, decay=decay)
+        return run_slice(e, [((e.fs, fr), sp) for fr, sp in files], firs=firs, decay=decay, align=align)
 
 
-def oracle_measurement(oe, files, firs, fs, decay=None):
+def oracle_measurement(oe, files, firs, fs, decay=None, align=False):
     """the oracle composition: estimate -> crop_heads -> crop_tails -> FIR 'full' -> [adjust decay] -> normalize (fp64)"""
     from oracle import decay as odecay
     from oracle import hrir as ohrir
@@ -75,6 +75,10 @@ def oracle_measurement(oe, files, firs, fs, decay=None):
         for sp, sd, col in ohrir.split_recording(stored, speakers, N, fs):
             irs.setdefault(sp, {})[sd] = oe.estimate(col)
     irs = ohrir.crop_heads(irs, fs, head_ms=1)
+    if align:
+        pairs = (("FL", "FR"), ("SL", "SR"), ("BL", "BR"), ("TFL", "TFR"), ("TSL", "TSR"), ("TBL", "TBR"), ("FC", "FC"), ("WL", "WR"))
+        irs = ohrir.align_ipsilateral_all(irs, fs, pairs, segment_ms=30)
+        irs = ohrir.align_onset_groups_peak_leftref(irs)
     tail_ind, irs = ohrir.crop_tails(irs, fs, N, oe.n_octaves)
     for sp in irs:
         for sd in irs[sp]:
@@ -318,6 +322,90 @@ def test_resident_slice_decay_stage():
         again = rs.run(meas[:1])
     assert_same_as_staged(again[0], staged_measurement(e, [(meas[0][0], spk)], firs))
     assert np.all(rs.slice.results()[0]["decay_state"] == 0)
+    rs.close()
+
+
+def test_resident_slice_alignment_stage():
+    """The alignments `_stage_crop_and_align` runs between crop_heads and crop_tails (core/pipeline.py:593-597):
+    align_ipsilateral_all (lags from the cross-correlation of 30 ms segments, K10) and align_onset_groups_peak_leftref.  A
+    5-speaker layout whose arrival times differ per speaker, so that both alignments really shift rows (delays and
+    advances).  The resident sequence decides lags, leader peaks and shifts on the device; the staged path does the same
+    on device rows (xcorr_argmax_device, shift_rows); both equal the oracle composition of the same stages; the shifts are
+    the oracle's integers; the host-array form of the two methods (responses brought to the host first) gives the same
+    samples."""
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.resident_slice import Layout, ResidentSlice, _fir_taps
+    from impulse_hip.pipeline_slice import run_slice
+    from oracle import estimator as oest
+    from oracle import hrir as ohrir
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=fs)
+    oe = oest.Estimator(min_duration=1.0, fs=fs)
+    spk = ["FL", "FR", "FC", "SL", "SR"]
+    meas = [[synth_frames(e, spk, 1200 + m, rt60=0.2 + 0.02 * m)] for m in range(3)]
+    layout = Layout(e, [(meas[0][0].shape[0], 2, spk)])
+    firs = synth_firs(layout.tasks, _fir_taps(fs), 13)
+    rs = ResidentSlice(e, layout, max_measurements=3)
+    rs.set_firs(firs)
+    rs.set_alignment(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = rs.run(meas)
+    rows, res = rs.slice.results()
+    assert rs.stats["staged"] == 0, res["flags"]
+    assert np.any(rows["shift_ipsilateral"] > 0) and np.any(rows["shift_onset"] != 0)
+    R = rs.slice.rows
+    N = len(oe)
+    for m in range(3):
+        want = staged_measurement(e, [(meas[m][0], spk)], firs, align=True)
+        assert_same_as_staged(got[m], want)
+        # the shifts against the oracle's own alignment of the oracle's cropped responses
+        stored = meas[m][0].T.astype(np.float64) / 2.0 ** 31
+        irs = {}
+        for sp, sd, col in ohrir.split_recording(stored, spk, N, fs):
+            irs.setdefault(sp, {})[sd] = oe.estimate(col)
+        irs = ohrir.crop_heads(irs, fs, head_ms=1)
+        seg = int(fs * 30 / 1000)
+        lag_fl = ohrir.ipsilateral_lag(irs["FL"]["left"], irs["FR"]["right"], seg)
+        d = rows["shift_ipsilateral"][m * R:(m + 1) * R]
+        assert (int(d[2]), int(d[3])) == ((lag_fl, lag_fl) if lag_fl > 0 else (0, 0))          # FR delayed by a positive lag
+        assert (int(d[0]), int(d[1])) == ((-lag_fl, -lag_fl) if lag_fl < 0 else (0, 0))
+        tail_ind, g, o_irs = oracle_measurement(oe, [(meas[m][0], spk)], firs, fs, align=True)
+        assert int(res["keep"][m]) == tail_ind
+        assert got[m][1] == pytest.approx(g, abs=1e-5)
+        for sp in o_irs:
+            for sd in o_irs[sp]:
+                assert rel(got[m][0].irs[sp][sd].peek(), o_irs[sp][sd]) <= 2 * TIME_TOL, (sp, sd)
+    # the host-array form of the two methods on the same cropped responses
+    from impulse_hip.hrir import HRIR
+    from impulse_hip.constants import IPSILATERAL_PAIRS
+    a, b = HRIR(e), HRIR(e)
+    for h in (a, b):
+        h.open_recording_frames(fs, meas[0][0], spk)
+        h.crop_heads(head_ms=1)
+    for sp in spk:
+        for sd in ("left", "right"):
+            b.irs[sp][sd].data = b.irs[sp][sd].data                          # to the host
+    for h in (a, b):
+        h.align_ipsilateral_all(speaker_pairs=list(IPSILATERAL_PAIRS), segment_ms=30)
+        h.align_onset_groups_peak_leftref()
+    for sp in spk:
+        for sd in ("left", "right"):
+            assert a.irs[sp][sd]._data is None and a.irs[sp][sd]._row is not None          # never left the device
+            assert np.array_equal(a.irs[sp][sd].peek(), b.irs[sp][sd].data), (sp, sd)
+    # alignment and decay together, then both off again
+    rs.set_decay({"FL": 0.5})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        both = rs.run(meas[:1])
+    assert_same_as_staged(both[0], staged_measurement(e, [(meas[0][0], spk)], firs, decay={"FL": 0.5}, align=True))
+    rs.set_decay(None)
+    rs.set_alignment(False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plain = rs.run(meas[:1])
+    assert_same_as_staged(plain[0], staged_measurement(e, [(meas[0][0], spk)], firs))
+    assert np.all(rs.slice.results()[0]["shift_onset"] == 0)
     rs.close()
 
 
