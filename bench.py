@@ -235,7 +235,7 @@ def slice_rate(est, rec, L, reps=24, workers=None):
     def job(n, to_host=True):
         firs = {(sp, sd): fir for sp, sd, fir in process_equalization_batch(layout.tasks, None, None, None, None, None, target, common, fs,
                                                                             on_device=True)}
-        return runner.run([[frames]] * n, firs, to_host=to_host), firs
+        return runner.run([[frames]] * n, firs, to_host=to_host, align=True), firs
 
     import warnings
     with warnings.catch_warnings():
@@ -261,18 +261,18 @@ def slice_rate(est, rec, L, reps=24, workers=None):
                 b[0][...] = frames
             for _ in range(2):
                 t0 = time.perf_counter()
-                r_ = runner.run([bufs[i % 4] for i in range(reps)], firs)
+                r_ = runner.run([bufs[i % 4] for i in range(reps)], firs, align=True)
                 d_ = (time.perf_counter() - t0) / reps * 1e3
                 pinned_ms = d_ if pinned_ms is None else min(pinned_ms, d_)
                 del r_
             del bufs
         # the same measurement through the staged class path (one host readback per stage): identical samples
-        hrir, gain = run_slice(est, [((fs, frames), speakers)], firs=firs)
+        hrir, gain = run_slice(est, [((fs, frames), speakers)], firs=firs, align=True)
         same = all(np.array_equal(res[k][0].irs[sp][sd].data, hrir.irs[sp][sd].data) for k in (0, reps - 1) for sp in speakers
                    for sd in ("left", "right"))
         t0 = time.perf_counter()
         for _ in range(4):
-            run_slice(est, [((fs, frames), speakers)], firs=firs)[0].to_host()
+            run_slice(est, [((fs, frames), speakers)], firs=firs, align=True)[0].to_host()
         staged_ms = (time.perf_counter() - t0) / 4 * 1e3
         runner.close()
     return dict(value=16 / dt, unit="IR/s", ms_per_measurement=dt * 1e3, measurements=reps, workers=workers,
@@ -313,7 +313,7 @@ class SliceTeam:
     a context (stream) of its own, fed round robin by one host thread; the recordings of a call sit in HBM (a ring of
     `ring` call blocks per stream, so that a call's inputs were last touched 2+ calls ago)."""
 
-    def __init__(self, est, rec, L, n_streams=2, M=8, ring=3, speakers=None, quiet_setup=False):
+    def __init__(self, est, rec, L, n_streams=2, M=8, ring=3, speakers=None, quiet_setup=False, align=True):
         from impulse_hip import Context
         from impulse_hip._native import using_context
         from impulse_hip.resident_slice import Layout, ResidentSlice
@@ -333,6 +333,7 @@ class SliceTeam:
             if self.firs is None:
                 self.firs = synth_firs(len(self.layout.tasks), rs.taps)
             rs.set_firs(self.firs)
+            rs.set_alignment(align)
             d_in = []
             for _ in range(ring):
                 p = ctx.malloc(M * packed.nbytes)
@@ -358,7 +359,7 @@ class SliceTeam:
         rs = self.lanes[0]["rs"]
         return (f"{len(self.lanes)} streams x {self.M} measurements per call, {self.rows} rows each, column {self.layout.column_len}, "
                 f"keep_cap {rs.keep_cap}, taps {rs.taps}, normalisation transform {rs.slice.norm_fft_len} points, "
-                f"{'pair' if rs.plan.paired else 'mono'} plan of {rs.plan.n1} rows")
+                f"{'pair' if rs.plan.paired else 'mono'} plan of {rs.plan.n1} rows, alignment {'on' if rs.align else 'off'}")
 
     def step(self, design=False):
         """one call per lane; design: the call's FIRs are designed first (K12 -> K6 on the lane's stream, flat target: the
@@ -878,6 +879,19 @@ def slice_resident_block(est, rec, L, workload, no_pmc=False, n_streams=3, M=8, 
         dt_design = time.perf_counter() - t0
         for ln in team.lanes:                              # back to the job FIRs the checks below use
             ln["rs"].set_firs(team.firs)
+        # the sequence without the two alignments (what rounds 3 / early 4 timed)
+        for ln in team.lanes:
+            ln["rs"].set_alignment(False)
+        for _ in range(2):
+            team.step()
+        team.sync()
+        t0 = time.perf_counter()
+        for _ in range(calls_d):
+            team.step()
+        team.sync()
+        dt_plain = time.perf_counter() - t0
+        for ln in team.lanes:
+            ln["rs"].set_alignment(True)
         # the same with the optional stage between equalize and normalize: every row's decay pulled to a 0.3 s RT60
         for ln in team.lanes:
             ln["rs"].set_decay(0.3)
@@ -901,7 +915,7 @@ def slice_resident_block(est, rec, L, workload, no_pmc=False, n_streams=3, M=8, 
         out = team.fetch(0)
         rs = team.lanes[0]["rs"]
         firs = {t: team.firs[i] for i, t in enumerate(team.layout.tasks)}
-        hrir, gain = run_slice(est, [((est.fs, team.frames), team.speakers)], firs=firs)
+        hrir, gain = run_slice(est, [((est.fs, team.frames), team.speakers)], firs=firs, align=True)
         n = int(meas["out_len"][0])
         same = abs(float(meas["gain_db"][0]) - gain) <= 1e-11
         for q, sp in enumerate(team.speakers):
@@ -922,6 +936,11 @@ def slice_resident_block(est, rec, L, workload, no_pmc=False, n_streams=3, M=8, 
                                                note="every call designs its 16 minimum-phase FIRs first (K12 -> K6 on the call's "
                                                     "stream, left on the device, spectra formed there): a job of M measurements "
                                                     "with equalisation curves of its own per call"),
+                 without_alignment=dict(value=calls_d * n_streams * M * rows_per / dt_plain, unit="IR/s", calls=calls_d * n_streams,
+                                        note="ingest -> crop_heads -> crop_tails -> equalize -> normalize only (the sequence of "
+                                             "earlier rounds' lines)"),
+                 shifts_of_one_measurement=dict(ipsilateral=[int(v) for v in rows["shift_ipsilateral"][:rows_per]],
+                                                onset=[int(v) for v in rows["shift_onset"][:rows_per]]),
                  with_decay_adjustment=dict(value=calls_d * n_streams * M * rows_per / dt_decay, unit="IR/s", calls=calls_d * n_streams,
                                             target_rt60_s=0.3, row_states_of_one_call=decay_states, flags_seen=decay_flags,
                                             note="the optional stage of core/pipeline.py:694-716 between equalize and normalize, on "
@@ -930,8 +949,9 @@ def slice_resident_block(est, rec, L, workload, no_pmc=False, n_streams=3, M=8, 
                  keep=int(meas["keep"][0]), out_len=n, flags_seen=flags, no_measurement_flagged=flags == [0],
                  bit_identical_to_staged_path=bool(same),
                  algorithmic_bytes_per_ir=alg, path_achieved=rate * alg / 1e9, path_frac=rate * alg / 1e9 / HBM_PEAK_GBS,
-                 note="the reference's stage sequence (core/pipeline.py:565-573, 585-601, 647-692, 725-735) per measurement: "
+                 note="the reference's stage sequence (core/pipeline.py:565-573, 585-601 incl. the alignments of :593-597, 647-692, 725-735) per measurement: "
                       "PCM frames in HBM -> K1 (pair mode) -> first peaks -> crop_heads (earlier ear of each pair - 1 ms, fade-in) -> "
+                      "align_ipsilateral_all (K10 lags of 30 ms segments) + align_onset_groups_peak_leftref, rows materialised -> "
                       "Lundeby knees (K7c) -> crop_tails at min(shortest row, next_fast_len(latest knee)) + fade-out -> per-channel "
                       f"{rs.taps}-tap FIR (K5) -> normalize (K2 of the ear sums, gain on the device); scalars read back once per call; "
                       "FIRs set once per job.  algorithmic bytes per IR = the recording's PCM bytes / 16 in + 4 (keep + taps - 1) out")

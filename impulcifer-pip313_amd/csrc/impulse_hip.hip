@@ -2368,6 +2368,28 @@ extern "C" int imp_sosfilt(imp_ctx* ctx, const double* sos, int64_t n_sections, 
   return IMP_OK;
 }
 
+// K10 on the stream: the lag slices of every pair, then the first maximum over the slices.  lds_doubles = longest a_len + b_len,
+// nk_max = longest a_len + b_len - 1; part_k / part_val: [B * xcorr_slices(nk_max)]
+static int64_t xcorr_slices(int64_t nk_max) {
+  const int64_t per = (int64_t)imp::kXcorrThreads * imp::kXcorrLags;
+  return std::max<int64_t>(1, (nk_max + per - 1) / per);
+}
+template <class Sample>
+static int launch_xcorr(imp_ctx* ctx, hipStream_t s, const Sample* a, const int64_t* a_off, const int64_t* a_len, const Sample* b,
+                        const int64_t* b_off, const int64_t* b_len, int64_t B, int64_t lds_doubles, int64_t nk_max, long long* part_k,
+                        double* part_val, long long* d_arg, double* d_val) {
+  int rc;
+  if ((rc = ctx_kernel_lds(ctx, reinterpret_cast<const void*>(imp::xcorr_argmax_kernel<Sample>), (size_t)imp::xcorr_lds_doubles(16384, 0) * sizeof(double))))
+    return rc;
+  const int64_t S = xcorr_slices(nk_max);
+  hipLaunchKernelGGL(imp::xcorr_argmax_kernel<Sample>, dim3((unsigned)B, (unsigned)S), dim3(imp::kXcorrThreads),
+                     (size_t)imp::xcorr_lds_doubles(lds_doubles, 0) * sizeof(double), s, a, a_off, a_len, b, b_off, b_len, part_k, part_val);
+  hipLaunchKernelGGL(imp::xcorr_reduce_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, (const long long*)part_k, (const double*)part_val, (int)S,
+                     (int)B, d_arg, d_val);
+  HIP_TRY(hipGetLastError());
+  return IMP_OK;
+}
+
 extern "C" int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_off, const int64_t* a_len,
                                 const double* b, const int64_t* b_off, const int64_t* b_len, int64_t B,
                                 int64_t* arg_out, double* val_out) {
@@ -2392,7 +2414,8 @@ extern "C" int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_
   hipStream_t s = ctx->stream;
   // scratch: a, b (fp64), 4 x int64 meta, arg (int64), val (fp64)
   const size_t meta = (size_t)B * sizeof(int64_t);
-  const size_t bytes = (size_t)(ta + tb) * sizeof(double) + 6 * meta;
+  const int64_t S = xcorr_slices(lds - 1);
+  const size_t bytes = (size_t)(ta + tb) * sizeof(double) + 6 * meta + 2 * (size_t)(B * S) * 8;
   void* scr = nullptr;
   if ((rc = ctx_scratch(ctx, bytes, &scr))) return rc;
   double* d_a = (double*)scr;
@@ -2400,16 +2423,16 @@ extern "C" int imp_xcorr_argmax(imp_ctx* ctx, const double* a, const int64_t* a_
   int64_t* d_meta = (int64_t*)(d_b + tb);
   long long* d_arg = (long long*)(d_meta + 4 * B);
   double* d_val = (double*)(d_arg + B);
+  long long* d_pk = (long long*)(d_val + B);
+  double* d_pv = (double*)(d_pk + B * S);
   HIP_TRY(hipMemcpyAsync(d_a, a, (size_t)ta * sizeof(double), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_b, b, (size_t)tb * sizeof(double), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_meta, a_off, meta, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_meta + B, a_len, meta, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_meta + 2 * B, b_off, meta, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_meta + 3 * B, b_len, meta, hipMemcpyHostToDevice, s));
-  if ((rc = ctx_kernel_lds(ctx, reinterpret_cast<const void*>(imp::xcorr_argmax_kernel<double>), 16384 * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(imp::xcorr_argmax_kernel<double>, dim3((unsigned)B), dim3(256), (size_t)lds * sizeof(double), s, (const double*)d_a, (const int64_t*)d_meta,
-                     d_meta + B, d_b, d_meta + 2 * B, d_meta + 3 * B, d_arg, d_val);
-  HIP_TRY(hipGetLastError());
+  if ((rc = launch_xcorr<double>(ctx, s, d_a, d_meta, d_meta + B, d_b, d_meta + 2 * B, d_meta + 3 * B, B, lds, lds - 1, d_pk, d_pv, d_arg, d_val)))
+    return rc;
   std::vector<long long> h_arg((size_t)B);
   std::vector<double> h_val((size_t)B);
   HIP_TRY(hipMemcpyAsync(h_arg.data(), d_arg, (size_t)B * sizeof(long long), hipMemcpyDeviceToHost, s));
@@ -2442,19 +2465,20 @@ extern "C" int imp_xcorr_argmax_device(imp_ctx* ctx, const float* d_x, const int
   if (rc) return rc;
   hipStream_t s = ctx->stream;
   const size_t meta = (size_t)B * sizeof(int64_t);
+  const int64_t S = xcorr_slices(lds - 1);
   void* scr = nullptr;
-  if ((rc = ctx_scratch(ctx, 6 * meta, &scr))) return rc;
+  if ((rc = ctx_scratch(ctx, 6 * meta + 2 * (size_t)(B * S) * 8, &scr))) return rc;
   int64_t* d_meta = (int64_t*)scr;
   long long* d_arg = (long long*)(d_meta + 4 * B);
   double* d_val = (double*)(d_arg + B);
+  long long* d_pk = (long long*)(d_val + B);
+  double* d_pv = (double*)(d_pk + B * S);
   HIP_TRY(hipMemcpyAsync(d_meta, a_off, meta, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_meta + B, a_len, meta, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_meta + 2 * B, b_off, meta, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_meta + 3 * B, b_len, meta, hipMemcpyHostToDevice, s));
-  if ((rc = ctx_kernel_lds(ctx, reinterpret_cast<const void*>(imp::xcorr_argmax_kernel<float>), 16384 * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(imp::xcorr_argmax_kernel<float>, dim3((unsigned)B), dim3(256), (size_t)lds * sizeof(double), s, d_x, (const int64_t*)d_meta,
-                     (const int64_t*)(d_meta + B), d_x, (const int64_t*)(d_meta + 2 * B), (const int64_t*)(d_meta + 3 * B), d_arg, d_val);
-  HIP_TRY(hipGetLastError());
+  if ((rc = launch_xcorr<float>(ctx, s, d_x, d_meta, d_meta + B, d_x, d_meta + 2 * B, d_meta + 3 * B, B, lds, lds - 1, d_pk, d_pv, d_arg, d_val)))
+    return rc;
   std::vector<long long> h_arg((size_t)B);
   std::vector<double> h_val((size_t)B);
   HIP_TRY(hipMemcpyAsync(h_arg.data(), d_arg, (size_t)B * sizeof(long long), hipMemcpyDeviceToHost, s));

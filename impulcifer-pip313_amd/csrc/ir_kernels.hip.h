@@ -555,42 +555,106 @@ __global__ __launch_bounds__(256) void seg_from_float_kernel(const float* __rest
 // scipy.signal.correlate(a, b, "full") then np.argmax).  corr[k] = sum_l a[l + k - (nb - 1)] b[l],
 // k = 0 .. na + nb - 2, summed in fp64 in index order.  One workgroup per pair, both segments in LDS,
 // a thread owns lags k = tid, tid + 256, ...; the first maximum wins, as in np.argmax.
-// Sample = double (host segments, uploaded) or float (device-resident rows, converted exactly on load)
+// Sample = double (host segments, uploaded) or float (device-resident rows, converted exactly on load).
+// A thread owns four ADJACENT lags (k = 4 T .. 4 T + 3) and walks l once for all of them: one LDS read of b[l] and one new
+// a sample per step feed four fused multiply-adds (a register window slides over a).  l runs over a range that is
+// uniform per WAVE (the union of its 256 lags' ranges; a sits in LDS between kXcorrPad zeros on either side, which cover the
+// steps a lane runs beyond its own range and leave its sums unchanged), so the window's address is `uniform + 4 T`: with a
+// stored as four interleaved planes (plane c holds a[4 m + c]) the lanes of a wave read CONSECUTIVE slots of one plane -
+// no bank conflict - and eight steps issue their sixteen reads together.  Every lag's sum is still the fma chain over l in
+// index order, so maxima and their order are those of a one-lag-per-thread form.  The lags of a pair are cut into slices of
+// kXcorrThreads * 4 (grid.y): a workgroup leaves its slice's first maximum, xcorr_reduce_kernel picks the first over slices.
+constexpr int kXcorrThreads = 256;
+constexpr int kXcorrLags = 4;
+constexpr int kXcorrPad = 260;                     // >= 64 lanes * 4 lags + the 3-sample window, a multiple of 4
+__host__ __device__ inline long long xcorr_lds_doubles(long long na, long long nb) {
+  return 4 * ((na + 2 * kXcorrPad + 3) / 4 + 1) + nb;
+}
 template <class Sample>
-__global__ __launch_bounds__(256) void xcorr_argmax_kernel(const Sample* __restrict__ a, const int64_t* __restrict__ a_off,
-                                                           const int64_t* __restrict__ a_len,
-                                                           const Sample* __restrict__ b, const int64_t* __restrict__ b_off,
-                                                           const int64_t* __restrict__ b_len,
-                                                           long long* __restrict__ arg_out, double* __restrict__ val_out) {
+__global__ __launch_bounds__(kXcorrThreads) void xcorr_argmax_kernel(const Sample* __restrict__ a, const int64_t* __restrict__ a_off,
+                                                                     const int64_t* __restrict__ a_len,
+                                                                     const Sample* __restrict__ b, const int64_t* __restrict__ b_off,
+                                                                     const int64_t* __restrict__ b_len,
+                                                                     long long* __restrict__ part_k, double* __restrict__ part_val) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* sa = reinterpret_cast<double*>(smem_raw);
+  double* plane = reinterpret_cast<double*>(smem_raw);
   const int p = blockIdx.x;
   const int na = (int)a_len[p], nb = (int)b_len[p];
-  double* sb = sa + na;
-  for (int i = threadIdx.x; i < na; i += blockDim.x) sa[i] = (double)a[a_off[p] + i];
+  const int P = (na + 2 * kXcorrPad + 3) / 4 + 1;      // slots per plane
+  double* sb = plane + 4 * P;
+  for (int i = threadIdx.x; i < 4 * P; i += blockDim.x) {     // i' = 4 m + c <-> a[i' - pad], zero outside
+    const int c = i / P, m = i - c * P, src = 4 * m + c - kXcorrPad;
+    plane[i] = (src >= 0 && src < na) ? (double)a[a_off[p] + src] : 0.0;
+  }
   for (int i = threadIdx.x; i < nb; i += blockDim.x) sb[i] = (double)b[b_off[p] + i];
   __syncthreads();
   double best = -__builtin_huge_val();
   int best_k = 0x7fffffff;
   const int nk = na + nb - 1;
-  for (int k = threadIdx.x; k < nk; k += blockDim.x) {
-    const int sh = k - (nb - 1);                   // a index = l + sh
-    const int lo = sh < 0 ? -sh : 0;
-    const int hi = (na - sh < nb) ? (na - sh) : nb;
-    double acc = 0.0;
-    for (int l = lo; l < hi; ++l) acc = fma(sa[l + sh], sb[l], acc);
-    if (acc > best) {
-      best = acc;
-      best_k = k;
+  const int T = (int)blockIdx.y * kXcorrThreads + (int)threadIdx.x;           // lags 4 T .. 4 T + 3
+  const int kw = __builtin_amdgcn_readfirstlane(((int)blockIdx.y * kXcorrThreads + ((int)threadIdx.x & ~63)) * kXcorrLags);
+  if (kw < nk) {                                                               // wave-uniform
+    int lo = (nb - 1) - (kw + 64 * kXcorrLags - 1);
+    lo = lo < 0 ? 0 : lo;
+    int hi = na + nb - 1 - kw;
+    hi = hi > nb ? nb : hi;
+    // a index of (l, lag 4 T + r) = l + 4 T + r - (nb - 1); padded: + kXcorrPad.  q = the wave-uniform part.
+    const double* __restrict__ lane = plane + T;
+    auto win = [&](int q) { return lane[(q & 3) * P + (q >> 2)]; };            // q + 4 T >= 0 inside the padded range
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int l = lo;
+    int q0 = l - (nb - 1) + kXcorrPad;
+    double w0 = win(q0), w1 = win(q0 + 1), w2 = win(q0 + 2);
+    constexpr int U = 8;
+    for (; l + U <= hi; l += U) {
+      double bb[U], ww[U + 3];
+      ww[0] = w0;
+      ww[1] = w1;
+      ww[2] = w2;
+      const int q = l - (nb - 1) + kXcorrPad + 3;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        bb[u] = sb[l + u];
+        ww[u + 3] = win(q + u);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        acc0 = fma(ww[u], bb[u], acc0);
+        acc1 = fma(ww[u + 1], bb[u], acc1);
+        acc2 = fma(ww[u + 2], bb[u], acc2);
+        acc3 = fma(ww[u + 3], bb[u], acc3);
+      }
+      w0 = ww[U];
+      w1 = ww[U + 1];
+      w2 = ww[U + 2];
     }
+    for (; l < hi; ++l) {
+      const double w3 = win(l - (nb - 1) + kXcorrPad + 3);
+      const double bv = sb[l];
+      acc0 = fma(w0, bv, acc0);
+      acc1 = fma(w1, bv, acc1);
+      acc2 = fma(w2, bv, acc2);
+      acc3 = fma(w3, bv, acc3);
+      w0 = w1;
+      w1 = w2;
+      w2 = w3;
+    }
+    const int k0 = T * kXcorrLags;
+    const double acc[kXcorrLags] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+    for (int r = 0; r < kXcorrLags; ++r)
+      if (k0 + r < nk && acc[r] > best) {            // increasing k: the first maximum stays
+        best = acc[r];
+        best_k = k0 + r;
+      }
   }
   // block argmax, ties to the smaller index
-  __shared__ double rv[256];
-  __shared__ int rk[256];
+  __shared__ double rv[kXcorrThreads];
+  __shared__ int rk[kXcorrThreads];
   rv[threadIdx.x] = best;
   rk[threadIdx.x] = best_k;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = kXcorrThreads / 2; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
       const double ov = rv[threadIdx.x + s];
       const int ok = rk[threadIdx.x + s];
@@ -602,9 +666,27 @@ __global__ __launch_bounds__(256) void xcorr_argmax_kernel(const Sample* __restr
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    arg_out[p] = rk[0];
-    val_out[p] = rv[0];
+    part_k[(long long)p * gridDim.y + blockIdx.y] = rk[0];
+    part_val[(long long)p * gridDim.y + blockIdx.y] = rv[0];
   }
+}
+
+// the first maximum over a pair's lag slices (slices are in lag order: a later slice wins only with a larger value)
+__global__ __launch_bounds__(64) void xcorr_reduce_kernel(const long long* __restrict__ part_k, const double* __restrict__ part_val, int slices,
+                                                          int n_pairs, long long* __restrict__ arg_out, double* __restrict__ val_out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  double best = part_val[(long long)p * slices];
+  long long k = part_k[(long long)p * slices];
+  for (int y = 1; y < slices; ++y) {
+    const double v = part_val[(long long)p * slices + y];
+    if (v > best) {
+      best = v;
+      k = part_k[(long long)p * slices + y];
+    }
+  }
+  arg_out[p] = k;
+  if (val_out) val_out[p] = best;
 }
 
 // ---------------------------------------------------------------------------------------------

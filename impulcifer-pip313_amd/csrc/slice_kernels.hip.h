@@ -311,6 +311,7 @@ __global__ __launch_bounds__(64) void slice_align_onset_kernel(const RowPeak* __
                                                                const int64_t* __restrict__ len1, const float* __restrict__ x,
                                                                const int64_t* __restrict__ off2, const int* __restrict__ leader, int ref_pair,
                                                                int rows_per_meas, int n_meas, long long* __restrict__ s2,
+                                                               long long shifted_base, long long shifted_pitch, int64_t* __restrict__ off_al,
                                                                SliceRowOut* __restrict__ rows, int* __restrict__ meas_flags) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n_meas) return;
@@ -336,6 +337,8 @@ __global__ __launch_bounds__(64) void slice_align_onset_kernel(const RowPeak* __
     for (int e = 0; e < 2; ++e) {
       const int b = r0 + 2 * q + e;
       s2[b] = sh;
+      // a row neither alignment moved stays where crop_heads left it; the others are materialised (shift_rows_kernel)
+      off_al[b] = (d1[b] == 0 && sh == 0) ? off2[b] : shifted_base + (long long)b * shifted_pitch;
       rows[b].shift_ipsilateral = d1[b];
       rows[b].shift_onset = sh;
     }
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(256) void shift_rows_kernel(const float* __restrict
   const int b = blockIdx.y;
   const long long n = len[b];
   const long long a = d1 ? d1[b] : 0, s = s2[b];
+  if (d1 && a == 0 && s == 0) return;           // (the slice: an unmoved row is read where it is)
   const float* __restrict__ in = src + src_off[b];
   float* __restrict__ out = dst + dst_off[b];
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {

@@ -259,6 +259,15 @@ def test_resident_slice_full_size(config):
     assert set(rows["decay_state"]) <= {1, 2, 3} and np.count_nonzero(rows["decay_state"] == 1) >= 4      # adjusted / already faster
     for m in range(2):
         assert_same_as_staged(got[m], staged_measurement(e, [(meas[m][0], spk)], firs, decay=0.3))
+    # ... and with the two alignments of the reference's flow between crop_heads and crop_tails as well
+    rs.set_alignment(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = rs.run(meas[:2])
+    rows, res = rs.slice.results()
+    assert np.all(res["flags"] & 256 == 0), res["flags"]
+    for m in range(2):
+        assert_same_as_staged(got[m], staged_measurement(e, [(meas[m][0], spk)], firs, decay=0.3, align=True))
     rs.close()
 
 
