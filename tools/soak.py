@@ -95,6 +95,7 @@ def main():
         sl.results()
         # the decay stage's tables, the float64 pack and a page-locked result block: made, used and released per iteration
         sl.set_decay([0.3, np.nan, 0.3, 0.3])
+        sl.set_alignment([(0, 1)], [-1, 0], 0, 1440)
         sl.execute_device(d_rec, pcm.size, 2, d_out, sl.out_len_max)
         d_packed = ctx.malloc(2 * 4 * sl.out_len_max * 8)
         sl.pack_f64(d_out, sl.out_len_max, 2, d_packed, 4 * sl.out_len_max)
