@@ -85,6 +85,28 @@ class Layout:
         return out
 
 
+ONSET_GROUPS = [("FL", "FR"), ("SL", "SR"), ("BL", "BR"), ("WL", "WR"), ("TFL", "TFR"), ("TSL", "TSR"), ("TBL", "TBR"), ("FC",)]
+
+
+def alignment_tables(speakers):
+    """The two alignments of core/hrir.py:921-1001 as tables over the ear pairs of a layout (pair q = speakers[q]):
+    (ipsilateral pairs [(q1, q2)] of IPSILATERAL_PAIRS whose speakers are both present, leader_of_pair[q] = the pair whose
+    left ear gives the onset group of q its peak - or -1: the reference group FL/FR, speakers in no group, groups whose
+    FIRST speaker is absent (the reference skips those) -, FL's pair).  Raises as the reference does without FL."""
+    idx = {sp: q for q, sp in enumerate(speakers)}
+    if "FL" not in idx:
+        raise RuntimeError("Cannot find FL left channel reference for onset alignment.")
+    ipsi = [(idx[a], idx[b]) for a, b in IPSILATERAL_PAIRS if a in idx and b in idx]
+    leader = [-1] * len(speakers)
+    for group in ONSET_GROUPS:
+        if group == ("FL", "FR") or group[0] not in idx:
+            continue
+        for sp in group:
+            if sp in idx:
+                leader[idx[sp]] = idx[group[0]]
+    return ipsi, leader, idx["FL"]
+
+
 class ResidentSlice:
     """ingest -> crop_heads -> crop_tails -> equalize -> normalize for up to `max_measurements` measurements of one
     layout per call.  FIRs are per job (set_firs); results are HRIR objects whose responses are device rows."""
@@ -133,8 +155,6 @@ class ResidentSlice:
         if self.align:
             self.set_alignment(True)
 
-    ONSET_GROUPS = [("FL", "FR"), ("SL", "SR"), ("BL", "BR"), ("WL", "WR"), ("TFL", "TFR"), ("TSL", "TSR"), ("TBL", "TBR"), ("FC",)]
-
     def set_alignment(self, on=True):
         """the alignments `_stage_crop_and_align` runs between crop_heads and crop_tails (core/pipeline.py:593-597):
         align_ipsilateral_all over IPSILATERAL_PAIRS with 30 ms segments, then align_onset_groups_peak_leftref - lag searches,
@@ -143,18 +163,8 @@ class ResidentSlice:
         if not on:
             self.slice.set_alignment(None, None, 0, 0)
             return
-        idx = {sp: q for q, sp in enumerate(self.layout.speakers)}
-        if "FL" not in idx:
-            raise RuntimeError("Cannot find FL left channel reference for onset alignment.")
-        ipsi = [(idx[a], idx[b]) for a, b in IPSILATERAL_PAIRS if a in idx and b in idx]
-        leader = [-1] * len(self.layout.speakers)
-        for group in self.ONSET_GROUPS:
-            if group == ("FL", "FR") or group[0] not in idx:
-                continue
-            for sp in group:
-                if sp in idx:
-                    leader[idx[sp]] = idx[group[0]]
-        self.slice.set_alignment(ipsi, leader, idx["FL"], int(self.fs * 30 / 1000))
+        ipsi, leader, ref = alignment_tables(self.layout.speakers)
+        self.slice.set_alignment(ipsi, leader, ref, int(self.fs * 30 / 1000))
 
     def set_decay(self, decay):
         """the optional stage between equalize and normalize (core/pipeline.py:694-716): decay = None (off), a target RT60

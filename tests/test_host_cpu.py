@@ -559,3 +559,20 @@ def test_device_shards_partition_and_result_order():
     finally:
         os.environ.clear()
         os.environ.update(env)
+
+
+def test_alignment_tables_of_a_layout():
+    """The pair tables imp_slice_set_alignment takes, from a layout's speakers: core/hrir.py:921-1001's rules - a pair of
+    IPSILATERAL_PAIRS counts when both speakers are present, an onset group follows its FIRST speaker's left ear and is
+    skipped when that speaker is absent, FL/FR is the reference, FL must be there."""
+    from impulse_hip.resident_slice import alignment_tables
+    spk = ["FL", "FR", "FC", "BL", "BR", "SL", "SR", "WL"]
+    ipsi, leader, ref = alignment_tables(spk)
+    assert ref == 0
+    assert ipsi == [(0, 1), (5, 6), (3, 4), (2, 2)]                   # FL-FR, SL-SR, BL-BR, FC-FC; WL-WR lacks WR
+    assert leader == [-1, -1, 2, 3, 3, 5, 5, 7]                       # FC and WL lead themselves, BR follows BL, SR follows SL
+    ipsi, leader, ref = alignment_tables(["FR", "FL", "SR", "WR", "TBL", "TBR"])
+    assert ref == 1 and ipsi == [(1, 0), (4, 5)]
+    assert leader == [-1, -1, -1, -1, 4, 4]                           # SR / WR: their groups' first speakers are absent
+    with pytest.raises(RuntimeError):
+        alignment_tables(["FR", "FC"])

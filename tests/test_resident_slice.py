@@ -418,6 +418,97 @@ def test_resident_slice_alignment_stage():
     rs.close()
 
 
+def test_alignment_guard_flags_take_the_staged_path():
+    """A delayed row whose first sample is not zero (no head fade: head_ms = 0) could gain a first peak from its new zero
+    neighbour: the device flags the measurement (IMP_SLICE_ALIGN_GUARD) instead of assuming peak_index(shifted) = shift +
+    peak_index, and the staged path (which searches the materialised rows) gives the result."""
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.resident_slice import Layout, ResidentSlice, _fir_taps
+    from impulse_hip import _native
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=fs)
+    spk = ["FL", "FR", "SL", "SR"]
+    meas = [[synth_frames(e, spk, 1300 + m)] for m in range(2)]
+    layout = Layout(e, [(meas[0][0].shape[0], 2, spk)])
+    firs = synth_firs(layout.tasks, _fir_taps(fs), 3)
+    rs = ResidentSlice(e, layout, max_measurements=2, head_ms=0)
+    rs.set_firs(firs)
+    rs.set_alignment(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = rs.run(meas)
+    rows, res = rs.slice.results()
+    assert np.any(rows["shift_ipsilateral"] > 0)
+    assert np.all(res["flags"] & _native.SLICE_ALIGN_GUARD), res["flags"]
+    assert rs.stats["staged"] == 2
+    from impulse_hip.pipeline_slice import run_slice
+    for m in range(2):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = run_slice(e, [((fs, meas[m][0]), spk)], firs=firs, head_ms=0, align=True)
+        assert_same_as_staged(got[m], want)
+    rs.close()
+    # a speaker in two ipsilateral pairs is refused (the searches of a measurement run as one batch)
+    rs = ResidentSlice(e, layout, max_measurements=1)
+    with pytest.raises(_native.NativeError):
+        rs.slice.set_alignment([(0, 1), (1, 2)], [-1, -1, -1, -1], 0, 1440)
+    with pytest.raises(_native.NativeError):
+        rs.slice.set_alignment([(0, 1)], [-1, -1, -1, -1], 0, 9000)        # two segments must fit the lag search's LDS
+    rs.close()
+
+
+def test_shift_and_lag_search_of_device_rows_edge_cases():
+    """imp_shift_rows_device against ImpulseResponse.shift's NumPy form (core/impulse_response.py:92-108) for delays and
+    advances up to and beyond the row length and empty rows; imp_xcorr_argmax_device against imp_xcorr_argmax on the rows'
+    float64 copies for equal and unequal segment lengths, the 30 ms segments of 48 - 192 kHz and lag slices that end inside
+    a wave."""
+    from impulse_hip import _native
+    ctx = _native.default_context()
+    rng = np.random.default_rng(5)
+    lens = np.array([1, 2, 63, 64, 65, 1000, 4097, 0, 777], dtype=np.int64)
+    shifts = np.array([0, 1, -1, 70, -64, 999, -5000, 3, -776], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens + 5)[:-1]]).astype(np.int64)
+    flat = rng.standard_normal(int(offs[-1] + lens[-1] + 5)).astype(np.float32)
+    d_src, d_dst = ctx.malloc(flat.nbytes), ctx.malloc(flat.nbytes)
+    ctx.h2d(d_src, flat)
+    ctx.memset(d_dst, 0xFF, flat.nbytes)
+    ctx.shift_rows_device(d_src, offs, lens, shifts, d_dst, offs)
+    out = np.empty_like(flat)
+    ctx.synchronize()
+    ctx.d2h(out, d_dst)
+    for o, n, sh in zip(offs, lens, shifts):
+        x = flat[o:o + n].astype(np.float64)
+        if sh > 0:
+            want = np.concatenate((np.zeros(sh), x))[:n]
+        elif sh < 0:
+            t = x[-sh:]
+            want = np.pad(t, (0, n - len(t))) if len(t) < n else t
+        else:
+            want = x
+        assert np.array_equal(out[o:o + n].astype(np.float64), want), (int(n), int(sh))
+    ctx.free(d_dst)
+    # lag searches
+    segs = [(1440, 1440), (5760, 5760), (1, 1), (7, 300), (300, 7), (1025, 1024), (255, 257), (2880, 2880), (64, 64)]
+    a_len = np.array([p[0] for p in segs], dtype=np.int64)
+    b_len = np.array([p[1] for p in segs], dtype=np.int64)
+    a_off = np.concatenate([[0], np.cumsum(a_len)[:-1]]).astype(np.int64)
+    b_off = (a_off[-1] + a_len[-1] + np.concatenate([[0], np.cumsum(b_len)[:-1]])).astype(np.int64)
+    rows = (rng.standard_normal(int(b_off[-1] + b_len[-1])) * np.exp(-np.arange(int(b_off[-1] + b_len[-1])) % 997 / 200.0)).astype(np.float32)
+    d_rows = ctx.malloc(rows.nbytes)
+    ctx.h2d(d_rows, rows)
+    arg, val = ctx.xcorr_argmax_device(d_rows, a_off, a_len, b_off, b_len)
+    ctx.free(d_rows)
+    ctx.free(d_src)
+    a64 = [rows[o:o + n].astype(np.float64) for o, n in zip(a_off, a_len)]
+    b64 = [rows[o:o + n].astype(np.float64) for o, n in zip(b_off, b_len)]
+    arg_h, val_h = ctx.xcorr_argmax(a64, b64)
+    assert np.array_equal(arg, arg_h) and np.array_equal(val, val_h)
+    for k, (x, y) in enumerate(zip(a64, b64)):
+        corr = np.correlate(x, y, mode="full")
+        assert int(arg[k]) == int(np.argmax(corr)), k
+        assert abs(val[k] - corr.max()) <= 1e-12 * max(1.0, abs(corr.max())), k
+
+
 def test_decay_times_of_device_rows_have_the_bits_of_their_float64_copies():
     from impulse_hip import _native
     from impulse_hip.decay import decay_params, decay_times

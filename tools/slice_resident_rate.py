@@ -37,9 +37,10 @@ with warnings.catch_warnings():
     t0 = time.perf_counter()
     for _ in range(calls):
         team.step()
+    issued = time.perf_counter() - t0
     team.sync()
     dt = time.perf_counter() - t0
     irs = calls * n_streams * M * team.rows
     print(f"{irs} IRs in {dt * 1e3:.1f} ms = {irs / dt / 1e3:.1f} k IR/s; {dt / (calls * n_streams) * 1e3:.3f} ms per call of {M} measurements; "
-          f"flags {team.flags()}")
+          f"flags {team.flags()}; host thread busy issuing {issued / dt * 100:.0f} % of that ({issued / (calls * n_streams) * 1e3:.3f} ms per call)")
     team.release()
