@@ -1931,9 +1931,7 @@ extern "C" int imp_chain_execute_device(imp_chain* c, const float* d_x, int64_t 
   hipStream_t lane_stream = lane ? c->ctx->side_streams[(size_t)(lane - 1)] : c->ctx->stream;
   hipStream_t tail = c->tail_ctx->stream;
   if (c->ir_busy[(size_t)l] && tail != lane_stream) HIP_TRY(hipStreamWaitEvent(lane_stream, c->ir_free[(size_t)l], 0));
-  // experiment switch: 1 = pass C leaves no chunk maxima, the peak search's first step is a read of the deconvolved rows
-  static const bool no_tile_max = [] { const char* e = std::getenv("IMPULSE_HIP_NO_TILE_MAX"); return e && e[0] == '1'; }();
-  c->deconv->tile_max = no_tile_max ? nullptr : c->d_tile[(size_t)l];
+  c->deconv->tile_max = c->d_tile[(size_t)l];
   rc = imp_conv_execute_device(c->deconv, d_x, c->B, chan_stride_in, elem_stride_in, c->d_ir[(size_t)l], c->pitch_ir);
   c->deconv->tile_max = nullptr;
   if (rc) return rc;
@@ -1942,23 +1940,10 @@ extern "C" int imp_chain_execute_device(imp_chain* c, const float* d_x, int64_t 
     HIP_TRY(hipEventRecord(c->k1_done[(size_t)l], lane_stream));
     HIP_TRY(hipStreamWaitEvent(tail, c->k1_done[(size_t)l], 0));
   }
-  // measurement switch (tools/chain_rate.py): 1 = stop after the peak search, 2 = stop after K1 - the outputs are then stale
-  static const int skip = [] { const char* e = std::getenv("IMPULSE_HIP_CHAIN_SKIP"); return e ? atoi(e) : 0; }();
-  if (skip >= 2) return IMP_OK;
-  if (no_tile_max) {
-    const int64_t kc = std::max<int64_t>(1, (c->deconv->out_len + imp::kPeakChunk - 1) / imp::kPeakChunk);
-    hipLaunchKernelGGL(imp::row_chunk_max_kernel, dim3((unsigned)kc, (unsigned)c->B), dim3(256), 0, tail, c->d_ir[(size_t)l], c->d_meta,
-                       c->d_meta + c->B, (int64_t)0, c->d_tile[(size_t)l], kc);
-    hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)c->B), dim3(imp::kPeakThreads), 0, tail, c->d_ir[(size_t)l],
-                       c->d_meta, c->d_meta + c->B, (int64_t)0, (const unsigned*)nullptr, 0, (const unsigned*)c->d_tile[(size_t)l], kc,
-                       c->d_res[(size_t)l], c->peak_height, d_peaks_out);
-  } else {
-    hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)c->B), dim3(imp::kPeakThreads), 0, tail, c->d_ir[(size_t)l],
-                       c->d_meta, c->d_meta + c->B, c->deconv->out_start, (const unsigned*)c->d_tile[(size_t)l], c->tiles,
-                       (const unsigned*)nullptr, c->chunks, c->d_res[(size_t)l], c->peak_height, d_peaks_out);
-  }
+  hipLaunchKernelGGL(imp::row_first_peak_chunked_kernel, dim3((unsigned)c->B), dim3(imp::kPeakThreads), 0, tail, c->d_ir[(size_t)l],
+                     c->d_meta, c->d_meta + c->B, c->deconv->out_start, (const unsigned*)c->d_tile[(size_t)l], c->tiles,
+                     (const unsigned*)nullptr, c->chunks, c->d_res[(size_t)l], c->peak_height, d_peaks_out);
   HIP_TRY(hipGetLastError());
-  if (skip >= 1) return IMP_OK;
   imp::LoadCropAtPeak ld{c->d_ir[(size_t)l], c->pitch_ir, c->deconv->out_len, c->d_res[(size_t)l], c->n, c->head, c->fade_in, c->fade_out,
                          c->d_win};
   if ((rc = run_group_with(c->fir, ld, c->B, d_out, chan_stride_out, 0, 2))) return rc;
