@@ -507,10 +507,11 @@ class SlicePipeline:
     (_native.PinnedPool) with one linear copy per measurement and builds the HRIR objects.  Hand-overs are host queues
     after synchronous copies / imp_slice_results, so no cross-stream event is needed.  Same surface as SliceRunner."""
 
-    def __init__(self, estimator, layout, depth=3, head_ms=1, peak_target=-0.1, pinned_mb=None, keep_cap=None):
+    def __init__(self, estimator, layout, depth=3, head_ms=1, peak_target=-0.1, pinned_mb=None, keep_cap=None, device=None):
         import queue
         import threading
         self.estimator, self.layout = estimator, layout
+        self.device = _native.default_device() if device is None else int(device)
         self.head_ms, self.peak_target, self.keep_cap = head_ms, peak_target, keep_cap
         self.depth = max(2, int(depth))
         self.pool = _native.PinnedPool(pinned_mb)
@@ -566,7 +567,7 @@ class SlicePipeline:
 
     # ---- stage 1: the link, upward
     def _upload(self):
-        ctx = self.ctxs[1] = _native.Context(_native.default_device())
+        ctx = self.ctxs[1] = _native.Context(self.device)
         item = self.layout.dtype.itemsize
         with _native.using_context(ctx):
             while True:
@@ -610,7 +611,7 @@ class SlicePipeline:
         from .pipeline_slice import run_slice
         est, layout = self.estimator, self.layout
         try:
-            ctx = self.ctxs[0] = _native.Context(_native.default_device())
+            ctx = self.ctxs[0] = _native.Context(self.device)
             with _native.using_context(ctx):
                 rs = self.rs = ResidentSlice(est, layout, max_measurements=1, head_ms=self.head_ms, peak_target=self.peak_target,
                                              keep_cap=self.keep_cap)
@@ -630,7 +631,7 @@ class SlicePipeline:
                     break
                 host = job["to_host"]
                 try:
-                    rs.set_firs(job["firs"])
+                    rs.set_firs(_firs_for(job["firs"], layout, ctx))
                     rs.set_decay(job["decay"])
                     rs.set_alignment(job["align"])
                 except BaseException as exc:               # noqa: BLE001
@@ -696,7 +697,7 @@ class SlicePipeline:
 
     # ---- stage 3: the link, downward
     def _download(self):
-        ctx = self.ctxs[2] = _native.Context(_native.default_device())
+        ctx = self.ctxs[2] = _native.Context(self.device)
         with _native.using_context(ctx):
             while True:
                 t0 = time.perf_counter()
@@ -756,15 +757,73 @@ class SlicePipeline:
         self.pool.close()
 
 
+def _firs_for(firs, layout, ctx):
+    """a job's FIRs for a slice on ctx's device: FIRs a design left on ANOTHER device come as host taps (one readback per job)"""
+    if isinstance(firs, _native.DeviceFirs):
+        return firs if firs.ctx.device == ctx.device else firs.host()
+    if isinstance(firs, dict):
+        rows = [firs[t] for t in layout.tasks]
+        if any(isinstance(r, _native.DeviceFir) and r.batch.ctx.device != ctx.device for r in rows):
+            return {t: np.asarray(r) for t, r in zip(layout.tasks, rows)}
+    return firs
+
+
+class SliceFleet:
+    """Jobs of many measurements over SEVERAL devices from one process: a SlicePipeline per entry of IMPULSE_HIP_DEVICES (its
+    own three streams, its own link), the measurements of a job cut into contiguous blocks - one per device, as
+    sharding.shard_channels cuts channels - and run concurrently; results in job order.  With one device this is one
+    SlicePipeline.  The deconvolution spectrum is prepared once (first device) and peer-copied by the estimator's plan
+    cache; FIRs a design left on the first device reach the others as host taps, once per job."""
+
+    def __init__(self, estimator, layout, devices=None, **kw):
+        self.devices = list(_native.device_list() if devices is None else devices)
+        self.pipes = []
+        try:
+            for d in self.devices:
+                self.pipes.append(SlicePipeline(estimator, layout, device=d, **kw))
+        except BaseException:
+            self.close()
+            raise
+
+    def run(self, measurements, firs, to_host=True, decay=None, align=False):
+        from concurrent.futures import ThreadPoolExecutor
+        from .sharding import shard_channels
+        n = len(measurements)
+        blocks = [(k,) + shard_channels(n, len(self.pipes), k, keep_pairs=False) for k in range(len(self.pipes))]
+        blocks = [(k, lo, hi) for k, lo, hi in blocks if hi > lo]
+        if len(blocks) <= 1:
+            return self.pipes[0].run(measurements, firs, to_host=to_host, decay=decay, align=align) if n else []
+
+        def part(item):
+            k, lo, hi = item
+            return self.pipes[k].run(measurements[lo:hi], firs, to_host=to_host, decay=decay, align=align)
+
+        with ThreadPoolExecutor(max_workers=len(blocks), thread_name_prefix="impulse-fleet") as pool:
+            parts = list(pool.map(part, blocks))
+        return [r for p in parts for r in p]
+
+    def times(self, reset=True):
+        out = {}
+        for p in self.pipes:
+            for k, v in p.times(reset).items():
+                out[k] = out.get(k, 0.0) + v
+        return out
+
+    def close(self):
+        for p in self.pipes:
+            p.close()
+        self.pipes = []
+
+
 class _Skip(Exception):
     """a measurement of a job that has already failed: passed through the stages untouched"""
 
 
 def run_slice_jobs(estimator, layout, measurements, firs, workers=None, head_ms=1, peak_target=-0.1, decay=None, align=False):
-    """one job through a runner made for it (responses on the host): the three-stage SlicePipeline, or with `workers` that
-    many SliceRunner lanes; callers with several jobs keep a runner"""
+    """one job through a runner made for it (responses on the host): a three-stage SlicePipeline per device of
+    IMPULSE_HIP_DEVICES (SliceFleet), or with `workers` that many SliceRunner lanes; callers with several jobs keep a runner"""
     if workers is None:
-        runner = SlicePipeline(estimator, layout, head_ms=head_ms, peak_target=peak_target)
+        runner = SliceFleet(estimator, layout, head_ms=head_ms, peak_target=peak_target)
     else:
         runner = SliceRunner(estimator, layout, workers=workers, head_ms=head_ms, peak_target=peak_target)
     try:

@@ -611,6 +611,52 @@ def test_slice_pipeline_order_regrowth_recycling_and_errors():
         runner.close()
 
 
+def test_slice_fleet_folded_on_one_device():
+    """SliceFleet: a SlicePipeline per entry of the device list, the job's measurements cut into contiguous blocks.  Folded
+    here (two pipelines on device 0, as IMPULSE_HIP_DEVICES=0,0 would give): seven measurements come back in job order, each
+    identical to the staged path, with FIRs that a design left on the device (handed over in place on their own device;
+    the host-taps route for another device is the same call with a device mismatch, covered by _firs_for below)."""
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.resident_slice import Layout, SliceFleet, _firs_for, _fir_taps
+    from impulse_hip import _native
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=fs)
+    spk = ["FL", "FR"]
+    meas = [[synth_frames(e, spk, 1500 + m, rt60=0.18 + 0.01 * m)] for m in range(7)]
+    layout = Layout(e, [(meas[0][0].shape[0], 2, spk)])
+    firs = synth_firs(layout.tasks, _fir_taps(fs), 17)
+    fleet = SliceFleet(e, layout, devices=[0, 0])
+    try:
+        assert len(fleet.pipes) == 2
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = fleet.run(meas, firs, align=True)
+            assert len(got) == 7
+            for m in range(7):
+                assert_same_as_staged(got[m], staged_measurement(e, [(meas[m][0], spk)], firs, align=True))
+            assert fleet.pipes[0].rs.stats["measurements"] == 4 and fleet.pipes[1].rs.stats["measurements"] == 3
+            one = fleet.run(meas[:1], firs)                       # fewer measurements than devices: one pipeline takes them
+            assert_same_as_staged(one[0], staged_measurement(e, [(meas[0][0], spk)], firs))
+    finally:
+        fleet.close()
+    # FIRs designed on one device, a slice on another: host taps, the same numbers
+
+    class OtherDevice:
+        device = 1
+    ctx = _native.default_context()
+    mat = np.stack([firs[t] for t in layout.tasks])
+    d = ctx.malloc(mat.nbytes)
+    ctx.h2d(d, mat)
+    batch = _native.DeviceFirs(ctx, d, mat.shape[0], mat.shape[1])
+    same = _firs_for(batch, layout, ctx)
+    assert same is batch
+    moved = _firs_for(batch, layout, OtherDevice())
+    assert isinstance(moved, np.ndarray) and np.array_equal(moved, mat)
+    moved = _firs_for({t: r for t, r in zip(layout.tasks, batch.rows())}, layout, OtherDevice())
+    assert all(np.array_equal(moved[t], firs[t]) for t in layout.tasks)
+    batch.close()
+
+
 def test_firs_left_on_the_device_are_the_same_firs():
     """process_equalization_batch(on_device=True) leaves the minimum-phase FIRs on the device (core/pipeline.py:690-691 hands
     every FIR straight to ImpulseResponse.equalize: they never need to visit the host): the rows are the host version's bits,
