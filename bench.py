@@ -73,7 +73,8 @@ DEFAULT_BLOCKS = {"c2": 320, "c3": 96, "c4": 12, "c5": 12}
 # x 13-channel groups 194 k IR/s K1 and 154 k chain, 3 x 13: 197 k / 135 k, 3 x 26: 160 k / 135 k; C5, tools/c5_group_sweep.sh:
 # 8-channel groups x 2 streams 138 k IR/s, x 3: 130 k, x 1: 111 k, x 4: 119 k; groups of 4 / 6 / 12 / 16 / 32 at their best
 # 131 / 132 / 129 / 126 / 123 k - three 6.3 MB workspaces per channel in flight no longer fit beside inputs and outputs)
-CHAINS = {"c2": 3, "c3": 2, "c4": 2, "c5": 2}
+# (round 4, C3 with the pair plan, 26-channel calls: 1 / 2 / 3 / 4 chains = 111 / 118 / 123 / 111 k IR/s chain, 156 / 177 / 183 / 151 k K1)
+CHAINS = {"c2": 3, "c3": 3, "c4": 2, "c5": 2}
 # K1's plan kind of the headline legs: pair mode (two ears per complex transform: what the classes take for ear pairs) where the
 # one-channel-per-transform plan's even/odd unpack costs accuracy on the un-cropped column (C3: 4.1e-6 against 2.3e-6, C5:
 # 3.7e-6 against 3.0e-6); at C2 both kinds sit inside the fp32 floor and the mono plan is 4 % faster.
