@@ -352,6 +352,7 @@ class SliceRunner:
         self.lanes = []
         self._job = None
         self._lock = threading.Lock()
+        self._run_lock = threading.Lock()
         self.pool = _native.PinnedPool(pinned_mb)
         for k in range(max(1, int(workers))):
             ln = dict(todo=queue.Queue(), done=queue.Queue(), ready=threading.Event(), error=None, times={})
@@ -470,9 +471,10 @@ class SliceRunner:
         False = left on the device.  decay: as ResidentSlice.set_decay; align: as ResidentSlice.set_alignment."""
         job = dict(measurements=measurements, firs=firs, to_host=to_host, decay=decay, align=align, next=0, out=[None] * len(measurements))
         lanes = self.lanes[:max(1, min(len(self.lanes), len(measurements)))]
-        for ln in lanes:
-            ln["todo"].put(job)
-        errors = [e for e in (ln["done"].get() for ln in lanes) if e is not None]
+        with self._run_lock:                               # one job at a time: the lanes' completion markers carry no job identity
+            for ln in lanes:
+                ln["todo"].put(job)
+            errors = [e for e in (ln["done"].get() for ln in lanes) if e is not None]
         if errors:
             raise errors[0]
         return job["out"]
@@ -518,7 +520,7 @@ class SlicePipeline:
         self._q = queue
         self.free_rec, self.uploaded, self.free_packed, self.packed = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
         self.jobs = [queue.Queue() for _ in range(2)]       # compute, upload; the download stage takes its jobs from the items
-        self.done = queue.Queue()
+        self._submit = threading.Lock()
         self._times = {}
         self._tlock = threading.Lock()
         self.state = dict(error=None, ready=threading.Event())
@@ -727,7 +729,7 @@ class SlicePipeline:
                 self._add(download_stall=t1 - t0, to_host=t2 - t1, collect=time.perf_counter() - t2)
                 job["left"] -= 1
                 if job["left"] == 0:
-                    self.done.put(job)
+                    job["done"].set()
         ctx.close()
 
     def run(self, measurements, firs, to_host=True, decay=None, align=False):
@@ -735,11 +737,13 @@ class SlicePipeline:
         as SliceRunner.run"""
         if not len(measurements):
             return []
-        job = dict(measurements=measurements, firs=firs, to_host=to_host, decay=decay, align=align, out=[None] * len(measurements), left=len(measurements),
-                   error=None)
-        for q in self.jobs:
-            q.put(job)
-        self.done.get()
+        import threading
+        job = dict(measurements=measurements, firs=firs, to_host=to_host, decay=decay, align=align, out=[None] * len(measurements),
+                   left=len(measurements), error=None, done=threading.Event())
+        with self._submit:                                 # jobs of concurrent callers enter both stage queues in one order
+            for q in self.jobs:
+                q.put(job)
+        job["done"].wait()
         if job["error"] is not None:
             raise job["error"]
         return job["out"]

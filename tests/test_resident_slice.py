@@ -607,6 +607,14 @@ def test_slice_pipeline_order_regrowth_recycling_and_errors():
             for m in range(3):
                 assert on_dev[m][0].irs["FL"]["left"]._data is None
                 assert_same_as_staged(on_dev[m], want[m])
+            # two callers at once: each gets its own job's results, complete and in order
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=2) as tp:
+                fa, fb = tp.submit(runner.run, meas[:4], firs), tp.submit(runner.run, meas[2:], firs)
+                ra, rb = fa.result(), fb.result()
+            for m in range(4):
+                assert_same_as_staged(ra[m], want[m])
+                assert_same_as_staged(rb[m], want[2 + m])
     finally:
         runner.close()
 
