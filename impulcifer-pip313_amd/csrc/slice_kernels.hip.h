@@ -278,7 +278,8 @@ __global__ __launch_bounds__(64) void slice_align_jobs_kernel(const int64_t* __r
 __global__ __launch_bounds__(64) void slice_align_delays_kernel(const long long* __restrict__ arg, const int64_t* __restrict__ a_len,
                                                                 const int* __restrict__ ipsi_a, const int* __restrict__ ipsi_b, int n_ipsi,
                                                                 int rows_per_meas, int n_meas, const int64_t* __restrict__ len2,
-                                                                long long* __restrict__ d1, int64_t* __restrict__ len1) {
+                                                                const int* __restrict__ leads, long long* __restrict__ d1,
+                                                                int64_t* __restrict__ len1) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n_meas) return;
   const int r0 = m * rows_per_meas;
@@ -298,9 +299,10 @@ __global__ __launch_bounds__(64) void slice_align_delays_kernel(const long long*
       d1[r0 + 2 * qa + 1] = -lag;
     }
   }
+  // only the left rows of the onset leaders (and of the reference) are searched for a peak: the others get length 0
   for (int r = 0; r < rows_per_meas; ++r) {
     const long long n = len2[r0 + r] - d1[r0 + r];
-    len1[r0 + r] = n > 0 ? n : 0;
+    len1[r0 + r] = ((r & 1) == 0 && leads[r >> 1] && n > 0) ? n : 0;
   }
 }
 
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(64) void slice_align_onset_kernel(const RowPeak* __
     const int b = r0 + 2 * q;
     const RowPeak rp = res1[b];
     long long pk;
-    if (len1[b] == 0 || !(__uint_as_float(rp.maxabs_bits) >= 1e-20f)) {
+    if (len1[b] == 0 || !(__uint_as_float(rp.maxabs_bits) >= 1e-20f)) {          // (a leader's len1 is 0 only if the delay emptied it)
       pk = 0;
       if (d1[b] > 0) flags |= SLICE_ALIGN_GUARD;            // an all-zero row: its peak index does not move with the zeros
     } else {
