@@ -266,9 +266,10 @@ __global__ __launch_bounds__(64) void slice_align_jobs_kernel(const int64_t* __r
   const long long na = len2[ra] < segment ? len2[ra] : segment, nb = len2[rb] < segment ? len2[rb] : segment;
   // scipy raises on an empty segment, and lags[argmax] is indexed with len(a) only: unequal segments go to the host flow
   if (na < 1 || nb < 1 || na != nb) atomicOr(&meas_flags[m], SLICE_ALIGN_GUARD);
-  a_off[j] = off2[ra];
+  // (an empty row has no sample to read: its job looks at the block's first sample instead; the measurement is flagged)
+  a_off[j] = na < 1 ? 0 : off2[ra];
   a_len[j] = na < 1 ? 1 : na;
-  b_off[j] = off2[rb];
+  b_off[j] = nb < 1 ? 0 : off2[rb];
   b_len[j] = nb < 1 ? 1 : nb;
 }
 
