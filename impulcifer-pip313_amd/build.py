@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libimpulse_hip.so")
 SOURCES = ["impulse_hip.hip", "minphase.hip", "curves.hip", "comm.hip"]
-HEADERS = ["conv_kernels.hip.h", "xcd_kernels.hip.h", "fft_regs.hip.h", "ir_kernels.hip.h", "decay_kernels.hip.h",
+HEADERS = ["conv_kernels.hip.h", "fft_regs.hip.h", "ir_kernels.hip.h", "decay_kernels.hip.h",
            "slice_kernels.hip.h", "slice_host.hip.inc", "fft64.hip.h", "internal.h",
            os.path.join("..", "..", "include", "impulse_hip.h")]
 

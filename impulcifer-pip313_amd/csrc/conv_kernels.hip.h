@@ -896,8 +896,7 @@ __device__ __forceinline__ void rows_core(cf (&v)[16], cf* lds, const int half, 
 }
 
 // One row pair: workspace slot ws_b, spectrum of channel `chan`; 512 threads, 68 KiB of LDS at `lds`.  WS_AUX / AB_AUX: cache policy of
-// the workspace loads and of the alpha/beta loads (the three-launch path uses the defaults; the XCD-resident path reads
-// the workspace with sc1 because other CUs of the XCD wrote it, and streams alpha/beta with nt).
+// the workspace loads and of the alpha/beta loads (the launches use the defaults).
 template <int WS_AUX, int AB_AUX>
 __device__ __forceinline__ void rows_pair(const RowsArgs& args, const Twiddles& tw, int ws_b, int chan, int pair, cf* lds,
                                           const int tid) {

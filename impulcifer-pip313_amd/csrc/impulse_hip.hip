@@ -20,9 +20,6 @@
 
 #include "internal.h"
 #include "conv_kernels.hip.h"
-#ifdef IMP_XCD_RESIDENT          // the XCD-resident K1 experiment (measured slower): not in the default build
-#include "xcd_kernels.hip.h"
-#endif
 #include "ir_kernels.hip.h"
 #include "decay_kernels.hip.h"      // it switches fp contraction off for what follows
 #include "slice_kernels.hip.h"
@@ -237,7 +234,6 @@ extern "C" int imp_ctx_set_stream(imp_ctx* ctx, void* hip_stream) {
   return IMP_OK;
 }
 
-static int resident_check(imp_plan* p);      // defined with the plan
 static void pool_release(imp_ctx* ctx);      // defined with imp_malloc
 
 extern "C" int imp_ctx_synchronize(imp_ctx* ctx) {
@@ -247,8 +243,6 @@ extern "C" int imp_ctx_synchronize(imp_ctx* ctx) {
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   for (auto st : ctx->side_streams) HIP_TRY(hipStreamSynchronize(st));
-  for (imp_plan* p : ctx->resident_plans)
-    if ((rc = resident_check(p))) return rc;
   return IMP_OK;
 }
 
@@ -524,22 +518,6 @@ struct imp_plan {
   float* d_in = nullptr;
   float* d_out = nullptr;
   size_t d_in_bytes = 0, d_out_bytes = 0;
-  // XCD-resident path (xcd_kernels.hip.h)
-  int xF = 0, xR2 = 0;               // column-tile shape of the persistent kernel; 0 = plan does not qualify
-  bool resident = false;
-  cf* xws = nullptr;                 // [8][N1][4096]
-  cf* xP = nullptr;                  // digit twiddles
-  cf* xQ = nullptr;
-#ifdef IMP_XCD_RESIDENT
-  imp::XcdCtl* xctl = nullptr;       // two control blocks, used alternately
-#else
-  void* xctl = nullptr;
-#endif
-  unsigned* xsticky = nullptr;       // [0] sticky abort
-  int xparity = 0;
-  int64_t xlaunches = 0;
-  int x_cus = 0;
-  int64_t xunchecked = 0;            // resident launches since the abort word was last read
   // set by imp_chain around a launch: pass C also leaves K3's chunk maxima (ir_kernels.hip.h StoreRealCropMax)
   unsigned* tile_max = nullptr;     // [channels][column tiles][N1]
   // timing
@@ -813,12 +791,6 @@ extern "C" void imp_plan_destroy(imp_plan* p) {
   if (p->ws) (void)hipFree(p->ws);
   if (p->d_in) (void)hipFree(p->d_in);
   if (p->d_out) (void)hipFree(p->d_out);
-  p->ctx->resident_plans.erase(p);
-  if (p->xws) (void)hipFree(p->xws);
-  if (p->xP) (void)hipFree(p->xP);
-  if (p->xQ) (void)hipFree(p->xQ);
-  if (p->xctl) (void)hipFree(p->xctl);
-  if (p->xsticky) (void)hipFree(p->xsticky);
   for (auto ev : p->events) (void)hipEventDestroy(ev);
   delete p;
 }
@@ -1287,179 +1259,6 @@ static int check_input_span(const imp_plan* p, int64_t elem_stride, size_t sampl
   return IMP_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// XCD-resident path (xcd_kernels.hip.h): one persistent launch per call
-// ------------------------------------------------------------------------------------------------
-static void resident_shape(const imp_plan* p, int* F, int* R2) {
-  *F = *R2 = 0;
-#ifndef IMP_XCD_RESIDENT
-  return;                                   // the persistent kernel is not compiled into this build
-#endif
-  if (p->ola || p->paired || p->fused) return;
-  // one channel's workspace must stay in an XCD's 4 MiB L2 beside the digit twiddles and the row tables
-  if ((int64_t)p->N1 * imp::kN2 * (int64_t)sizeof(cf) > ((int64_t)2600 << 10)) return;
-  switch (p->N1) {
-    case 72: *F = 9; *R2 = 8; break;
-    case 64: *F = 8; *R2 = 8; break;
-    default: break;
-  }
-}
-
-#ifdef IMP_XCD_RESIDENT
-static int resident_alloc(imp_plan* p) {
-  if (p->xws) return IMP_OK;
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, p->ctx->device));
-  if (prop.multiProcessorCount != 256)
-    return fail(IMP_ERR_UNSUPPORTED, "the resident path assumes the whole device (8 XCDs, 256 CUs); this one exposes %d CUs",
-                prop.multiProcessorCount);
-  p->x_cus = prop.multiProcessorCount;
-  const size_t plane = (size_t)p->N1 * imp::kN2;
-  hipError_t e = hipMalloc((void**)&p->xws, (size_t)imp::kXcdMax * plane * sizeof(cf));
-  if (e != hipSuccess) return fail(IMP_ERR_ALLOC, "hipMalloc(resident workspace): %s", hipGetErrorString(e));
-  std::vector<cf> P((size_t)8 * imp::kN2), Q((size_t)(p->N1 / 8) * imp::kN2);
-  for (int64_t d = 0; d < 8; ++d)
-    for (int64_t n2 = 0; n2 < imp::kN2; ++n2) P[(size_t)(d * imp::kN2 + n2)] = unit_root(d * n2, p->Nc);
-  for (int64_t q = 0; q < p->N1 / 8; ++q)
-    for (int64_t n2 = 0; n2 < imp::kN2; ++n2) Q[(size_t)(q * imp::kN2 + n2)] = unit_root(8 * q * n2, p->Nc);
-  int rc;
-  if ((rc = upload_table(&p->xP, P, p->ctx->stream))) return rc;
-  if ((rc = upload_table(&p->xQ, Q, p->ctx->stream))) return rc;
-  HIP_TRY(hipMalloc((void**)&p->xctl, 2 * sizeof(imp::XcdCtl)));
-  HIP_TRY(hipMemsetAsync(p->xctl, 0, 2 * sizeof(imp::XcdCtl), p->ctx->stream));
-  HIP_TRY(hipMalloc((void**)&p->xsticky, 256));
-  HIP_TRY(hipMemsetAsync(p->xsticky, 0, 256, p->ctx->stream));
-  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-  p->ctx->resident_plans.insert(p);
-  return IMP_OK;
-}
-
-#endif
-
-static int resident_check(imp_plan* p) {
-  if (!p->xsticky || p->xunchecked == 0) return IMP_OK;
-  unsigned sticky = 0;
-  HIP_TRY(hipMemcpy(&sticky, p->xsticky, sizeof(unsigned), hipMemcpyDeviceToHost));
-  p->xunchecked = 0;
-  if (sticky) {
-    (void)hipMemset(p->xsticky, 0, sizeof(unsigned));
-    return fail(IMP_ERR_HIP, "a bounded wait of the XCD-resident kernel expired: the outputs of that call are invalid");
-  }
-  return IMP_OK;
-}
-
-#ifdef IMP_XCD_RESIDENT
-template <int F, int R2, class Load>
-static int launch_resident_shape(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64_t chan_stride_out, int64_t first_chan) {
-  using Cfg = imp::XcdCfg<F, R2>;
-  auto kern = imp::xcd_conv_kernel<F, R2, Load>;
-  int rc = ctx_kernel_lds(p->ctx, reinterpret_cast<const void*>(kern), Cfg::lds_bytes);
-  if (rc) return rc;
-  const int64_t plane = (int64_t)p->N1 * imp::kN2;
-  imp::XcdArgs<Load> a;
-  a.ld = ld;
-  a.st = imp::StoreRealCrop{d_y, chan_stride_out, p->out_start, p->out_len};
-  a.ws = p->xws;
-  a.ab = p->ab + (p->n_filters > 1 ? first_chan * plane : 0);
-  a.ab_chan_stride = p->n_filters > 1 ? plane : 0;
-  a.nchan = (int)nchan;
-  a.n1_total = p->N1;
-  a.nx = imp::kXcdMax;
-  a.ctl = p->xctl + p->xparity;
-  a.ctl_next = p->xctl + (1 - p->xparity);
-  a.sticky = p->xsticky;
-  const char* to = std::getenv("IMPULSE_HIP_RESIDENT_TIMEOUT_MS");
-  a.timeout_ticks = (unsigned)std::min<long long>((long long)(to ? std::max(1, atoi(to)) : 250) * 100000ll, 0xFFFFFFFFll);   // 100 MHz ticks
-  imp::Twiddles tw{p->tw.full, p->tw.hi, p->ctx->tw_t1, p->ctx->tw_t2, p->ctx->tw_t4};
-  imp::DigitTwiddles dt{p->xP, p->xQ};
-  static const int wg_per_cu = [] { const char* e = std::getenv("IMPULSE_HIP_RESIDENT_WG_PER_CU"); return e ? std::max(1, std::min(2, atoi(e))) : 2; }();
-  dim3 grid((unsigned)(p->x_cus * wg_per_cu)), block(512);
-  hipLaunchKernelGGL(kern, grid, block, Cfg::lds_bytes, p->ctx->stream, a, tw, dt);
-  HIP_TRY(hipGetLastError());
-  p->xparity ^= 1;
-  ++p->xlaunches;
-  ++p->xunchecked;
-  return IMP_OK;
-}
-
-template <class Load>
-static int run_resident(imp_plan* p, Load ld, int64_t nchan, float* d_y, int64_t chan_stride_out, int64_t first_chan) {
-  if (nchan < 1) return IMP_OK;
-  if (nchan > (1 << 24)) return fail(IMP_ERR_INVALID, "too many channels for one resident launch");
-  if (p->n_filters > 1 && first_chan + nchan > p->n_filters)
-    return fail(IMP_ERR_INVALID, "channel %lld has no filter: the plan holds %lld per-channel filters",
-                (long long)(first_chan + nchan - 1), (long long)p->n_filters);
-  int rc;
-  p->cur_stream = p->ctx->stream;
-  if ((rc = timing_event(p, 0))) return rc;
-  if (p->xF == 9 && p->xR2 == 8) rc = launch_resident_shape<9, 8>(p, ld, nchan, d_y, chan_stride_out, first_chan);
-  else if (p->xF == 8 && p->xR2 == 8) rc = launch_resident_shape<8, 8>(p, ld, nchan, d_y, chan_stride_out, first_chan);
-  else rc = fail(IMP_ERR_UNSUPPORTED, "no resident kernel for %d rows", p->N1);
-  if (rc) return rc;
-  for (int slot = 1; slot <= 3; ++slot)
-    if ((rc = timing_event(p, slot))) return rc;      // the whole launch is reported as "pass A"; B and C read 0
-  return IMP_OK;
-}
-
-#else
-static int resident_alloc(imp_plan*) { return fail(IMP_ERR_UNSUPPORTED, "the XCD-resident kernel is not compiled into this build (-DIMP_XCD_RESIDENT)"); }
-template <class Load>
-static int run_resident(imp_plan*, Load, int64_t, float*, int64_t, int64_t) {
-  return fail(IMP_ERR_UNSUPPORTED, "the XCD-resident kernel is not compiled into this build (-DIMP_XCD_RESIDENT)");
-}
-#endif
-
-extern "C" int imp_plan_set_resident(imp_plan* p, int on, int* available) {
-  if (!p) return fail(IMP_ERR_INVALID, "null plan");
-  IMP_CTX_LOCK(p->ctx);
-  int f = 0, r2 = 0;
-  resident_shape(p, &f, &r2);
-  if (available) *available = f ? 1 : 0;
-  if (!on) {
-    if (!available) p->resident = false;      // with `available` given and on = 0 the call is a pure query
-    return IMP_OK;
-  }
-  if (!f) return fail(IMP_ERR_UNSUPPORTED, "this plan (%d rows%s) does not qualify for the XCD-resident path", p->N1,
-                      p->ola ? ", overlap-add" : "");
-  int rc = ctx_bind(p->ctx);
-  if (rc) return rc;
-  p->xF = f;
-  p->xR2 = r2;
-  if ((rc = resident_alloc(p))) return rc;
-  p->resident = true;
-  return IMP_OK;
-}
-
-extern "C" int imp_plan_resident_status(imp_plan* p, int* aborted, unsigned* xcc_seen, unsigned long long* wait_ticks) {
-  if (!p) return fail(IMP_ERR_INVALID, "null plan");
-  IMP_CTX_LOCK(p->ctx);
-  if (aborted) *aborted = 0;
-  if (xcc_seen) *xcc_seen = 0;
-  if (wait_ticks) *wait_ticks = 0;
-  if (!p->xctl) return IMP_OK;
-#ifdef IMP_XCD_RESIDENT
-  int rc = ctx_bind(p->ctx);
-  if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-  unsigned sticky = 0;
-  HIP_TRY(hipMemcpy(&sticky, p->xsticky, sizeof(unsigned), hipMemcpyDeviceToHost));
-  if (sticky) (void)hipMemset(p->xsticky, 0, sizeof(unsigned));
-  p->xunchecked = 0;
-  imp::XcdCtl last;
-  HIP_TRY(hipMemcpy(&last, p->xctl + (1 - p->xparity), sizeof(last), hipMemcpyDeviceToHost));
-  if (aborted) *aborted = (sticky || last.abort.v) ? 1 : 0;
-  if (xcc_seen) *xcc_seen = last.xcc_seen.v;
-  if (wait_ticks) *wait_ticks = last.wait_ticks.v;
-  if (std::getenv("IMPULSE_HIP_RESIDENT_DIAG")) {
-    static const char* names[8] = {"ticket", "ca_wait", "c_part", "a_part", "ca_drain", "b_wait", "b_work", "b_drain"};
-    for (int k = 0; k < 8; ++k) fprintf(stderr, "  xcd diag %-9s %10.1f us (sum over workgroups)\n", names[k], last.diag[k].v * 0.01);
-    if (last.clk[1].v) fprintf(stderr, "  xcd diag shader clock %.3f GHz (s_memtime / s_memrealtime x 100 MHz)\n",
-                               0.1 * (double)last.clk[0].v / (double)last.clk[1].v);
-  }
-#endif
-  return IMP_OK;
-}
-
 extern "C" int imp_conv_execute_device(imp_plan* p, const float* d_x, int64_t B, int64_t chan_stride_in,
                                        int64_t elem_stride_in, float* d_y, int64_t chan_stride_out) {
   if (!p || !d_x || !d_y) return fail(IMP_ERR_INVALID, "imp_conv_execute_device: null argument");
@@ -1475,8 +1274,6 @@ extern "C" int imp_conv_execute_device(imp_plan* p, const float* d_x, int64_t B,
                 (long long)p->n_filters);
   int rc = ctx_bind(p->ctx);
   if (rc) return rc;
-  if (p->resident)
-    return run_resident(p, imp::LoadRealPacked{d_x, chan_stride_in, elem_stride_in, p->L}, B, d_y, chan_stride_out, 0);
   const int64_t grp = p->ws_channels / p->lanes;
   for (int64_t c0 = 0; c0 < B; c0 += grp) {
     const int64_t n = std::min(grp, B - c0);
@@ -1498,13 +1295,6 @@ extern "C" int imp_conv_execute_device_pcm(imp_plan* p, const void* d_pcm, int b
   if (chan_stride_out < p->out_len) return fail(IMP_ERR_INVALID, "chan_stride_out < out_len");
   int rc = ctx_bind(p->ctx);
   if (rc) return rc;
-  if (p->resident) {
-    if (bits == 32)
-      return run_resident(p, imp::LoadPcmPacked<int32_t>{(const int32_t*)d_pcm, chan_stride_in, elem_stride_in, p->L,
-                                                         1.0f / 2147483648.0f}, B, d_y, chan_stride_out, 0);
-    return run_resident(p, imp::LoadPcmPacked<int16_t>{(const int16_t*)d_pcm, chan_stride_in, elem_stride_in, p->L,
-                                                       1.0f / 32768.0f}, B, d_y, chan_stride_out, 0);
-  }
   const int64_t grp = p->ws_channels / p->lanes;
   for (int64_t c0 = 0; c0 < B && p->paired; c0 += grp) {
     const int64_t n = std::min(grp, B - c0);
@@ -1624,13 +1414,10 @@ extern "C" int imp_conv_execute(imp_plan* p, const float* x, int64_t B, int64_t 
     const int64_t n = std::min(grp, B - c0);
     HIP_TRY(hipMemcpy2DAsync(p->d_in, (size_t)pin * sizeof(float), x + c0 * ld_in, (size_t)ld_in * sizeof(float),
                              (size_t)p->L * sizeof(float), (size_t)n, hipMemcpyHostToDevice, s));
-    if (p->resident) rc = run_resident(p, imp::LoadRealPacked{p->d_in, pin, 1, p->L}, n, p->d_out, pout, c0);
-    else rc = run_group(p, p->d_in, n, pin, 1, p->d_out, pout, c0, 2);
-    if (rc) return rc;
+    if ((rc = run_group(p, p->d_in, n, pin, 1, p->d_out, pout, c0, 2))) return rc;
     HIP_TRY(hipMemcpy2DAsync(y + c0 * ld_out, (size_t)ld_out * sizeof(float), p->d_out, (size_t)pout * sizeof(float),
                              (size_t)p->out_len * sizeof(float), (size_t)n, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (p->resident && (rc = resident_check(p))) return rc;
   }
   return IMP_OK;
 }
@@ -1840,8 +1627,7 @@ extern "C" int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int6
   if (deconv->lanes > 1 && deconv->ctx == fir->ctx)
     return fail(IMP_ERR_INVALID, "imp_chain_create: a deconvolution plan with several lanes needs the FIR plan on a context of its own "
                                  "(its stream carries the peak search and K5 beside the lanes)");
-  if (deconv->ola || fir->ola || deconv->resident || fir->resident)
-    return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: overlap-add and XCD-resident plans cannot be chained");
+  if (deconv->ola || fir->ola) return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: overlap-add plans cannot be chained");
   if (fir->paired) return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: the FIR stage reads one response per transform (mono plan)");
   if (deconv->fused) return fail(IMP_ERR_UNSUPPORTED, "imp_chain_create: a fused FIR plan cannot be the deconvolution stage");
   const int64_t n = fir->L;
@@ -1922,8 +1708,8 @@ extern "C" int imp_chain_execute_device(imp_chain* c, const float* d_x, int64_t 
   ChainLock lk(c->ctx, c->tail_ctx);
   if (chan_stride_out < c->fir->out_len)
     return fail(IMP_ERR_INVALID, "chan_stride_out %lld < out_len %lld", (long long)chan_stride_out, (long long)c->fir->out_len);
-  if (c->deconv->lanes != c->lanes || c->fir->lanes != 1 || c->deconv->resident || c->fir->resident)
-    return fail(IMP_ERR_INVALID, "imp_chain_execute_device: a plan's overlap / resident setting changed since the chain was made");
+  if (c->deconv->lanes != c->lanes || c->fir->lanes != 1)
+    return fail(IMP_ERR_INVALID, "imp_chain_execute_device: a plan's overlap setting changed since the chain was made");
   int rc = ctx_bind(c->ctx);
   if (rc) return rc;
   const int lane = c->lanes > 1 ? (int)(c->deconv->group_counter_lane % c->lanes) : 0;   // the lane run_group will pick

@@ -62,8 +62,6 @@ struct imp_ctx {
   // kernels whose dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) has been made ON THIS DEVICE:
   // the attribute is per device, so it is tracked per context, under the context lock
   std::set<const void*> lds_opt_in;
-  // plans with XCD-resident launches whose abort word has not been looked at since (imp_ctx_synchronize does)
-  std::set<struct imp_plan*> resident_plans;
   // imp_malloc / imp_free: blocks handed back are kept for the next request of about that size (hipFree costs ~0.4 ms
   // and drains the device; the per-measurement row blocks of the slice come and go at fixed sizes)
   std::map<void*, size_t> live_blocks;          // size of every block imp_malloc handed out

@@ -145,8 +145,6 @@ SIGNATURES = {
     "imp_curves_equalization_fir_device": (C.c_int, [_vp, _pd, _i64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                                      C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, _pd, C.POINTER(_vp), _pi64]),
     "imp_slice_set_firs_device": (C.c_int, [_vp, _vp, _i64]),
-    "imp_plan_set_resident": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int)]),
-    "imp_plan_resident_status": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_uint), C.POINTER(C.c_ulonglong)]),
     "imp_plan_set_timing": (C.c_int, [_vp, C.c_int]),
     "imp_plan_get_timing": (C.c_int, [_vp, _pd, _pi64, C.c_int]),
     "imp_debug_plan_geometry": (C.c_int, [_i64, _i64, C.c_int, _pi64, _pi64, _pi64]),
@@ -1266,23 +1264,6 @@ class ConvPlan:
     def set_filters_device(self, d_filt, ld=None):
         """New filters of the same shape from fp64 device memory [n_filters][ld]: no upload, no wait (stream order)."""
         _check(self._lib.imp_plan_set_filters_device(self._h, _vp(int(d_filt)), int(ld or self.M)))
-
-    def resident_available(self):
-        """True if this plan qualifies for the XCD-resident path (one channel's workspace fits an XCD's L2)."""
-        a = C.c_int(0)
-        _check(self._lib.imp_plan_set_resident(self._h, 0, C.byref(a)))
-        return bool(a.value)
-
-    def set_resident(self, on=True):
-        """Route execute_device / execute_device_pcm through the XCD-resident persistent kernel (one launch per call,
-        channel c on XCD c mod 8, workspace kept in that XCD's L2).  Raises NativeError if the plan does not qualify."""
-        _check(self._lib.imp_plan_set_resident(self._h, 1 if on else 0, None))
-
-    def resident_status(self):
-        """Synchronises; (aborted, xcc_seen mask, wait ticks @100 MHz) of the resident launches since the last call."""
-        a, m, w = C.c_int(0), C.c_uint(0), C.c_ulonglong(0)
-        _check(self._lib.imp_plan_resident_status(self._h, C.byref(a), C.byref(m), C.byref(w)))
-        return bool(a.value), int(m.value), int(w.value)
 
     def set_timing(self, every_n):
         """0/False = off; n = bracket the three passes of every n-th launch group with HIP events."""

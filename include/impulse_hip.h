@@ -186,21 +186,6 @@ int imp_plan_set_filters(imp_plan* plan, const double* filter, int64_t filter_ld
  * passed this call (imp_free on the same context's stream is ordered behind it). */
 int imp_plan_set_filters_device(imp_plan* plan, const double* d_filter, int64_t filter_ld);
 
-/* EXPERIMENT, compiled only with -DIMP_XCD_RESIDENT (python build.py --variant xcd IMP_XCD_RESIDENT; measured 163 k against
- * 390 k IR/s): in the default build *available is 0 and enabling it fails with IMP_ERR_UNSUPPORTED.
- * XCD-resident execution (one persistent launch per call instead of three launches per group): available when one
- * channel's workspace (nfft * 4 bytes) fits an XCD's 4 MiB L2 beside the tables, i.e. nfft <= 589 824 (the 7.1 x
- * 6.15 s configuration), on a device that exposes all 8 XCDs.  Channel c is processed on XCD c mod 8 and its
- * workspace never leaves that XCD's L2.  on = 1 enables it for imp_conv_execute_device(_pcm) (launches go to the
- * context stream in order; imp_plan_set_overlap does not apply to them); on = 0 restores the three-launch path.
- * *available (may be NULL) says whether the plan qualifies; enabling an unqualified plan is an error; on = 0 WITH
- * `available` given is a pure query and leaves the setting alone. */
-int imp_plan_set_resident(imp_plan* plan, int on, int* available);
-/* Synchronises and reports the resident launches since the last call: *aborted != 0 if a bounded in-kernel wait
- * expired (the outputs of that call are invalid; imp_ctx_synchronize returns an error too), *xcc_seen = OR of
- * 1 << XCC_ID over the workgroups of the last launch, *wait_ticks = 100 MHz ticks workgroups spent waiting for a
- * phase of their XCD to complete in the last launch.  Any pointer may be NULL. */
-int imp_plan_resident_status(imp_plan* plan, int* aborted, unsigned* xcc_seen, unsigned long long* wait_ticks);
 
 /* per-kernel timing with HIP events on the plan's stream (for bench.py's roofline block):
  * every_n = 0 switches it off, n >= 1 brackets the three passes of every n-th launch group. */
@@ -446,7 +431,7 @@ int imp_magnitude_db_sum_peak_device(imp_ctx* ctx, const float* d_rows, const in
  * imp_chain_execute_device is asynchronous on the context stream; d_out receives B rows of n + K - 1 samples,
  * d_peaks_out (device, may be NULL) the B peak indices.  Seven launches: the deconvolution's last pass also leaves the
  * row maxima the peak search starts from, and the FIR's first pass reads the cropped, faded responses in place.
- * Overlap-add and XCD-resident plans cannot be chained. */
+ * Overlap-add plans cannot be chained. */
 typedef struct imp_chain imp_chain;
 int imp_chain_create(imp_plan* deconv, imp_plan* fir, int64_t B, int64_t head, int64_t fade_in, int64_t fade_out,
                      double peak_height, imp_chain** out);

@@ -1645,68 +1645,6 @@ def test_full_batch_c4_c5_device_resident(gpu_ctx, B):
 
 
 # ------------------------------------------------------------------------------------------------
-# XCD-resident path (csrc/xcd_kernels.hip.h): one persistent launch, channel c on XCD c mod 8, workspace replaced in
-# place inside that XCD's L2.  Optional (measured slower than the three-launch path); parity is held
-# to the same bar.
-# ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("L,M,mode,B,n1", [(420000, 295270, "same", 23, 72), (300000, 400000, "same", 9, 64),
-                                           (300000, 280000, "full", 5, 72), (420000, 295270, "same", 1, 72)])
-def test_xcd_resident_path_matches_oracle_and_three_launch_path(gpu_ctx, L, M, mode, B, n1):
-    from impulse_hip import ConvPlan, NativeError
-    from oracle.scipy_restated import fft_convolve
-    rng = np.random.default_rng(L + M + B)
-    x = rng.standard_normal((B, L)).astype(np.float32)
-    if B > 2:
-        x[2] = 0.0
-    h = rng.standard_normal(M) * np.exp(-np.arange(M) / (M / 5.0))
-    plan = ConvPlan(gpu_ctx, h, L, mode, ws_channels=16)
-    if not plan.resident_available():
-        plan.close()
-        pytest.skip("the XCD-resident experiment is not compiled into the default library (build.py --variant xcd IMP_XCD_RESIDENT)")
-    assert plan.n1 == n1
-    ref3 = plan.execute(x)
-    plan.set_resident(True)
-    y = plan.execute(x)
-    y2 = plan.execute(x)
-    aborted, seen, _ = plan.resident_status()
-    plan.set_resident(False)
-    y3 = plan.execute(x)
-    plan.close()
-    assert not aborted and seen == 0xFF                          # every XCD took part, no bounded wait expired
-    assert np.array_equal(y, y2) and np.array_equal(y3, ref3)    # deterministic; switching back restores the old path
-    if B > 2:
-        assert not np.any(y[2])
-    assert rel(y, ref3.astype(np.float64)) <= 1e-6
-    for b in (0, B - 1):
-        ref = fft_convolve(x[b].astype(np.float64), h, mode)
-        assert rel(y[b], ref) <= TIME_TOL and spec_rel(y[b], ref) <= SPEC_TOL
-    big = ConvPlan(gpu_ctx, np.ones(8), 1 << 20, "same")         # 2^21-point transform: workspace larger than an L2
-    assert not big.resident_available()
-    with pytest.raises(NativeError, match="does not qualify"):
-        big.set_resident(True)
-    big.close()
-
-
-def test_xcd_resident_device_buffers_and_pcm(gpu_ctx):
-    """Device-resident entry points on the resident path: planar fp32 and the WAV wire format (int32 frames)."""
-    from impulse_hip import ConvPlan
-    rng = np.random.default_rng(77)
-    L, M, tracks = 420000, 295270, 2                       # a 72-row plan (the 6.15 s / 391 270 case takes 66 rows)
-    h = rng.standard_normal(M) * np.exp(-np.arange(M) / 60000.0)
-    frames = rng.integers(-2 ** 30, 2 ** 30, size=(L, tracks), dtype=np.int32)
-    plan = ConvPlan(gpu_ctx, h, L, "same", ws_channels=4)
-    if not plan.resident_available():
-        plan.close()
-        pytest.skip("the XCD-resident experiment is not compiled into the default library (build.py --variant xcd IMP_XCD_RESIDENT)")
-    want = plan.execute_pcm_columns(frames, [0])[0]
-    plan.set_resident(True)
-    got = plan.execute_pcm_columns(frames, [0])[0]
-    assert not plan.resident_status()[0]
-    plan.close()
-    assert rel(got, want.astype(np.float64)) <= 1e-6
-
-
-# ------------------------------------------------------------------------------------------------
 # Round-2 fixtures (tests/golden/round2.npz, reference run): class-level entry points that had no test
 # ------------------------------------------------------------------------------------------------
 def test_from_wav_estimators_deconvolve_their_own_sweep(gpu_ctx, golden, tmp_path):
