@@ -107,6 +107,44 @@ def alignment_tables(speakers):
     return ipsi, leader, idx["FL"]
 
 
+class WavMeasurements:
+    """The measurements of a job as WAV files on disk: measurement i = files[i] = [path of file 0, path of file 1, ...] in the
+    order of the layout's files.  A sequence for the job runners (len, [i]): measurement i's PCM blocks are read
+    (`audio_io.read_wav_pcm`: the file's own int16 / int32 frames, no conversion) when a runner's upload stage asks for
+    them - the read of measurement i + 1 overlaps the compute and the download of measurement i - and nothing is kept."""
+
+    def __init__(self, files, fs=None):
+        self.files = [list(f) if isinstance(f, (list, tuple)) else [f] for f in files]
+        self.fs = fs
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return WavMeasurements(self.files[i], self.fs)
+        from .audio_io import read_wav_pcm
+        out = []
+        for path in self.files[i]:
+            got = read_wav_pcm(path)
+            if got is None:
+                raise ValueError(f"{path}: the resident slice takes 16 / 32-bit PCM files (others: HRIR.open_recording)")
+            fs, frames = got
+            if self.fs is not None and fs != self.fs:
+                raise ValueError(f"{path}: sampling rate {fs}, expected {self.fs}")
+            out.append(frames)
+        return out
+
+    def layout(self, estimator, speakers_per_file, silence_length=2.0):
+        """the Layout of these measurements, from the first one's files: speakers_per_file[k] = the speakers recorded in
+        file k (core/hrir.py:307-355's `speakers` argument)"""
+        first = self[0]
+        if len(first) != len(speakers_per_file):
+            raise ValueError("one speaker list per file of a measurement")
+        files = [(fr.shape[0], fr.shape[1], list(sp), silence_length) for fr, sp in zip(first, speakers_per_file)]
+        return Layout(estimator, files, dtype=first[0].dtype)
+
+
 class ResidentSlice:
     """ingest -> crop_heads -> crop_tails -> equalize -> normalize for up to `max_measurements` measurements of one
     layout per call.  FIRs are per job (set_firs); results are HRIR objects whose responses are device rows."""

@@ -712,6 +712,45 @@ def test_slice_fleet_folded_on_one_device():
     batch.close()
 
 
+def test_job_from_wav_files_on_disk(tmp_path):
+    """WavMeasurements: a job whose measurements are PCM WAV files (one binaural file per measurement here); the runner's
+    upload stage reads measurement i + 1 while measurement i computes.  Results = the staged class path opening the same
+    files (HRIR.open_recording), PCM_16 and PCM_32; a float file is refused with the reason."""
+    from impulse_hip.audio_io import write_wav, write_wav_frames
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.pipeline_slice import run_slice
+    from impulse_hip.resident_slice import SlicePipeline, WavMeasurements, _fir_taps
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=fs)
+    spk = ["FL", "FR", "FC"]
+    for bits in (32, 16):
+        paths = []
+        for m in range(4):
+            fr = synth_frames(e, spk, 1700 + m + bits, rt60=0.2 + 0.02 * m)
+            path = str(tmp_path / f"m{bits}_{m}.wav")
+            write_wav_frames(path, fs, fr if bits == 32 else (fr >> 16).astype(np.int16), bits)
+            paths.append([path])
+        job = WavMeasurements(paths, fs=fs)
+        assert len(job) == 4 and len(job[1:]) == 3
+        layout = job.layout(e, [spk])
+        assert layout.dtype == (np.int32 if bits == 32 else np.int16)
+        firs = synth_firs(layout.tasks, _fir_taps(fs), 23)
+        runner = SlicePipeline(e, layout)
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                got = runner.run(job, firs, align=True)
+                for m in range(4):
+                    want = run_slice(e, [(paths[m][0], spk)], firs=firs, align=True)
+                    assert_same_as_staged(got[m], want)
+        finally:
+            runner.close()
+    odd = str(tmp_path / "float.wav")
+    write_wav(odd, fs, np.zeros((2, 1000)), bit_depth=24)
+    with pytest.raises(ValueError, match="PCM"):
+        WavMeasurements([[odd]])[0]
+
+
 def test_firs_left_on_the_device_are_the_same_firs():
     """process_equalization_batch(on_device=True) leaves the minimum-phase FIRs on the device (core/pipeline.py:690-691 hands
     every FIR straight to ImpulseResponse.equalize: they never need to visit the host): the rows are the host version's bits,
