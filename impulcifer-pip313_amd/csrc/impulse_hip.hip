@@ -15,7 +15,6 @@
 #include <mutex>
 #include <new>
 #include <string>
-#include <type_traits>
 #include <vector>
 
 #include "internal.h"

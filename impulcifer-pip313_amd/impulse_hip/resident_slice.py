@@ -32,8 +32,8 @@ class Layout:
         self.estimator = estimator
         self.fs = estimator.fs
         self.dtype = np.dtype(dtype)
-        if self.dtype not in (np.dtype(np.int16), np.dtype(np.int32), np.dtype(np.float32)):
-            raise ValueError("recordings are int16 / int32 PCM or float32 frames")
+        if self.dtype not in (np.dtype(np.int16), np.dtype(np.int32)):
+            raise ValueError("recordings are int16 / int32 PCM frames (other sample types: HRIR.open_recording)")
         self.files = []
         self.tasks = []                    # (speaker, side) in the order HRIR.irs lists them
         pair_offsets, speakers, columns = [], [], []
@@ -163,7 +163,7 @@ class ResidentSlice:
         self.ctx = self.plan.ctx
         self.max_measurements = int(max_measurements)
         self.delays = [int(np.round(SPEAKER_DELAYS[sp] * fs)) + self.head for sp in layout.speakers]
-        self.bits = {np.dtype(np.int16): 16, np.dtype(np.int32): 32, np.dtype(np.float32): 0}[layout.dtype]
+        self.bits = {np.dtype(np.int16): 16, np.dtype(np.int32): 32}[layout.dtype]
         self.firs = None
         self.decay = None
         self.align = False
@@ -312,7 +312,7 @@ class ResidentSlice:
         if recordings is None:
             return None
         f, start, length, tr = self.layout.columns[q]
-        scale = 1.0 if self.layout.dtype == np.float32 else 1.0 / float(2 ** (8 * self.layout.dtype.itemsize - 1))
+        scale = 1.0 / float(2 ** (8 * self.layout.dtype.itemsize - 1))
         return lambda: np.asarray(recordings[m][f])[start:start + length, tr + s].astype(np.float64) * scale
 
     def _warn_sides(self, rows):

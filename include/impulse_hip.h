@@ -483,7 +483,7 @@ typedef struct imp_slice imp_slice;
 typedef struct imp_slice_geometry {
   int64_t n_pairs;               /* ear pairs per measurement */
   int64_t elem_stride;           /* samples between consecutive frames of one ear (= tracks of the recordings) */
-  int bits;                      /* 16 / 32: PCM as in imp_conv_execute_device_pcm; 0: float32 frames */
+  int bits;                      /* 16 / 32: PCM frames as in imp_conv_execute_device_pcm */
   const int64_t* pair_offset;    /* [n_pairs] sample offset of the left ear's first sample from the measurement's base */
   const int64_t* delay;          /* [n_pairs] int(round(SPEAKER_DELAYS[speaker] * fs)) + head (core/hrir.py:566-567) */
   int64_t head;                  /* int(head_ms * fs / 1000) */
