@@ -117,6 +117,30 @@ class WavMeasurements:
         self.files = [list(f) if isinstance(f, (list, tuple)) else [f] for f in files]
         self.fs = fs
 
+    @classmethod
+    def from_dirs(cls, dir_paths, fs=None):
+        """(measurements, speakers_per_file) for measurement DIRECTORIES as the reference lays them out
+        (core/pipeline_stages.py:504-522 open_binaural_measurements): every file named `<speaker list>.wav` (FL,FR.wav,
+        FC.wav, ...) is one recording of the measurement, its speakers taken from the name, in the directory's listing
+        order.  All directories must hold the same file names (one layout per job)."""
+        import os
+        import re
+        from .room_correction import SPEAKER_LIST_PATTERN
+        pattern = re.compile(rf"^{SPEAKER_LIST_PATTERN}\.wav$")
+        names = None
+        files = []
+        for d in dir_paths:
+            found = [f for f in os.listdir(d) if pattern.match(f)]
+            if not found:
+                raise ValueError("No HRIR recordings found in the directory.")
+            if names is None:
+                names = found
+            elif sorted(found) != sorted(names):
+                raise ValueError(f"{d}: recordings {sorted(found)} differ from the job's layout {sorted(names)}")
+            files.append([os.path.join(d, f) for f in names])
+        speakers = [re.search(SPEAKER_LIST_PATTERN, f)[0].split(",") for f in names]
+        return cls(files, fs), speakers
+
     def __len__(self):
         return len(self.files)
 

@@ -745,6 +745,32 @@ def test_job_from_wav_files_on_disk(tmp_path):
                     assert_same_as_staged(got[m], want)
         finally:
             runner.close()
+    # measurement directories as the reference lays them out: <speaker list>.wav files, speakers from the names
+    dirs = []
+    for m in range(2):
+        d = tmp_path / f"measurement{m}"
+        d.mkdir()
+        write_wav_frames(str(d / "FL,FR.wav"), fs, synth_frames(e, ["FL", "FR"], 1900 + m), 32)
+        write_wav_frames(str(d / "FC.wav"), fs, synth_frames(e, ["FC"], 1950 + m), 32)
+        (d / "notes.txt").write_text("not a recording")
+        dirs.append(str(d))
+    job, spk_per_file = WavMeasurements.from_dirs(dirs, fs=fs)
+    assert sorted(map(tuple, spk_per_file)) == [("FC",), ("FL", "FR")] and len(job) == 2
+    layout = job.layout(e, spk_per_file)
+    firs = synth_firs(layout.tasks, _fir_taps(fs), 29)
+    runner = SlicePipeline(e, layout)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = runner.run(job, firs, align=True)
+            for m in range(2):
+                want = run_slice(e, [(p, sp) for p, sp in zip(job.files[m], spk_per_file)], firs=firs, align=True)
+                assert_same_as_staged(got[m], want)
+    finally:
+        runner.close()
+    (tmp_path / "measurement1" / "SL,SR.wav").write_bytes(b"")
+    with pytest.raises(ValueError, match="differ"):
+        WavMeasurements.from_dirs(dirs)
     odd = str(tmp_path / "float.wav")
     write_wav(odd, fs, np.zeros((2, 1000)), bit_depth=24)
     with pytest.raises(ValueError, match="PCM"):
