@@ -121,3 +121,24 @@ def run_slice(estimator, recordings, room_frs=None, target=None, head_ms=1, deca
     gain = hrir.normalize(peak_target=peak_target)
     snap("normalize")
     return hrir, gain
+
+
+def run_measurement_dirs(estimator, dir_paths, room_frs=None, target=None, head_ms=1, decay=None, peak_target=-0.1,
+                         hp_left=None, hp_right=None, eq_left=None, eq_right=None, align=True):
+    """The same stage sequence for MANY measurement directories of one layout (a listener measured again, a room measured at
+    several seats), each laid out as `open_binaural_measurements` reads it (core/pipeline_stages.py:504-522: `<speaker
+    list>.wav` files): the equalisation FIRs are designed once (the curves belong to the job), the recordings are read,
+    uploaded, run through the device-resident sequence (imp_slice) and brought back as overlapping stages - one pipeline
+    per device of IMPULSE_HIP_DEVICES.  Returns [(HRIR, gain dB)] in the order of dir_paths; every result is what
+    run_slice gives for that directory with the same arguments (align defaults to True here: the reference's flow runs
+    the two alignments between crop_heads and crop_tails)."""
+    from .resident_slice import WavMeasurements, run_slice_jobs
+    job, speakers = WavMeasurements.from_dirs(dir_paths, fs=estimator.fs)
+    layout = job.layout(estimator, speakers)
+    fs = estimator.fs
+    common = FrequencyResponse.generate_frequencies(f_min=10, f_max=fs / 2, f_step=1.01)
+    if target is None:
+        target = FrequencyResponse(name="target", frequency=common.copy(), raw=0)
+    firs = {(sp, sd): fir for sp, sd, fir in process_equalization_batch(layout.tasks, room_frs, hp_left, hp_right, eq_left, eq_right,
+                                                                        target, common, fs, on_device=True)}
+    return run_slice_jobs(estimator, layout, job, firs, head_ms=head_ms, peak_target=peak_target, decay=decay, align=align)

@@ -768,6 +768,15 @@ def test_job_from_wav_files_on_disk(tmp_path):
                 assert_same_as_staged(got[m], want)
     finally:
         runner.close()
+    # the whole flow for the directories: FIRs designed once from the (default, flat) target, one call
+    from impulse_hip.pipeline_slice import run_measurement_dirs
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        whole = run_measurement_dirs(e, dirs, decay={"FC": 0.4})
+        for m in range(2):
+            want = run_slice(e, [(p, sp) for p, sp in zip(job.files[m], spk_per_file)], decay={"FC": 0.4}, align=True)
+            assert_same_as_staged(whole[m], want)
+            assert whole[m][0].irs["FC"]["left"].data.dtype == np.float64
     (tmp_path / "measurement1" / "SL,SR.wav").write_bytes(b"")
     with pytest.raises(ValueError, match="differ"):
         WavMeasurements.from_dirs(dirs)
