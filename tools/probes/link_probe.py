@@ -53,3 +53,29 @@ for label, a_up in (("pageable up", src), ("pinned up", src_pinned)):
     [t.start() for t in th]
     [t.join() for t in th]
     print(f"both at once ({label}): up {out['up']:.3f} ms, down {out['down']:.3f} ms")
+
+# the upload cut in two halves on two streams (two host threads)
+up2_ctx = _native.Context(_native.default_device())
+half = (UP // 8) * 4
+
+
+def up_half(ctx, lo, hi, a, n):
+    for _ in range(n):
+        ctx.h2d(d_up + lo, a.view(np.uint8)[lo:hi])
+
+
+def up_split(a, n=N):
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=up_half, args=(up_ctx, 0, half, a, n)), threading.Thread(target=up_half, args=(up2_ctx, half, UP, a, n))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+up_split(src, 3)
+print(f"up in two halves on two streams, pageable: {up_split(src):.3f} ms; page-locked: {up_split(src_pinned):.3f} ms")
+th = threading.Thread(target=lambda: out.__setitem__("down", down(3 * N)))
+th.start()
+both = up_split(src)
+th.join()
+print(f"the same with the download running: up {both:.3f} ms, down {out['down']:.3f} ms")
