@@ -576,3 +576,44 @@ def test_alignment_tables_of_a_layout():
     assert leader == [-1, -1, -1, -1, 4, 4]                           # SR / WR: their groups' first speakers are absent
     with pytest.raises(RuntimeError):
         alignment_tables(["FR", "FC"])
+
+
+def test_wav_measurements_read_files_and_directories(tmp_path):
+    """WavMeasurements on the CPU: lazy reads of PCM files in wire order, the layout of a job from its first measurement,
+    directories as open_binaural_measurements lists them (core/pipeline_stages.py:504-522), refusals with the reason."""
+    from impulse_hip.audio_io import write_wav, write_wav_frames
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.resident_slice import WavMeasurements
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=0.5, fs=fs)
+    n = 2 * fs + 2 * (len(e) + 2 * fs)
+    rng = np.random.default_rng(3)
+    dirs = []
+    for m in range(2):
+        d = tmp_path / f"m{m}"
+        d.mkdir()
+        write_wav_frames(str(d / "FL,FR.wav"), fs, rng.integers(-2 ** 20, 2 ** 20, (n, 2)).astype(np.int32), 32)
+        write_wav_frames(str(d / "FC.wav"), fs, rng.integers(-2 ** 20, 2 ** 20, (fs * 2 + len(e) + 2 * fs, 2)).astype(np.int32), 32)
+        (d / "README.md").write_text("x")
+        dirs.append(str(d))
+    job, speakers = WavMeasurements.from_dirs(dirs, fs=fs)
+    assert len(job) == 2 and sorted(map(tuple, speakers)) == [("FC",), ("FL", "FR")]
+    first = job[0]
+    assert [f.dtype for f in first] == [np.dtype("<i4")] * 2 and all(f.ndim == 2 and f.shape[1] == 2 for f in first)
+    layout = job.layout(e, speakers)
+    assert sorted(layout.speakers) == ["FC", "FL", "FR"] and layout.tracks == 2 and layout.dtype == np.int32
+    assert layout.samples == sum(f.size for f in first)
+    assert len(job[1:]) == 1 and len(list(job)) == 2
+    with pytest.raises(ValueError, match="sampling rate"):
+        WavMeasurements(job.files, fs=44100)[0]
+    odd = str(tmp_path / "pcm24.wav")
+    write_wav(odd, fs, np.zeros((2, 100)), bit_depth=24)
+    with pytest.raises(ValueError, match="PCM"):
+        WavMeasurements([[odd]])[0]
+    (tmp_path / "m1" / "SL,SR.wav").write_bytes(b"")
+    with pytest.raises(ValueError, match="differ"):
+        WavMeasurements.from_dirs(dirs)
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    with pytest.raises(ValueError, match="No HRIR recordings"):
+        WavMeasurements.from_dirs([str(empty)])
