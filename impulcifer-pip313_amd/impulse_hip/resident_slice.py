@@ -412,7 +412,6 @@ class SliceRunner:
         self.estimator, self.layout = estimator, layout
         self.head_ms, self.peak_target = head_ms, peak_target
         self.lanes = []
-        self._job = None
         self._lock = threading.Lock()
         self._run_lock = threading.Lock()
         self.pool = _native.PinnedPool(pinned_mb)
@@ -579,7 +578,6 @@ class SlicePipeline:
         self.head_ms, self.peak_target, self.keep_cap = head_ms, peak_target, keep_cap
         self.depth = max(2, int(depth))
         self.pool = _native.PinnedPool(pinned_mb)
-        self._q = queue
         self.free_rec, self.uploaded, self.free_packed, self.packed = queue.Queue(), queue.Queue(), queue.Queue(), queue.Queue()
         self.jobs = [queue.Queue() for _ in range(2)]       # compute, upload; the download stage takes its jobs from the items
         self._submit = threading.Lock()
@@ -632,7 +630,6 @@ class SlicePipeline:
     # ---- stage 1: the link, upward
     def _upload(self):
         ctx = self.ctxs[1] = _native.Context(self.device)
-        item = self.layout.dtype.itemsize
         with _native.using_context(ctx):
             while True:
                 job = self.jobs[1].get()
