@@ -658,15 +658,18 @@ class SlicePipeline:
         rs, ctx = self.rs, self.ctxs[0]
         R, cap = rs.slice.rows, rs.slice.out_len_max
         others = [] if held is None else [self.free_packed.get() for _ in range(self.depth - 1)]
-        for ptr in [getattr(self, "d_out", 0)] + list(getattr(self, "d_packed", [])):
-            if ptr:
-                ctx.free(ptr)
-        self.d_out = ctx.malloc(R * rs.out_pitch * 4)
-        self.d_packed = [ctx.malloc(R * cap * 8) for _ in range(self.depth)]
-        ctx.synchronize()
-        self.cap = cap
-        for j in (range(self.depth) if held is None else others):
-            self.free_packed.put(j)
+        try:
+            for ptr in [getattr(self, "d_out", 0)] + list(getattr(self, "d_packed", [])):
+                if ptr:
+                    ctx.free(ptr)
+            self.d_out, self.d_packed, self.cap = 0, [], None
+            self.d_out = ctx.malloc(R * rs.out_pitch * 4)
+            self.d_packed = [ctx.malloc(R * cap * 8) for _ in range(self.depth)]
+            ctx.synchronize()
+            self.cap = cap
+        finally:                                           # (an allocation that fails must not strand the ring's indices)
+            for j in (range(self.depth) if held is None else others):
+                self.free_packed.put(j)
 
     def _compute(self):
         from .pipeline_slice import run_slice
@@ -711,7 +714,7 @@ class SlicePipeline:
                         def once():
                             if not host:
                                 return rs.execute_device(self.d_rec[k], 1)
-                            if self.cap != rs.slice.out_len_max:      # grown by a job that left its rows on the device
+                            if self.cap != rs.slice.out_len_max:      # grown by a job that left its rows on the device, or a failed re-make
                                 self._rings(held=j)
                             rs.execute_device(self.d_rec[k], 1, self.d_out)
                             rs.slice.pack_f64(self.d_out, rs.out_pitch, 1, self.d_packed[j], rs.slice.rows * self.cap)
