@@ -556,6 +556,58 @@ def test_resident_slice_random_layouts_against_the_oracle():
     assert checked >= 8
 
 
+def test_slice_refuses_bad_arguments_loudly():
+    """The C entry points of the slice say what is wrong instead of computing something: no FIRs yet, a decay target that is
+    not a positive time, more measurements than the slice was made for, an output pitch below keep_cap + taps - 1, a pack
+    call that does not match the last execute, an onset leader out of range."""
+    from impulse_hip.impulse_response_estimator import ImpulseResponseEstimator
+    from impulse_hip.resident_slice import Layout, ResidentSlice, _fir_taps
+    from impulse_hip import _native
+    fs = 48000
+    e = ImpulseResponseEstimator(min_duration=1.0, fs=fs)
+    spk = ["FL", "FR"]
+    fr = synth_frames(e, spk, 77)
+    layout = Layout(e, [(fr.shape[0], 2, spk)])
+    rs = ResidentSlice(e, layout, max_measurements=2)
+    ctx = rs.ctx
+    sl = rs.slice
+    d_rec = ctx.malloc(2 * layout.samples * 4)
+    ctx.h2d(d_rec, layout.pack([fr]))
+    ctx.h2d(d_rec + layout.samples * 4, layout.pack([fr]))
+    d_out = ctx.malloc(2 * sl.rows * rs.out_pitch * 4)
+    with pytest.raises(_native.NativeError, match="no FIRs"):
+        sl.execute_device(d_rec, layout.samples, 1, d_out, rs.out_pitch)
+    rs.set_firs(synth_firs(layout.tasks, _fir_taps(fs), 1))
+    with pytest.raises(_native.NativeError, match="capacity"):
+        sl.execute_device(d_rec, layout.samples, 3, d_out, rs.out_pitch)
+    with pytest.raises(_native.NativeError, match="out_pitch"):
+        sl.execute_device(d_rec, layout.samples, 1, d_out, sl.out_len_max - 1)
+    with pytest.raises(_native.NativeError, match="positive time"):
+        sl.set_decay([0.3, -1.0, np.nan, np.nan])
+    with pytest.raises(ValueError):
+        sl.set_decay([0.3])
+    with pytest.raises(_native.NativeError, match="out of range"):
+        sl.set_alignment([(0, 1)], [5, -1], 0, 1440)
+    with pytest.raises(_native.NativeError, match="reference pair"):
+        sl.set_alignment([(0, 1)], [-1, -1], 2, 1440)
+    sl.execute_device(d_rec, layout.samples, 2, d_out, rs.out_pitch)
+    d_pk = ctx.malloc(2 * sl.rows * sl.out_len_max * 8)
+    with pytest.raises(_native.NativeError, match="last call"):
+        sl.pack_f64(d_out, rs.out_pitch, 1, d_pk, sl.rows * sl.out_len_max)
+    with pytest.raises(_native.NativeError, match="too small"):
+        sl.pack_f64(d_out, rs.out_pitch, 2, d_pk, sl.rows * sl.out_len_max - 1)
+    sl.pack_f64(d_out, rs.out_pitch, 2, d_pk, sl.rows * sl.out_len_max)
+    rows, meas = sl.results()
+    assert len(meas) == 2 and np.array_equal(meas["out_len"][0:1], meas["out_len"][1:2])       # the same recording twice
+    for p in (d_rec, d_out, d_pk):
+        ctx.free(p)
+    rs.close()
+    with pytest.raises(ValueError, match="PCM"):
+        Layout(e, [(fr.shape[0], 2, spk)], dtype=np.float32)
+    with pytest.raises(ValueError, match="twice"):
+        Layout(e, [(fr.shape[0], 2, spk), (fr.shape[0], 2, ["FL", "FC"])])
+
+
 def test_decay_times_of_device_rows_have_the_bits_of_their_float64_copies():
     from impulse_hip import _native
     from impulse_hip.decay import decay_params, decay_times
