@@ -829,6 +829,13 @@ def test_job_from_wav_files_on_disk(tmp_path):
             want = run_slice(e, [(p, sp) for p, sp in zip(job.files[m], spk_per_file)], decay={"FC": 0.4}, align=True)
             assert_same_as_staged(whole[m], want)
             assert whole[m][0].irs["FC"]["left"].data.dtype == np.float64
+            # ... down to the files the reference's flow ends with (core/pipeline.py:865-876): hrir.wav and hesuvi.wav
+            from impulse_hip.constants import HESUVI_TRACK_ORDER
+            for name, order in (("hrir", None), ("hesuvi", HESUVI_TRACK_ORDER)):
+                a, b = str(tmp_path / f"{name}_{m}_resident.wav"), str(tmp_path / f"{name}_{m}_staged.wav")
+                whole[m][0].write_wav(a, track_order=order)
+                want[0].write_wav(b, track_order=order)
+                assert open(a, "rb").read() == open(b, "rb").read(), (name, m)
     (tmp_path / "measurement1" / "SL,SR.wav").write_bytes(b"")
     with pytest.raises(ValueError, match="differ"):
         WavMeasurements.from_dirs(dirs)
