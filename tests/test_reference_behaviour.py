@@ -109,6 +109,47 @@ def test_shift_delays_advances_and_keeps_the_length(gpu_ctx):
     assert np.array_equal(ir.data, x) and len(ir) == 8
 
 
+def _on_device(ctx, h):
+    """the responses of an HRIR as rows of one device block (what the classes hold between the stages of a measurement)"""
+    from impulse_hip.device_rows import DeviceBlock, Row
+    from impulse_hip.impulse_response import ImpulseResponse
+    names = [(sp, sd) for sp in h.irs for sd in h.irs[sp]]
+    pitch = max(len(h.irs[sp][sd].data) for sp, sd in names) + 64
+    flat = np.zeros(pitch * len(names), dtype=np.float32)
+    for i, (sp, sd) in enumerate(names):
+        flat[i * pitch:i * pitch + len(h.irs[sp][sd].data)] = h.irs[sp][sd].data
+    block = DeviceBlock(ctx, flat.size)
+    ctx.h2d(block.ptr, flat)
+    for i, (sp, sd) in enumerate(names):
+        h.irs[sp][sd] = ImpulseResponse.on_device(Row(block, i * pitch, len(h.irs[sp][sd])), FS)
+    return h
+
+
+def test_ipsilateral_alignment_and_shift_on_device_rows(gpu_ctx):
+    """the two properties above (tests/test_dsp_stages.py:105-166) for responses that are rows of a device block: the lag
+    search, the shifts and the onset alignment leave them there"""
+    n, late = 2048, 7
+    h = _on_device(gpu_ctx, _hrir({"FL": {"left": _pulse(n, 60), "right": _pulse(n, 60)},
+                                   "FR": {"left": _pulse(n, 60), "right": _pulse(n, 60 + late)},
+                                   "SL": {"left": _pulse(n, 90), "right": _pulse(n, 95)}}))
+    h.align_ipsilateral_all(speaker_pairs=[("FL", "FR")])
+    assert all(ir._data is None and ir._row is not None for pair in h.irs.values() for ir in pair.values())
+    a, b = h.irs["FL"]["left"].peek(), h.irs["FR"]["right"].peek()
+    seg = int(FS * 30 / 1000)
+    corr = np.correlate(a[:seg], b[:seg], mode="full")
+    assert abs(int(np.arange(-seg + 1, seg)[np.argmax(corr)])) <= 1
+    assert all(len(ir) == n for pair in h.irs.values() for ir in pair.values())
+    h.align_onset_groups_peak_leftref()
+    assert all(ir._data is None and ir._row is not None for pair in h.irs.values() for ir in pair.values())
+    assert int(np.argmax(np.abs(h.irs["SL"]["left"].peek()))) == int(np.argmax(np.abs(h.irs["FL"]["left"].peek())))
+    x = np.arange(1.0, 9.0)
+    for amount, want in ((3, [0, 0, 0, 1, 2, 3, 4, 5]), (-3, [4, 5, 6, 7, 8, 0, 0, 0]), (0, x), (9, np.zeros(8)), (-8, np.zeros(8))):
+        one = _on_device(gpu_ctx, _hrir({"FL": {"left": x.copy(), "right": x.copy()}}))
+        ir = one.irs["FL"]["left"]
+        ir.shift(amount)
+        assert ir._data is None and np.array_equal(ir.peek(), want) and len(ir) == 8, amount
+
+
 def test_a_recording_at_another_sampling_rate_is_refused(gpu_ctx, tmp_path):
     """tests/test_dsp_stages.py:171-184 and tests/test_dsp_characterization.py:220-226"""
     from impulse_hip.audio_io import write_wav
